@@ -1,0 +1,272 @@
+// Shared device-side building blocks for the MI355X (gfx950 / CDNA4) kernels.
+//
+// Execution model used by every MLP kernel in this library
+// ---------------------------------------------------------
+//   * one WAVE (64 lanes) owns 32 points for a whole pass through a network; a workgroup is 4 waves
+//     (one per SIMD, up to 512 unified VGPR+AGPR each);
+//   * activations never leave registers between layers.  A layer is out^T[N x 32] = W[N x K] * in^T[K x 32]
+//     computed with v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF/s peak): A operand = W, B operand = activations.
+//     The MFMA C/D layout (lane = point m + 32*hi, register r <-> row (r&3) + 8*(r>>2) + 4*hi) is, after a fixed
+//     permutation of the reduction index, exactly the B-operand layout of the next layer, so the output
+//     registers of layer l (after the activation function) are fed straight back as B operands of layer l+1;
+//   * weights are pre-packed ("streams") in the exact order the MFMAs consume them: one CHUNK = 64 lanes x 16 B
+//     = the A operands of 4 consecutive MFMAs.  A workgroup DMAs the stream global->LDS (global_load_lds,
+//     no VGPR round trip) in 32 KB stages, double buffered, one barrier per stage; the 4 waves share it.
+//
+// Register <-> index maps (hi = lane>>5, r = 4q+t):
+//   D-layout tile nt, reg r   <->  feature index 32*nt + 8*q + 4*hi + t
+//   chunk kc, element t        <->  reduction index 8*kc + 4*hi + t         (so chunk kc = 4*nt + q)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace i2sdf {
+
+constexpr int SC = 32;                    // chunks per LDS stage
+constexpr int CHUNK_FLOATS = 256;         // 64 lanes x 4 floats
+constexpr int STAGE_FLOATS = SC * CHUNK_FLOATS;   // 32 KB
+constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;   // double buffer
+constexpr int PF = 4;                     // ds_read prefetch depth (chunks)
+constexpr int WG_THREADS = 256;
+constexpr int PTS_PER_WAVE = 32;
+constexpr int PTS_PER_WG = 128;
+
+__host__ __device__ constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+__host__ __device__ constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// chunks of one dense op in a stream: [NT*4 bias chunks][NT*KC weight chunks], padded to whole stages
+__host__ __device__ constexpr int op_chunks(int NT, int KC) { return round_up(NT * 4 + NT * KC, SC); }
+// a row-vector op: [KC weight chunks][1 scalar chunk]
+__host__ __device__ constexpr int rowvec_chunks(int KC, int nrows) { return round_up(nrows * KC + 1, SC); }
+
+#define I2SDF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#define I2SDF_MASK_MFMA 0x008
+#define I2SDF_MASK_DSREAD 0x100
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight stream: linear walk over a packed buffer, global -> LDS by DMA, double buffered.
+// ---------------------------------------------------------------------------------------------
+struct WStream {
+  const float* g;     // next stage to fetch
+  float* lds;         // two STAGE_FLOATS buffers
+  int cur;            // buffer that the NEXT advance() returns
+  int left;           // stages still to be fetched
+
+  __device__ __forceinline__ void issue(float* dst, int tid) {
+    const float* src = g + tid * 4;
+    float* d = dst + (tid & ~63) * 4;     // wave-uniform LDS base; hardware adds lane*16 B
+#pragma unroll
+    for (int i = 0; i < STAGE_FLOATS / (WG_THREADS * 4); ++i) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * WG_THREADS * 4),
+                                       (__attribute__((address_space(3))) void*)(d + i * WG_THREADS * 4), 16, 0, 0);
+    }
+    g += STAGE_FLOATS;
+  }
+  // n_stages = total stages this kernel will consume from `base`
+  __device__ __forceinline__ void begin(const float* base, float* lds_, int n_stages, int tid) {
+    g = base; lds = lds_; cur = 0; left = n_stages;
+    if (left > 0) { issue(lds, tid); --left; }
+  }
+  // Returns the LDS buffer holding the next stage.  All 4 waves must call this in lock step.
+  __device__ __forceinline__ const float* advance(int tid) {
+    __syncthreads();      // (a) my DMA for this stage landed (hipcc drains vmcnt before the barrier),
+                          // (b) every wave's did, (c) every wave finished reading the other buffer
+    const float* ret = lds + cur * STAGE_FLOATS;
+    if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
+    cur ^= 1;
+    return ret;
+  }
+  // skip `n` stages without computing (still in lock step)
+  __device__ __forceinline__ void skip(int n, int tid) {
+    for (int i = 0; i < n; ++i) (void)advance(tid);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// One dense op:  acc[NT] (+)= bias + W * in     (32 points per wave, all in registers)
+//   stream layout of the op: [NT*4 bias chunks][NT*KC weight chunks] padded to whole stages
+//   MODE 0: acc = bias + W*in     MODE 1: acc = W*in (bias chunks skipped)    MODE 2: acc += W*in
+// ---------------------------------------------------------------------------------------------
+template <int NT, int KC, int MODE>
+__device__ __forceinline__ void dense_op(WStream& ws, const float (&in)[KC * 4], f32x16 (&acc)[NT], int tid) {
+  constexpr int NB = NT * 4, NW = NT * KC, TOT = op_chunks(NT, KC), NS = TOT / SC;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+    // ---- bias chunks of this stage
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < NB) {
+        const int nt = c / 4, q = c % 4;
+        if (MODE == 0) {
+          f32x4 b = cur[j * 64];
+          acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+        } else if (MODE == 1) {
+          acc[nt][4 * q + 0] = 0.f; acc[nt][4 * q + 1] = 0.f; acc[nt][4 * q + 2] = 0.f; acc[nt][4 * q + 3] = 0.f;
+        }
+      }
+    }
+    // ---- weight chunks of this stage: [j0, j1) within the stage
+    constexpr int dummy = 0; (void)dummy;
+    const int j0 = (s * SC < NB) ? ((NB - s * SC < SC) ? NB - s * SC : SC) : 0;
+    const int j1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? NB + NW - s * SC : 0) : SC;
+    f32x4 ab[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (j0 + i < j1) ab[i] = cur[(j0 + i) * 64];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j >= j0 && j < j1) {
+        const int w = s * SC + j - NB;
+        const int nt = w / KC, kc = w % KC;
+        f32x4 a = ab[(j - j0) % PF];
+        if (j + PF < j1) ab[(j - j0) % PF] = cur[(j + PF) * 64];
+        acc[nt] = mfma(a.x, in[kc * 4 + 0], acc[nt]);
+        acc[nt] = mfma(a.y, in[kc * 4 + 1], acc[nt]);
+        acc[nt] = mfma(a.z, in[kc * 4 + 2], acc[nt]);
+        acc[nt] = mfma(a.w, in[kc * 4 + 3], acc[nt]);
+      }
+    }
+    // pin the software pipeline: PF reads up front, then {4 MFMA, 1 read} per chunk
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (j0 + i < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j >= j0 && j < j1) {
+        I2SDF_SGB(I2SDF_MASK_MFMA, 4);
+        if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+      }
+    }
+  }
+}
+
+// Row-vector op: out[row] = sum_k w_row[k] * in[k] (+ scalar), VALU dot product + one cross-half exchange.
+// stream layout: [NROWS*KC chunks: element t of chunk (row,kc) = w_row[8kc+4hi+t]][1 chunk: {s0,s1,s2,s3}]
+template <int NROWS, int KC>
+__device__ __forceinline__ void rowvec_op(WStream& ws, const float (&in)[KC * 4], float (&out)[NROWS], int tid) {
+  constexpr int TOT = rowvec_chunks(KC, NROWS), NS = TOT / SC, NW = NROWS * KC;
+  const int lane = tid & 63;
+  float part[NROWS];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) part[r] = 0.f;
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < NW) {
+        const int row = c / KC, kc = c % KC;
+        f32x4 w = cur[j * 64];
+        part[row] = fmaf(w.x, in[kc * 4 + 0], part[row]);
+        part[row] = fmaf(w.y, in[kc * 4 + 1], part[row]);
+        part[row] = fmaf(w.z, in[kc * 4 + 2], part[row]);
+        part[row] = fmaf(w.w, in[kc * 4 + 3], part[row]);
+      } else if (c == NW) {
+        sc = cur[j * 64];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    float v = part[r] + __shfl_xor(part[r], 32);
+    out[r] = v + (r == 0 ? sc.x : r == 1 ? sc.y : r == 2 ? sc.z : sc.w);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// activations
+// ---------------------------------------------------------------------------------------------
+// nn.Softplus(beta=100, threshold=20): log1p(exp(100a))/100, identity above the threshold (mlp.py:76).
+// log1p through the compensated form log(u) * z/(u-1), u = fl(1+z): ~1 ulp without a slow-path call.
+__device__ __forceinline__ float softplus100(float a) {
+  const float t = 100.f * a;
+  const float z = __builtin_amdgcn_exp2f(t * 1.44269504088896341f);
+  const float u = 1.0f + z;
+  const float d = u - 1.0f;
+  const float lg = __builtin_amdgcn_logf(u) * (0.693147180559945309f * 0.01f);
+  float r = lg * (z * __builtin_amdgcn_rcpf(d));
+  r = (d == 0.f) ? z * 0.01f : r;
+  return (t > 20.f) ? a : r;
+}
+// sigma = softplus100'(a) recovered from h = softplus100(a):  1 - exp(-100 h)   (exactly 1 in the threshold
+// branch up to rounding: 1 - e^-20 rounds to 1.0f).
+__device__ __forceinline__ float sp_sigma_from_h(float h) {
+  return 1.0f - __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * h);
+}
+
+// ---------------------------------------------------------------------------------------------
+// positional encoding in B-operand layout -- embedder.py:6-38 (include_input, log-sampled powers of two,
+// [sin, cos] per frequency, each block 3 wide).  PEC = chunks (8 reduction indices each), zero padded.
+// ---------------------------------------------------------------------------------------------
+template <int LF>
+struct PE {
+  static constexpr int DIM = 3 + 6 * LF;
+  static constexpr int PEC = cdiv(DIM, 8);
+};
+
+template <int LF>
+__device__ __forceinline__ void pe_full(float x, float y, float z, float (&full)[PE<LF>::PEC * 8]) {
+#pragma unroll
+  for (int i = 0; i < PE<LF>::PEC * 8; ++i) full[i] = 0.f;
+  full[0] = x; full[1] = y; full[2] = z;
+#pragma unroll
+  for (int k = 0; k < LF; ++k) {
+    const float f = (float)(1 << k);
+    full[3 + 6 * k + 0] = sinf(x * f); full[3 + 6 * k + 1] = sinf(y * f); full[3 + 6 * k + 2] = sinf(z * f);
+    full[3 + 6 * k + 3] = cosf(x * f); full[3 + 6 * k + 4] = cosf(y * f); full[3 + 6 * k + 5] = cosf(z * f);
+  }
+}
+template <int NC>
+__device__ __forceinline__ void to_b_layout(const float (&full)[NC * 8], float (&regs)[NC * 4], int hi) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) regs[c * 4 + t] = hi ? full[8 * c + 4 + t] : full[8 * c + t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// D-layout tile <-> point-major HBM rows ([m][ld] fp32): 16 B per lane per (nt,q); a 128 B line is
+// completed by the 4 q-stores of one tile.
+// ---------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void store_tile(float* __restrict__ row, int hi, bool valid, const f32x16 (&t)[NT]) {
+  if (!valid) return;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {t[nt][4 * q], t[nt][4 * q + 1], t[nt][4 * q + 2], t[nt][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q + 4 * hi) = v;
+    }
+}
+template <int NC>
+__device__ __forceinline__ void store_regs(float* __restrict__ row, int hi, bool valid, const float (&r)[NC * 4]) {
+  if (!valid) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    f32x4 v = {r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]};
+    *reinterpret_cast<f32x4*>(row + 8 * c + 4 * hi) = v;
+  }
+}
+template <int NC>
+__device__ __forceinline__ void load_regs(const float* __restrict__ row, int hi, float (&r)[NC * 4]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * c + 4 * hi);
+    r[4 * c] = v.x; r[4 * c + 1] = v.y; r[4 * c + 2] = v.z; r[4 * c + 3] = v.w;
+  }
+}
+
+}  // namespace i2sdf

@@ -1,0 +1,104 @@
+// SDF network forward without gradient: ImplicitNetwork.forward / get_sdf_vals
+// (model/network/mlp.py:84-105,145-151).  MFMA-bound: 2*524544 FLOP per point at synthetic.yml shapes.
+#include "plan.h"
+
+using namespace i2sdf;
+
+int i2sdf_hip_check(hipError_t e, const char* what);
+
+namespace {
+
+template <int N>
+__device__ __forceinline__ void softplus_tiles(const f32x16 (&acc)[N], float (&h)[N * 16]) {
+#pragma unroll
+  for (int nt = 0; nt < N; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(acc[nt][r]);
+}
+
+// stages consumed by the forward pass (must mirror build_sdf() in plan.cpp)
+__host__ __device__ constexpr int sdf_fwd_stages(int H, int F, int PEC, int L, bool has_skip, bool full) {
+  int c = op_chunks(H / 32, PEC);
+  for (int l = 1; l < L - 1; ++l) c += op_chunks(H / 32, H / 8);
+  if (has_skip) c += op_chunks(H / 32, H / 8 + PEC) - op_chunks(H / 32, H / 8);
+  c += rowvec_chunks(H / 8, 1);
+  if (full) c += op_chunks(F / 32, H / 8);
+  return c / SC;
+}
+
+template <int H, int F, int LF, bool FULL>
+__global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ stream, int n_stages, int L, int skip,
+                                                       const float* __restrict__ points, int64_t M, float* __restrict__ sdf_out,
+                                                       float* __restrict__ feat_out, int64_t ld_feat) {
+  constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
+  const float px = points[mc * 3 + 0], py = points[mc * 3 + 1], pz = points[mc * 3 + 2];
+  float pe[PEC * 4];
+  {
+    float full[PEC * 8];
+    pe_full<LF>(px, py, pz, full);
+    to_b_layout<PEC>(full, pe, hi);
+  }
+  WStream ws;
+  ws.begin(stream, lds, n_stages, tid);
+  f32x16 acc[NT];
+  float h[NT * 16];
+  dense_op<NT, PEC, 0>(ws, pe, acc, tid);
+  softplus_tiles<NT>(acc, h);
+  for (int l = 1; l < L - 1; ++l) {
+    if (l == skip) {
+      constexpr float rs2 = 0.70710678118654752440f;
+      float u[(KC + PEC) * 4];
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * rs2;
+#pragma unroll
+      for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = pe[i] * rs2;
+      dense_op<NT, KC + PEC, 0>(ws, u, acc, tid);
+    } else {
+      dense_op<NT, KC, 0>(ws, h, acc, tid);
+    }
+    softplus_tiles<NT>(acc, h);
+  }
+  float s[1];
+  rowvec_op<1, KC>(ws, h, s, tid);
+  if (sdf_out != nullptr && valid && hi == 0) sdf_out[m] = s[0];
+  if (FULL) {
+    constexpr int FT = F / 32;
+    f32x16 fa[FT];
+    dense_op<FT, KC, 0>(ws, h, fa, tid);
+    store_tile<FT>(feat_out + mc * ld_feat, hi, valid, fa);
+  }
+}
+
+template <int H, int F, int LF>
+int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, const float* points, int64_t M, float* sdf_out, float* feat_out,
+                   int64_t ld_feat, hipStream_t st) {
+  const i2sdf_mlp_desc& d = p->sdf.d;
+  const float* stream = packed + p->scale_floats + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
+  const bool full = feat_out != nullptr;
+  const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (full)
+    sdf_fwd_kernel<H, F, LF, true><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, M, sdf_out, feat_out, ld_feat);
+  else
+    sdf_fwd_kernel<H, F, LF, false><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, M, sdf_out, nullptr, 0);
+  return i2sdf_hip_check(hipGetLastError(), "sdf_forward launch");
+}
+
+}  // namespace
+
+extern "C" int i2sdf_sdf_forward(const i2sdf_plan* p, const float* packed, const float* points, int64_t M, float* sdf_out,
+                                 float* feat_out, int64_t ld_feat, void* stream) {
+  if (!p || !packed || !points || M < 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (feat_out && (ld_feat < p->F || ld_feat % 4)) return I2SDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (p->sdf.d.multires != 6) return I2SDF_EINVAL;
+  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, points, M, sdf_out, feat_out, ld_feat, st);
+  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, points, M, sdf_out, feat_out, ld_feat, st);
+  return I2SDF_EINVAL;
+}

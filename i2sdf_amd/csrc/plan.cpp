@@ -1,0 +1,221 @@
+// Plan construction (host) + the C-ABI entry points that do not launch MLP kernels.
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <string>
+#include "plan.h"
+
+using namespace i2sdf;
+
+static thread_local std::string g_hip_err;
+
+int i2sdf_hip_check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return I2SDF_OK;
+  g_hip_err = std::string(what) + ": " + hipGetErrorString(e);
+  return I2SDF_EHIP;
+}
+
+extern "C" int i2sdf_version(void) { return I2SDF_VERSION; }
+extern "C" const char* i2sdf_last_hip_error(void) { return g_hip_err.c_str(); }
+extern "C" const char* i2sdf_strerror(int code) {
+  switch (code) {
+    case I2SDF_OK: return "ok";
+    case I2SDF_EINVAL: return "invalid argument or unsupported network shape";
+    case I2SDF_EHIP: return "HIP runtime error";
+    case I2SDF_ESPHERE: return "ray misses the scene bounding sphere";
+    case I2SDF_EWORKSPACE: return "workspace too small";
+    default: return "unknown error";
+  }
+}
+
+namespace {
+
+constexpr int32_t HUGE_SPLIT = 1 << 30;
+
+struct Builder {
+  std::vector<Seg>& segs;
+  int64_t chunk;     // running chunk cursor
+  void add(Seg s) { s.chunk0 = chunk; chunk += s.nchunks; segs.push_back(s); }
+  void pad_to_stage() {
+    int64_t r = chunk % SC;
+    if (r) { Seg z{}; z.type = SEG_ZERO; z.nchunks = (int32_t)(SC - r); add(z); }
+  }
+};
+
+Seg base_seg(const NetPlan& np, int l, int type) {
+  Seg s{};
+  s.type = type;
+  s.off_v = np.d.off_v[l]; s.off_bias = np.d.off_bias[l];
+  s.scale_off = np.scale_off[l];
+  s.rows = np.d.out_dim[l]; s.cols = np.d.in_dim[l];
+  s.row_off = 0; s.nrows = s.rows;
+  s.mult = 1.0f;
+  s.cm = ColMap{HUGE_SPLIT, 0, s.cols, 0, 0};
+  return s;
+}
+
+int pe_dim(const i2sdf_mlp_desc& d) { return d.multires > 0 ? d.d_in + 2 * d.d_in * d.multires : d.d_in; }
+int pe_chunks(const i2sdf_mlp_desc& d) { return cdiv(pe_dim(d), 8); }
+
+// dense forward op: [NT*4 bias chunks][NT*KC weight chunks] padded to stages
+void emit_dense_fwd(Builder& b, const NetPlan& np, int l, int NT, int KC, ColMap cm, int row_off, int nrows) {
+  Seg sb = base_seg(np, l, SEG_BIAS);
+  sb.NT = NT; sb.KC = 4; sb.nchunks = NT * 4; sb.used = NT * 4; sb.row_off = row_off; sb.nrows = nrows;
+  b.add(sb);
+  Seg sw = base_seg(np, l, SEG_WFWD);
+  sw.NT = NT; sw.KC = KC; sw.used = NT * KC; sw.nchunks = op_chunks(NT, KC) - NT * 4; sw.cm = cm;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
+// transposed op (no bias): out tiles over the layer's input space, reduction over its output rows
+void emit_dense_bwd(Builder& b, const NetPlan& np, int l, int KT, int NC, ColMap cm, int row_off, int nrows) {
+  Seg sw = base_seg(np, l, SEG_WBWD);
+  sw.NT = KT; sw.KC = NC; sw.used = KT * NC; sw.nchunks = round_up(KT * NC, SC); sw.cm = cm;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
+void emit_rowvec(Builder& b, const NetPlan& np, int l, int nrows, int KC, ColMap cm) {
+  Seg sw = base_seg(np, l, SEG_ROWVEC);
+  sw.NT = nrows; sw.KC = KC; sw.used = nrows * KC; sw.nchunks = nrows * KC; sw.cm = cm; sw.nrows = nrows;
+  b.add(sw);
+  Seg sc = base_seg(np, l, SEG_SCALAR);
+  sc.nchunks = rowvec_chunks(KC, nrows) - nrows * KC; sc.used = 1; sc.nrows = nrows;
+  b.add(sc);
+}
+
+int check_mlp(const i2sdf_mlp_desc& d) {
+  if (d.n_lin < 2 || d.n_lin > I2SDF_MAX_LAYERS) return I2SDF_EINVAL;
+  if (d.hidden % 32 || d.hidden < 32 || d.hidden > 256) return I2SDF_EINVAL;
+  return I2SDF_OK;
+}
+
+// ---- SDF net (ImplicitNetwork with positional encoding) -------------------------------------
+int build_sdf(i2sdf_plan* p, Builder& b) {
+  NetPlan& np = p->sdf;
+  const i2sdf_mlp_desc& d = np.d;
+  const int L = d.n_lin, H = d.hidden, PEC = pe_chunks(d), PED = pe_dim(d);
+  const int F = d.d_out - 1;
+  if (check_mlp(d)) return I2SDF_EINVAL;
+  if (d.multires <= 0 || d.d_in != 3 || d.in0 != PED) return I2SDF_EINVAL;
+  if (F < 0 || F % 32 || F > 256) return I2SDF_EINVAL;
+  if (d.skip_layer == 0 || d.skip_layer >= L - 1) return I2SDF_EINVAL;
+  for (int l = 0; l < L - 1; ++l) {
+    const int want_out = (l + 1 == d.skip_layer) ? H - PED : H;
+    const int want_in = (l == 0) ? PED : H;
+    if (d.out_dim[l] != want_out || d.in_dim[l] != want_in) return I2SDF_EINVAL;
+  }
+  if (d.in_dim[L - 1] != H) return I2SDF_EINVAL;
+  p->H = H; p->F = F;
+  // forward stream
+  np.fwd_chunk0 = b.chunk;
+  for (int l = 0; l < L - 1; ++l) {
+    ColMap cm{HUGE_SPLIT, 0, d.in_dim[l], 0, 0};
+    int KC = (l == 0) ? PEC : H / 8;
+    if (l == d.skip_layer) { cm = ColMap{H, 0, d.in_dim[l] - PED, d.in_dim[l] - PED, PED}; KC += PEC; }
+    emit_dense_fwd(b, np, l, H / 32, KC, cm, 0, d.out_dim[l]);
+  }
+  emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  if (F > 0) emit_dense_fwd(b, np, L - 1, F / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F);
+  np.fwd_chunks = b.chunk - np.fwd_chunk0;
+  // reverse (transposed) stream: [Wfeat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
+  np.rev_chunk0 = b.chunk;
+  if (F > 0) emit_dense_bwd(b, np, L - 1, H / 32, F / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F);
+  np.rev_wsdf_chunk = b.chunk;
+  emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  for (int l = L - 2; l >= 0; --l) {
+    ColMap cm{HUGE_SPLIT, 0, d.in_dim[l], 0, 0};
+    int KT = (l == 0) ? cdiv(PEC * 8, 32) : H / 32;
+    if (l == d.skip_layer) { cm = ColMap{H, 0, d.in_dim[l] - PED, d.in_dim[l] - PED, PED}; KT += cdiv(PEC * 8, 32); }
+    emit_dense_bwd(b, np, l, KT, H / 8, cm, 0, d.out_dim[l]);
+  }
+  np.rev_chunks = b.chunk - np.rev_chunk0;
+  return I2SDF_OK;
+}
+
+// ---- radiance net ('nerf' mode): input [PE(view) | feature] ---------------------------------------
+int build_rgb(i2sdf_plan* p, Builder& b) {
+  NetPlan& np = p->rgb;
+  const i2sdf_mlp_desc& d = np.d;
+  const int L = d.n_lin, H = d.hidden, PEC = pe_chunks(d), PED = pe_dim(d), F = p->F;
+  if (check_mlp(d)) return I2SDF_EINVAL;
+  if (d.skip_layer >= 0 || d.d_out != 3 || d.multires <= 0 || d.in0 != PED + F || F <= 0) return I2SDF_EINVAL;
+  for (int l = 0; l < L - 1; ++l)
+    if (d.out_dim[l] != H || d.in_dim[l] != (l == 0 ? PED + F : H)) return I2SDF_EINVAL;
+  np.fwd_chunk0 = b.chunk;
+  emit_dense_fwd(b, np, 0, H / 32, PEC + F / 8, ColMap{PEC * 8, 0, PED, PED, F}, 0, H);
+  for (int l = 1; l < L - 1; ++l) emit_dense_fwd(b, np, l, H / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H);
+  emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  np.fwd_chunks = b.chunk - np.fwd_chunk0;
+  np.rev_chunk0 = b.chunk;
+  emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  for (int l = L - 2; l >= 1; --l) emit_dense_bwd(b, np, l, H / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H);
+  emit_dense_bwd(b, np, 0, F / 32, H / 8, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H);   // feature columns only
+  np.rev_chunks = b.chunk - np.rev_chunk0;
+  return I2SDF_OK;
+}
+
+// ---- light-mask head: relu(feature) -> [hidden] softplus100 -> 1, sigmoid -----------------------
+int build_light(i2sdf_plan* p, Builder& b) {
+  NetPlan& np = p->light;
+  const i2sdf_mlp_desc& d = np.d;
+  if (d.n_lin == 0) return I2SDF_OK;
+  const int H = d.hidden, F = p->F;
+  if (d.n_lin != 2 || H % 32 || H > 256 || d.d_out != 1 || d.in0 != F || d.multires != 0) return I2SDF_EINVAL;
+  if (d.out_dim[0] != H || d.in_dim[0] != F || d.in_dim[1] != H) return I2SDF_EINVAL;
+  np.fwd_chunk0 = b.chunk;
+  emit_dense_fwd(b, np, 0, H / 32, F / 8, ColMap{HUGE_SPLIT, 0, F, 0, 0}, 0, H);
+  emit_rowvec(b, np, 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  np.fwd_chunks = b.chunk - np.fwd_chunk0;
+  np.rev_chunk0 = b.chunk;
+  emit_rowvec(b, np, 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  np.rev_chunks = b.chunk - np.rev_chunk0;
+  return I2SDF_OK;
+}
+
+void assign_scales_and_wgrad(i2sdf_plan* p, NetPlan& np) {
+  for (int l = 0; l < np.d.n_lin; ++l) {
+    np.scale_off[l] = p->n_scale;
+    p->n_scale += np.d.out_dim[l];
+    // effective-weight gradient block: padded [rows32][cols(+pad to 32)]
+    np.wg_rows[l] = round_up(np.d.out_dim[l], 32);
+    np.wg_cols[l] = round_up(np.d.in_dim[l] + 32, 32);
+    np.wgrad_off[l] = p->wgrad_floats;
+    p->wgrad_floats += (int64_t)np.wg_rows[l] * np.wg_cols[l] + np.wg_rows[l];   // + bias-grad row
+  }
+}
+
+}  // namespace
+
+extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
+  if (!desc || !out) return I2SDF_EINVAL;
+  i2sdf_plan* p = new i2sdf_plan();
+  p->desc = *desc;
+  p->sdf.d = desc->sdf; p->rgb.d = desc->rgb; p->light.d = desc->light;
+  assign_scales_and_wgrad(p, p->sdf);
+  assign_scales_and_wgrad(p, p->rgb);
+  if (desc->light.n_lin) assign_scales_and_wgrad(p, p->light);
+  p->scale_floats = round_up(p->n_scale, CHUNK_FLOATS);
+  Builder b{p->segs, 0};
+  int rc = build_sdf(p, b);
+  if (!rc) rc = build_rgb(p, b);
+  if (!rc) rc = build_light(p, b);
+  if (rc) { delete p; return rc; }
+  { Seg z{}; z.type = SEG_ZERO; z.nchunks = SC; b.add(z); }   // slack: the DMA look-ahead may touch one stage past the end
+  p->total_chunks = b.chunk;
+  p->n_segs = (int32_t)p->segs.size();
+  hipError_t e = hipMalloc((void**)&p->d_segs, sizeof(Seg) * p->segs.size());
+  if (e == hipSuccess) e = hipMemcpy(p->d_segs, p->segs.data(), sizeof(Seg) * p->segs.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { rc = i2sdf_hip_check(e, "plan table upload"); if (p->d_segs) hipFree(p->d_segs); delete p; return rc; }
+  *out = p;
+  return I2SDF_OK;
+}
+
+extern "C" void i2sdf_plan_destroy(i2sdf_plan* p) {
+  if (!p) return;
+  if (p->d_segs) hipFree(p->d_segs);
+  delete p;
+}
+
+extern "C" int64_t i2sdf_plan_pack_floats(const i2sdf_plan* p) {
+  return p ? p->scale_floats + p->total_chunks * CHUNK_FLOATS : 0;
+}
+extern "C" int64_t i2sdf_plan_wgrad_floats(const i2sdf_plan* p) { return p ? p->wgrad_floats : 0; }

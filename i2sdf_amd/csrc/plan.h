@@ -1,0 +1,62 @@
+// Host-side plan: where every packed weight stream lives and how it is produced from the flat parameter
+// buffer.  The kernels walk the streams linearly; the order of ops inside a stream is fixed by the
+// kernel's own static structure (see mlp_fwd.hip), and build_*_stream() below must emit the same order.
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "../../include/i2sdf.h"
+#include "common.h"
+
+namespace i2sdf {
+
+enum SegType : int32_t { SEG_ZERO = 0, SEG_BIAS = 1, SEG_WFWD = 2, SEG_WBWD = 3, SEG_ROWVEC = 4, SEG_SCALAR = 5 };
+
+// Column map from a padded register-space index to a source column of weight_v:
+//   kp <  split : kp < valid0 ? base0 + kp : none
+//   kp >= split : (kp-split) < valid1 ? base1 + (kp-split) : none
+struct ColMap { int32_t split, base0, valid0, base1, valid1; };
+
+struct Seg {
+  int64_t chunk0;        // first chunk of the segment inside the pack buffer
+  int32_t nchunks;       // chunks covered (including its zero padding)
+  int32_t type;
+  int64_t off_v, off_bias;
+  int32_t scale_off;     // index of row 0 of this layer in the row-scale array
+  int32_t rows, cols;    // logical shape of weight_v
+  int32_t row_off;       // first logical row this segment covers (e.g. 1 for the feature rows)
+  int32_t nrows;         // rows covered from row_off (rows beyond are zero)
+  int32_t NT, KC;        // tile geometry: WFWD chunk (nt,kc); WBWD chunk (kt,nc) with NT=#kt, KC=#nc
+  int32_t used;          // chunks that carry data (rest is zero padding)
+  ColMap cm;
+  float mult;
+};
+
+struct LayerGeom {       // per net, per layer: padded geometry shared by pack + kernels
+  int32_t NT;            // output tiles (32 rows each)
+  int32_t KC;            // input chunks (8 cols each)
+};
+
+struct NetPlan {
+  i2sdf_mlp_desc d;
+  int32_t scale_off[I2SDF_MAX_LAYERS];
+  int64_t fwd_chunk0 = 0, fwd_chunks = 0;      // forward stream
+  int64_t rev_chunk0 = 0, rev_chunks = 0;      // transposed / reverse stream
+  int64_t rev_wsdf_chunk = 0;                  // where the igrad chain starts inside rev (sdf net)
+  int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
+  int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
+};
+
+}  // namespace i2sdf
+
+struct i2sdf_plan {
+  i2sdf_net_desc desc;
+  i2sdf::NetPlan sdf, rgb, light;
+  std::vector<i2sdf::Seg> segs;
+  i2sdf::Seg* d_segs = nullptr;      // device copy
+  int32_t n_segs = 0;
+  int32_t n_scale = 0;               // total rows over all layers of all nets
+  int64_t scale_floats = 0;          // region [0, scale_floats) of the pack buffer holds g/||v||
+  int64_t total_chunks = 0;          // chunks after the scale region (+1 stage of slack for the DMA look-ahead)
+  int64_t wgrad_floats = 0;
+  int32_t H = 0, F = 0;              // sdf hidden width / feature size
+};

@@ -1,0 +1,81 @@
+"""ctypes binding of the C ABI declared in include/i2sdf.h (libi2sdf_hip.so, built in-tree by
+i2sdf_amd/csrc/build.sh or __graft_entry__.build()).  No CPU fallback: a missing library or a failing call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_LAYERS = 12
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libi2sdf_hip.so")
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_lin", C.c_int32), ("hidden", C.c_int32), ("d_in", C.c_int32), ("in0", C.c_int32), ("d_out", C.c_int32),
+                ("multires", C.c_int32), ("skip_layer", C.c_int32), ("reserved", C.c_int32),
+                ("out_dim", C.c_int32 * MAX_LAYERS), ("in_dim", C.c_int32 * MAX_LAYERS),
+                ("off_bias", C.c_int64 * MAX_LAYERS), ("off_g", C.c_int64 * MAX_LAYERS), ("off_v", C.c_int64 * MAX_LAYERS)]
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("sdf", MlpDesc), ("rgb", MlpDesc), ("light", MlpDesc), ("off_beta", C.c_int64), ("n_params", C.c_int64),
+                ("beta_min", C.c_float), ("scene_bounding_sphere", C.c_float)]
+
+
+class I2SDFError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes).  Must list every symbol include/i2sdf.h declares (tests/test_cabi.py checks it).
+_P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+SIGNATURES = {
+    "i2sdf_version": (C.c_int, []),
+    "i2sdf_strerror": (C.c_char_p, [C.c_int]),
+    "i2sdf_last_hip_error": (C.c_char_p, []),
+    "i2sdf_plan_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(_P)]),
+    "i2sdf_plan_destroy": (None, [_P]),
+    "i2sdf_plan_pack_floats": (_I64, [_P]),
+    "i2sdf_plan_wgrad_floats": (_I64, [_P]),
+    "i2sdf_pack_weights": (C.c_int, [_P, _P, _P, _P]),
+    "i2sdf_sdf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
+}
+
+
+def load():
+    """Load the HIP library or raise -- there is deliberately no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise I2SDFError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        lib = load()
+        msg = lib.i2sdf_strerror(rc).decode()
+        if rc == -2:
+            msg += ": " + lib.i2sdf_last_hip_error().decode()
+        raise I2SDFError(f"{what} failed ({rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C ABI needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,105 @@
+/*
+ * i2sdf.h -- C ABI of the MI355X-native volume-rendering core for I2-SDF.
+ *
+ * The upstream reference (jingsenzhu/i2-sdf) has no FFI / plugin interface: its hot path is entered
+ * through one Python call form, `I2SDFNetwork.forward(input, predict_only)` (model/network/__init__.py:80),
+ * plus bare `implicit_network(x)` queries (model/eval/recon.py:51,90).  This header is the boundary a
+ * maintainer binds UNDER that Python module (ctypes stub in INTEGRATION.md): every entry point replaces a
+ * span of stock-torch ops of the reference, cited per function as file:line relative to the upstream root.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes, no torch types;
+ *   - all tensors fp32, row-major, contiguous unless a leading dimension is given;
+ *   - stream-ordered on the `hipStream_t` passed last (as void*), re-entrant, no allocation inside,
+ *     no hidden global state: everything a call needs travels in `i2sdf_net` + caller-owned buffers;
+ *   - return 0 on success, a negative I2SDF_E* code otherwise (never exit(), unlike
+ *     utils/rend_util.py:220-222); `i2sdf_strerror` maps codes to text.
+ */
+#ifndef I2SDF_H
+#define I2SDF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2SDF_VERSION 100          /* major*10000 + minor*100 + patch */
+#define I2SDF_MAX_LAYERS 12
+
+#define I2SDF_OK 0
+#define I2SDF_EINVAL (-1)          /* bad argument / unsupported shape */
+#define I2SDF_EHIP (-2)            /* HIP runtime error (see i2sdf_last_hip_error) */
+#define I2SDF_ESPHERE (-3)         /* ray does not hit the bounding sphere (rend_util.py:220 `exit()`) */
+#define I2SDF_EWORKSPACE (-4)      /* caller workspace too small */
+
+/* ------------------------------------------------------------------------------------------------
+ * Network description.  Parameters live in ONE flat fp32 device buffer (`params`), laid out exactly in
+ * the reference's state_dict order: for each net, for each layer l: bias[out], weight_g[out],
+ * weight_v[out*in] (model/network/mlp.py:45-74, 196-203); then density.beta (density.py:6-8).
+ * Offsets are in floats.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_mlp_desc {
+  int32_t n_lin;                          /* number of nn.Linear layers                              */
+  int32_t hidden;                         /* hidden width H (multiple of 32, <= 256)                 */
+  int32_t d_in;                           /* raw input dims of layer 0 before encoding               */
+  int32_t in0;                            /* columns of lin0.weight_v                                */
+  int32_t d_out;                          /* rows of the last layer                                  */
+  int32_t multires;                       /* positional-encoding frequencies L (embedder.py:138-152) */
+  int32_t skip_layer;                     /* l with `l in skip_in` (mlp.py:94), -1 if none           */
+  int32_t reserved;
+  int32_t out_dim[I2SDF_MAX_LAYERS];      /* rows of weight_v per layer                              */
+  int32_t in_dim[I2SDF_MAX_LAYERS];       /* cols of weight_v per layer                              */
+  int64_t off_bias[I2SDF_MAX_LAYERS];
+  int64_t off_g[I2SDF_MAX_LAYERS];
+  int64_t off_v[I2SDF_MAX_LAYERS];
+} i2sdf_mlp_desc;
+
+typedef struct i2sdf_net_desc {
+  i2sdf_mlp_desc sdf;                     /* ImplicitNetwork: PE(x) -> softplus100 stack -> [sdf | feature]   */
+  i2sdf_mlp_desc rgb;                     /* RenderingNetwork 'nerf': [PE(view) | feature] -> ReLU -> sigmoid */
+  i2sdf_mlp_desc light;                   /* light-mask head (n_lin == 0 when absent)                         */
+  int64_t off_beta;                       /* density.beta                                                     */
+  int64_t n_params;                       /* total floats in `params`                                         */
+  float beta_min;                         /* density.py:17                                                    */
+  float scene_bounding_sphere;            /* model/network/__init__.py:23                                     */
+} i2sdf_net_desc;
+
+/* Opaque, caller-owned plan: host copy of the derived layouts + a small device table.
+ * i2sdf_plan_create allocates it (the only allocation in the library, one-time), i2sdf_plan_destroy frees. */
+typedef struct i2sdf_plan i2sdf_plan;
+
+int i2sdf_version(void);
+const char* i2sdf_strerror(int code);
+const char* i2sdf_last_hip_error(void);    /* thread-local text of the last HIP failure */
+
+int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out);
+void i2sdf_plan_destroy(i2sdf_plan* plan);
+/* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
+int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
+/* floats of the effective-weight gradient buffer i2sdf_weightnorm_backward consumes */
+int64_t i2sdf_plan_wgrad_floats(const i2sdf_plan* plan);
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight-norm reparametrisation + packing.  Replaces `W = g * v/||v||` executed inside every `lin(x)`
+ * (mlp.py:71-72,97,222) for all layers at once and lays W out in the order the MFMA kernels stream it.
+ * Must be called after every parameter update, before any kernel below.
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_pack_weights(const i2sdf_plan* plan, const float* params, float* packed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SDF network forward without gradient -- ImplicitNetwork.forward / get_sdf_vals (mlp.py:84-105,145-151),
+ * the call the sampler (ray_sampler.py:88-89), marching cubes (model/eval/recon.py:51,90) and the bubble
+ * loss (model/network/__init__.py:200) make.
+ *   points   (M,3)
+ *   sdf_out  (M)            or NULL
+ *   feat_out (M, ld_feat)   or NULL : the feature columns out[:,1:]   (ld_feat >= feature size, multiple of 4)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_sdf_forward(const i2sdf_plan* plan, const float* packed, const float* points, int64_t M,
+                      float* sdf_out, float* feat_out, int64_t ld_feat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2SDF_H */
