@@ -1,0 +1,155 @@
+// Pieces shared by the training-mode MLP kernels (forward-with-saves, igrad chain, backward sweeps).
+#pragma once
+#include "plan.h"
+
+namespace i2sdf {
+
+constexpr float RS2 = 0.70710678118654752440f;
+
+template <int N>
+__device__ __forceinline__ void softplus_tiles(const f32x16 (&acc)[N], float (&h)[N * 16]) {
+#pragma unroll
+  for (int nt = 0; nt < N; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(acc[nt][r]);
+}
+
+// stage counts -- must mirror plan.cpp
+__host__ __device__ constexpr int sdf_fwd_stages(int H, int F, int PEC, int L, bool has_skip, bool full) {
+  int c = op_chunks(H / 32, PEC);
+  for (int l = 1; l < L - 1; ++l) c += op_chunks(H / 32, H / 8);
+  if (has_skip) c += op_chunks(H / 32, H / 8 + PEC) - op_chunks(H / 32, H / 8);
+  c += rowvec_chunks(H / 8, 1);
+  if (full) c += op_chunks(F / 32, H / 8);
+  return c / SC;
+}
+__host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
+// reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space
+__host__ __device__ constexpr int sdf_rev_stages(int H, int PEC, int L, bool has_skip) {
+  const int PT = cdiv(PEC * 8, 32);
+  int c = rowvec_chunks(H / 8, 1);
+  for (int l = L - 2; l >= 1; --l) c += bwd_op_chunks(H / 32, H / 8);
+  if (has_skip) c += bwd_op_chunks(H / 32 + PT, H / 8) - bwd_op_chunks(H / 32, H / 8);
+  c += bwd_op_chunks(PT, H / 8);
+  return c / SC;
+}
+__host__ __device__ constexpr int sdf_rev_feat_stages(int H, int F) { return bwd_op_chunks(H / 32, F / 8) / SC; }
+
+// transposed dense op without bias: stream layout [KT*NC weight chunks] padded to stages
+//   MODE 1: acc = W^T in     MODE 2: acc += W^T in
+template <int KT, int NC, int MODE>
+__device__ __forceinline__ void dense_op_nobias(WStream& ws, const float (&in)[NC * 4], f32x16 (&acc)[KT], int tid) {
+  constexpr int NW = KT * NC, TOT = round_up(NW, SC), NS = TOT / SC;
+  const int lane = tid & 63;
+  if (MODE == 1) {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+    const int j1 = (NW - s * SC < SC) ? NW - s * SC : SC;
+    f32x4 ab[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (i < j1) ab[i] = cur[i * 64];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j < j1) {
+        const int w = s * SC + j;
+        const int kt = w / NC, nc = w % NC;
+        f32x4 a = ab[j % PF];
+        if (j + PF < j1) ab[j % PF] = cur[(j + PF) * 64];
+        acc[kt] = mfma(a.x, in[nc * 4 + 0], acc[kt]);
+        acc[kt] = mfma(a.y, in[nc * 4 + 1], acc[kt]);
+        acc[kt] = mfma(a.z, in[nc * 4 + 2], acc[kt]);
+        acc[kt] = mfma(a.w, in[nc * 4 + 3], acc[kt]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (i < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j < j1) {
+        I2SDF_SGB(I2SDF_MASK_MFMA, 4);
+        if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+      }
+    }
+  }
+}
+
+// read a row vector (w_row[k] in B layout) from a rowvec op: regs[kc*4+t] = w[8kc+4hi+t]; also returns the scalar chunk
+template <int KC>
+__device__ __forceinline__ void rowvec_load(WStream& ws, float (&w)[KC * 4], f32x4& scalars, int tid) {
+  constexpr int TOT = rowvec_chunks(KC, 1), NS = TOT / SC;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < KC) {
+        f32x4 v = cur[j * 64];
+        w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
+      } else if (c == KC) {
+        scalars = cur[j * 64];
+      }
+    }
+  }
+}
+
+// ---- positional-encoding Jacobian helpers -----------------------------------------------------------
+// coefficient d PE_k / d x_axis(k) for every k of the padded PE space, from the PE values themselves:
+//   identity: 1 ; sin(f x): f cos(f x) = f * PE[k+3] ; cos(f x): -f sin(f x) = -f * PE[k-3]
+template <int LF>
+__device__ __forceinline__ void pe_coef(const float (&full)[PE<LF>::PEC * 8], float (&coef)[PE<LF>::PEC * 8]) {
+#pragma unroll
+  for (int k = 0; k < PE<LF>::PEC * 8; ++k) {
+    if (k < 3) coef[k] = 1.f;
+    else if (k < PE<LF>::DIM) {
+      const int kk = k - 3, j = kk / 6, w = kk % 6;
+      const float f = (float)(1 << j);
+      coef[k] = (w < 3) ? f * full[k + 3] : -f * full[k - 3];
+    } else coef[k] = 0.f;
+  }
+}
+__host__ __device__ constexpr int pe_axis(int k) { return k < 3 ? k : (k - 3) % 3; }
+
+// n = J^T pbar, pbar given as D-layout tiles over the padded PE space (PT tiles)
+template <int LF, int PT>
+__device__ __forceinline__ void pe_jt_apply(const float (&coef)[PE<LF>::PEC * 8], const f32x16 (&pbar)[PT], int hi, float (&n)[3]) {
+  float a0[3] = {0.f, 0.f, 0.f}, a1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < PT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k0 = 32 * kt + (r & 3) + 8 * (r >> 2), k1 = k0 + 4;
+      if (k0 < PE<LF>::DIM) a0[pe_axis(k0)] = fmaf(coef[k0], pbar[kt][r], a0[pe_axis(k0)]);
+      if (k1 < PE<LF>::DIM) a1[pe_axis(k1)] = fmaf(coef[k1], pbar[kt][r], a1[pe_axis(k1)]);
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float v = hi ? a1[i] : a0[i];
+    n[i] = v + __shfl_xor(v, 32);
+  }
+}
+// G(pbar) = J nbar in B layout (chunk regs over the padded PE space)
+template <int LF>
+__device__ __forceinline__ void pe_j_apply(const float (&coef)[PE<LF>::PEC * 8], const float (&nb)[3], int hi,
+                                           float (&out)[PE<LF>::PEC * 4]) {
+#pragma unroll
+  for (int c = 0; c < PE<LF>::PEC; ++c)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k0 = 8 * c + t, k1 = k0 + 4;
+      const float v0 = (k0 < PE<LF>::DIM) ? coef[k0] * nb[pe_axis(k0)] : 0.f;
+      const float v1 = (k1 < PE<LF>::DIM) ? coef[k1] * nb[pe_axis(k1)] : 0.f;
+      out[c * 4 + t] = hi ? v1 : v0;
+    }
+}
+
+}  // namespace i2sdf

@@ -1,30 +1,12 @@
 // SDF network forward without gradient: ImplicitNetwork.forward / get_sdf_vals
 // (model/network/mlp.py:84-105,145-151).  MFMA-bound: 2*524544 FLOP per point at synthetic.yml shapes.
-#include "plan.h"
+#include "mlp_common.h"
 
 using namespace i2sdf;
 
 int i2sdf_hip_check(hipError_t e, const char* what);
 
 namespace {
-
-template <int N>
-__device__ __forceinline__ void softplus_tiles(const f32x16 (&acc)[N], float (&h)[N * 16]) {
-#pragma unroll
-  for (int nt = 0; nt < N; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(acc[nt][r]);
-}
-
-// stages consumed by the forward pass (must mirror build_sdf() in plan.cpp)
-__host__ __device__ constexpr int sdf_fwd_stages(int H, int F, int PEC, int L, bool has_skip, bool full) {
-  int c = op_chunks(H / 32, PEC);
-  for (int l = 1; l < L - 1; ++l) c += op_chunks(H / 32, H / 8);
-  if (has_skip) c += op_chunks(H / 32, H / 8 + PEC) - op_chunks(H / 32, H / 8);
-  c += rowvec_chunks(H / 8, 1);
-  if (full) c += op_chunks(F / 32, H / 8);
-  return c / SC;
-}
 
 template <int H, int F, int LF, bool FULL>
 __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ stream, int n_stages, int L, int skip,
@@ -51,7 +33,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
   softplus_tiles<NT>(acc, h);
   for (int l = 1; l < L - 1; ++l) {
     if (l == skip) {
-      constexpr float rs2 = 0.70710678118654752440f;
+      constexpr float rs2 = RS2;
       float u[(KC + PEC) * 4];
 #pragma unroll
       for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * rs2;

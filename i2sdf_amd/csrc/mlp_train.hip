@@ -1,0 +1,270 @@
+// Training/eval-mode forward kernels:
+//   sdf_train_fwd : ImplicitNetwork.get_outputs (model/network/mlp.py:123-143) = forward + d sdf/dx, where the
+//                   reference builds d sdf/dx with torch.autograd.grad(create_graph=True); here the reverse chain
+//                    is evaluated explicitly in the same kernel, in registers.
+//                   Saves h_l = softplus(a_{l-1}) and abar_l = d sdf / d a_l for the backward kernels.
+//   rgb_fwd       : RenderingNetwork.forward, 'nerf' mode (mlp.py:208-229), saves the post-ReLU activations.
+#include "mlp_common.h"
+
+using namespace i2sdf;
+
+int i2sdf_hip_check(hipError_t e, const char* what);
+
+struct SdfTrainFwdArgs {
+  const float* fwd; int n_fwd;
+  const float* rev; int n_rev;          // starts at the w_sdf row vector
+  int L, skip;
+  const float* points;                  // (M,3) or nullptr -> ray mode
+  const float* cam; const float* dirs; const float* z; int64_t ldz; int n_per_ray;   // ray mode: x = cam[r] + z[r,j]*dirs[r]
+  int64_t M, Mp;
+  float* sdf;                           // (M)
+  float* feat;                          // (Mp, F)
+  float* grad;                          // (M,3) or nullptr
+  float* hs;                            // (L-1, Mp, H)  h_1..h_{L-1}   or nullptr (no saves: eval)
+  float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
+};
+
+namespace {
+
+__device__ __forceinline__ void fetch_point(const SdfTrainFwdArgs& a, int64_t mc, float& x, float& y, float& z) {
+  if (a.points != nullptr) {
+    x = a.points[mc * 3 + 0]; y = a.points[mc * 3 + 1]; z = a.points[mc * 3 + 2];
+  } else {
+    const int64_t ray = mc / a.n_per_ray;
+    const int j = (int)(mc - ray * a.n_per_ray);
+    const float t = a.z[ray * a.ldz + j];
+    // mul then add, two roundings, as `cam_loc + z_vals * ray_dirs` does (model/network/__init__.py:103)
+    x = __fadd_rn(a.cam[ray * 3 + 0], __fmul_rn(t, a.dirs[ray * 3 + 0]));
+    y = __fadd_rn(a.cam[ray * 3 + 1], __fmul_rn(t, a.dirs[ray * 3 + 1]));
+    z = __fadd_rn(a.cam[ray * 3 + 2], __fmul_rn(t, a.dirs[ray * 3 + 2]));
+  }
+}
+
+template <int H, int F, int LF, bool GRAD>
+__global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FT = F / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  float px, py, pz;
+  fetch_point(a, mc, px, py, pz);
+  float pe[PEC * 4];
+  {
+    float full[PEC * 8];
+    pe_full<LF>(px, py, pz, full);
+    to_b_layout<PEC>(full, pe, hi);
+  }
+  const int64_t lstride = a.Mp * H;
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x16 acc[NT];
+  float h[NT * 16];
+  dense_op<NT, PEC, 0>(ws, pe, acc, tid);
+  softplus_tiles<NT>(acc, h);
+  if (a.hs) store_regs<KC>(a.hs + m * H, hi, valid, h);
+  for (int l = 1; l < a.L - 1; ++l) {
+    if (l == a.skip) {
+      float u[(KC + PEC) * 4];
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * RS2;
+#pragma unroll
+      for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = pe[i] * RS2;
+      dense_op<NT, KC + PEC, 0>(ws, u, acc, tid);
+    } else {
+      dense_op<NT, KC, 0>(ws, h, acc, tid);
+    }
+    softplus_tiles<NT>(acc, h);
+    if (a.hs) store_regs<KC>(a.hs + l * lstride + m * H, hi, valid, h);
+  }
+  {
+    float s[1];
+    rowvec_op<1, KC>(ws, h, s, tid);
+    if (valid && hi == 0) a.sdf[m] = s[0];
+  }
+  if (a.feat != nullptr) {
+    f32x16 fa[FT];
+    dense_op<FT, KC, 0>(ws, h, fa, tid);
+    store_tile<FT>(a.feat + m * F, hi, valid, fa);
+  }
+  if (!GRAD) return;
+  // ---------------- reverse chain: n = d sdf / d x  (appendix A.2) ----------------
+  __syncthreads();                      // every wave is done with the forward stream's LDS buffers
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float ab[KC * 4];
+  {
+    float wv[KC * 4];
+    f32x4 sc;
+    rowvec_load<KC>(ws, wv, sc, tid);
+#pragma unroll
+    for (int i = 0; i < KC * 4; ++i) ab[i] = wv[i] * sp_sigma_from_h(h[i]);     // abar_{L-2} = w_sdf (.) sigma_{L-2}
+  }
+  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + m * H, hi, valid, ab);
+  f32x16 pt[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[i][r] = 0.f;
+  for (int l = a.L - 2; l >= 1; --l) {
+    float hl[KC * 4];
+    if (l == a.skip) {
+      f32x16 as[NT + PT];
+      dense_op_nobias<NT + PT, KC, 1>(ws, ab, as, tid);
+      load_regs<KC>(a.hs + (l - 1) * lstride + mc * H, hi, hl);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ab[nt * 16 + r] = as[nt][r] * RS2 * sp_sigma_from_h(hl[nt * 16 + r]);
+#pragma unroll
+      for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[i][r] += as[NT + i][r] * RS2;
+    } else {
+      f32x16 a2[NT];
+      dense_op_nobias<NT, KC, 1>(ws, ab, a2, tid);
+      load_regs<KC>(a.hs + (l - 1) * lstride + mc * H, hi, hl);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ab[nt * 16 + r] = a2[nt][r] * sp_sigma_from_h(hl[nt * 16 + r]);
+    }
+    if (a.abars) store_regs<KC>(a.abars + (l - 1) * lstride + m * H, hi, valid, ab);
+  }
+  dense_op_nobias<PT, KC, 2>(ws, ab, pt, tid);       // pbar += W_0^T abar_0
+  {
+    float full[PEC * 8], coef[PEC * 8], n[3];
+    pe_full<LF>(px, py, pz, full);
+    pe_coef<LF>(full, coef);
+    pe_jt_apply<LF, PT>(coef, pt, hi, n);
+    if (valid && hi == 0) { a.grad[m * 3 + 0] = n[0]; a.grad[m * 3 + 1] = n[1]; a.grad[m * 3 + 2] = n[2]; }
+  }
+}
+
+}  // namespace
+
+// ---- radiance network ---------------------------------------------------------------------------------------
+struct RgbFwdArgs {
+  const float* fwd; int n_fwd; int L;
+  const float* dirs; int n_per_ray;     // view dir of point m = dirs[m / n_per_ray]
+  const float* feat;                    // (Mp, F)
+  int64_t M, Mp;
+  float* rgb;                           // (M,3)
+  float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
+};
+
+namespace {
+
+__host__ __device__ constexpr int rgb_fwd_stages(int H, int F, int PECV, int L) {
+  int c = op_chunks(H / 32, PECV + F / 8);
+  for (int l = 1; l < L - 1; ++l) c += op_chunks(H / 32, H / 8);
+  c += rowvec_chunks(H / 8, 3);
+  return c / SC;
+}
+
+template <int H, int F, int LFV>
+__global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, PECV = PE<LFV>::PEC, FC = F / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t ray = mc / a.n_per_ray;
+  float in0[(PECV + FC) * 4];
+  {
+    float full[PECV * 8], pv[PECV * 4];
+    pe_full<LFV>(a.dirs[ray * 3 + 0], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2], full);
+    to_b_layout<PECV>(full, pv, hi);
+    float ft[FC * 4];
+    load_regs<FC>(a.feat + mc * F, hi, ft);
+#pragma unroll
+    for (int i = 0; i < PECV * 4; ++i) in0[i] = pv[i];
+#pragma unroll
+    for (int i = 0; i < FC * 4; ++i) in0[PECV * 4 + i] = ft[i];
+  }
+  const int64_t lstride = a.Mp * H;
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x16 acc[NT];
+  float r[NT * 16];
+  dense_op<NT, PECV + FC, 0>(ws, in0, acc, tid);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[nt * 16 + q] = fmaxf(acc[nt][q], 0.f);
+  if (a.rs) store_regs<KC>(a.rs + m * H, hi, valid, r);
+  for (int l = 1; l < a.L - 1; ++l) {
+    dense_op<NT, KC, 0>(ws, r, acc, tid);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) r[nt * 16 + q] = fmaxf(acc[nt][q], 0.f);
+    if (a.rs) store_regs<KC>(a.rs + l * lstride + m * H, hi, valid, r);
+  }
+  float o[3];
+  rowvec_op<3, KC>(ws, r, o, tid);
+  if (valid && hi == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.rgb[m * 3 + i] = 1.0f / (1.0f + expf(-o[i]));
+  }
+}
+
+}  // namespace
+
+// =============================================================================================================
+extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, const float* points, const float* cam,
+                                      const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t M, int64_t Mp,
+                                      float* sdf, float* feat, float* grad, float* hs, float* abars, void* stream) {
+  if (!p || !packed || M < 0 || !sdf) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  if (!points && (!cam || !dirs || !z || n_per_ray <= 0)) return I2SDF_EINVAL;
+  if (grad && !hs) return I2SDF_EINVAL;          // the reverse chain re-reads h_l
+  const i2sdf_mlp_desc& d = p->sdf.d;
+  if (d.multires != 6) return I2SDF_EINVAL;
+  SdfTrainFwdArgs a{};
+  const float* base = packed + p->scale_floats;
+  a.fwd = base + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
+  a.rev = base + p->sdf.rev_wsdf_chunk * CHUNK_FLOATS;
+  a.L = d.n_lin; a.skip = d.skip_layer;
+  a.points = points; a.cam = cam; a.dirs = dirs; a.z = z; a.ldz = ldz; a.n_per_ray = n_per_ray;
+  a.M = M; a.Mp = Mp; a.sdf = sdf; a.feat = feat; a.grad = grad; a.hs = hs; a.abars = abars;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  const bool has_skip = d.skip_layer > 0;
+#define LAUNCH(HH, FF)                                                                               \
+  do {                                                                                               \
+    a.n_fwd = sdf_fwd_stages(HH, FF, PE<6>::PEC, d.n_lin, has_skip, feat != nullptr);                \
+    a.n_rev = sdf_rev_stages(HH, PE<6>::PEC, d.n_lin, has_skip);                                     \
+    if (grad) sdf_train_fwd_kernel<HH, FF, 6, true><<<grid, 256, LDS_BYTES, st>>>(a);                \
+    else sdf_train_fwd_kernel<HH, FF, 6, false><<<grid, 256, LDS_BYTES, st>>>(a);                    \
+  } while (0)
+  if (p->H == 256 && p->F == 256) LAUNCH(256, 256);
+  else if (p->H == 64 && p->F == 64) LAUNCH(64, 64);
+  else return I2SDF_EINVAL;
+#undef LAUNCH
+  return i2sdf_hip_check(hipGetLastError(), "sdf_forward_grad launch");
+}
+
+extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
+                                 int64_t M, int64_t Mp, float* rgb, float* rs, void* stream) {
+  if (!p || !packed || !dirs || !feat || !rgb || M < 0 || n_per_ray <= 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  const i2sdf_mlp_desc& d = p->rgb.d;
+  if (d.multires != 4) return I2SDF_EINVAL;
+  RgbFwdArgs a{};
+  a.fwd = packed + p->scale_floats + p->rgb.fwd_chunk0 * CHUNK_FLOATS;
+  a.L = d.n_lin; a.dirs = dirs; a.n_per_ray = n_per_ray; a.feat = feat; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rs = rs;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (d.hidden == 256 && p->F == 256) {
+    a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
+    rgb_fwd_kernel<256, 256, 4><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else if (d.hidden == 64 && p->F == 64) {
+    a.n_fwd = rgb_fwd_stages(64, 64, PE<4>::PEC, d.n_lin);
+    rgb_fwd_kernel<64, 64, 4><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else return I2SDF_EINVAL;
+  return i2sdf_hip_check(hipGetLastError(), "rgb_forward launch");
+}

@@ -8,6 +8,7 @@ from typing import Optional
 import torch
 
 from . import lib as L
+from . import lib as L_
 from .config import NetConfig
 from .params import ParamLayout
 
@@ -51,3 +52,42 @@ class RenderEngine:
         L.check(self._lib.i2sdf_sdf_forward(self._plan, L.ptr(self.packed), L.ptr(pts), M, L.ptr(sdf), L.ptr(feat), self.F,
                                             L.stream_ptr()), "i2sdf_sdf_forward")
         return (sdf, feat) if want_features else sdf
+
+    # -- training-mode forward pieces (low level; the nn.Module composes them) ------------------
+    @staticmethod
+    def pad_rows(M: int) -> int:
+        return (M + 127) // 128 * 128
+
+    def sdf_forward_grad(self, points=None, rays=None, want_grad=True, save=True, want_feat=True):
+        """points (M,3) or rays=(cam (B,3), dirs (B,3), z (B,n)).  Returns dict(sdf, feat, grad, hs, abars, Mp)."""
+        cfgs = self.cfg.sdf
+        H, L = cfgs.hidden, cfgs.n_lin
+        if points is not None:
+            pts = points.detach().to(torch.float32).contiguous()
+            M, dev = pts.shape[0], pts.device
+            cam = dirs = z = None
+            ldz, npr = 0, 1
+        else:
+            cam, dirs, z = (t.detach().to(torch.float32).contiguous() for t in rays)
+            pts = None
+            M, dev = z.shape[0] * z.shape[1], z.device
+            ldz, npr = z.shape[1], z.shape[1]
+        Mp = self.pad_rows(M)
+        out = {"Mp": Mp, "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
+        out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
+        out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
+        out["hs"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
+        out["abars"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
+        L_.check(self._lib.i2sdf_sdf_forward_grad(self._plan, L_.ptr(self.packed), L_.ptr(pts), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
+                                                  ldz, npr, M, Mp, L_.ptr(out["sdf"]), L_.ptr(out["feat"]), L_.ptr(out["grad"]),
+                                                  L_.ptr(out["hs"]), L_.ptr(out["abars"]), L_.stream_ptr()), "i2sdf_sdf_forward_grad")
+        return out
+
+    def rgb_forward(self, dirs, n_per_ray, feat, M, save=True):
+        Mp = feat.shape[0]
+        rgb = torch.empty(M, 3, dtype=torch.float32, device=feat.device)
+        Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
+        rs = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=feat.device) if save else None
+        L_.check(self._lib.i2sdf_rgb_forward(self._plan, L_.ptr(self.packed), L_.ptr(dirs.contiguous()), n_per_ray, L_.ptr(feat), M, Mp,
+                                             L_.ptr(rgb), L_.ptr(rs), L_.stream_ptr()), "i2sdf_rgb_forward")
+        return rgb, rs

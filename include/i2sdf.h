@@ -99,6 +99,31 @@ int i2sdf_pack_weights(const i2sdf_plan* plan, const float* params, float* packe
 int i2sdf_sdf_forward(const i2sdf_plan* plan, const float* packed, const float* points, int64_t M,
                       float* sdf_out, float* feat_out, int64_t ld_feat, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * SDF network forward WITH d sdf/dx and saved activations -- ImplicitNetwork.get_outputs / .gradient
+ * (mlp.py:107-143) as called by the main render pass (model/network/__init__.py:113) and the eikonal pass
+ * (:188).  The reference obtains d sdf/dx from torch.autograd.grad(create_graph=True); here the reverse
+ * chain is explicit and fused into the same kernel.
+ *   points (M,3), or NULL for ray mode: x[m] = cam[r] + z[r*ldz + j]*dirs[r], r = m / n_per_ray, j = m % n_per_ray
+ *                                        (model/network/__init__.py:103)
+ *   Mp      row count of the workspaces, multiple of 128, >= M
+ *   sdf (M) ; feat (Mp,F) or NULL ; grad (M,3) or NULL
+ *   hs    (L-1, Mp, H)  h_l = softplus100(a_{l-1}), l = 1..L-1   (needed when grad != NULL; NULL otherwise ok)
+ *   abars (L-1, Mp, H)  d sdf / d a_l, l = 0..L-2                (NULL if no backward will follow)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_sdf_forward_grad(const i2sdf_plan* plan, const float* packed, const float* points, const float* cam,
+                           const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t M, int64_t Mp,
+                           float* sdf, float* feat, float* grad, float* hs, float* abars, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Radiance network forward, 'nerf' mode -- RenderingNetwork.forward (mlp.py:208-229):
+ * rgb = sigmoid(MLP([PE4(view_dir) | feature])).  dirs (B,3) unit view directions, point m uses dirs[m / n_per_ray].
+ *   rgb (M,3) ; rs (L-1, Mp, H) post-ReLU activations (NULL if no backward will follow)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_rgb_forward(const i2sdf_plan* plan, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
+                      int64_t M, int64_t Mp, float* rgb, float* rs, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+"""GPU: training-mode forward kernels (SDF forward + explicit d sdf/dx chain + saved activations; radiance net)
+vs the oracle's analytic restatement (fp64 arbiter)."""
+import pytest
+import torch
+
+from oracle import i2sdf_oracle as orc
+from helpers import assert_close, sd_from_npz, t
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def make_engine(conf, sd):
+    from i2sdf_amd.config import NetConfig
+    from i2sdf_amd.engine import RenderEngine
+    eng = RenderEngine(NetConfig.from_conf(conf))
+    eng.pack(eng.layout.flat_from_state_dict(sd).cuda())
+    return eng
+
+
+def dbl(sd):
+    return {k: v.double() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("which", ["synthetic", "light", "plumbing", "plumbing_skip"])
+def test_sdf_forward_grad_and_saves(which):
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    if which == "synthetic":
+        ocfg, conf = orc.synthetic_cfg(False), synthetic_conf(False)
+    elif which == "light":
+        ocfg, conf = orc.synthetic_cfg(True), synthetic_conf(True)
+    elif which == "plumbing":
+        ocfg, conf = orc.plumbing_cfg(False), plumbing_conf(False)
+    else:
+        ocfg, conf = orc.plumbing_cfg(True), plumbing_conf(True)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=5), 0.05, seed=6)
+    eng = make_engine(conf, sd)
+    M = 777
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.0
+    fw = orc.sdf_analytic_forward(dbl(sd), ocfg.sdf, x.double())
+    out = eng.sdf_forward_grad(points=x.cuda())
+    L = ocfg.sdf.n_lin
+    assert_close(out["sdf"].cpu(), fw["sdf"], TOL, "sdf")
+    assert_close(out["feat"][:M].cpu(), fw["feat"], TOL, "feature")
+    assert_close(out["grad"].cpu(), fw["n"], TOL, "d sdf/dx")
+    for l in range(L - 1):
+        ref_h = orc.softplus100(fw["a"][l])
+        w = ref_h.shape[1]
+        assert_close(out["hs"][l, :M, :w].cpu(), ref_h, TOL, f"h_{l+1}")
+        assert_close(out["abars"][l, :M, :w].cpu(), fw["abar"][l], TOL, f"abar_{l}")
+
+
+def test_sdf_forward_grad_ray_mode_matches_point_mode():
+    from i2sdf_amd.config import plumbing_conf
+    ocfg = orc.plumbing_cfg(True)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=5), 0.05, seed=6)
+    eng = make_engine(plumbing_conf(True), sd)
+    g = torch.Generator().manual_seed(2)
+    B, n = 37, 11
+    cam = torch.randn(B, 3, generator=g) * 0.3
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1)
+    z = torch.sort(torch.rand(B, n + 1, generator=g) * 4, -1)[0]
+    zc = z.cuda()
+    pts = (cam.cuda().unsqueeze(1) + zc[:, :n].unsqueeze(2) * dirs.cuda().unsqueeze(1)).reshape(-1, 3)
+    a = eng.sdf_forward_grad(points=pts)
+    b = eng.sdf_forward_grad(rays=(cam.cuda(), dirs.cuda(), zc[:, :n].contiguous()))
+    for k in ("sdf", "grad"):
+        assert_close(b[k], a[k], 1e-6, k)
+
+
+@pytest.mark.parametrize("which", ["synthetic", "light", "plumbing"])
+def test_rgb_forward(which):
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    if which == "plumbing":
+        ocfg, conf = orc.plumbing_cfg(False), plumbing_conf(False)
+    else:
+        ocfg, conf = orc.synthetic_cfg(which == "light"), synthetic_conf(which == "light")
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=7), 0.05, seed=8)
+    eng = make_engine(conf, sd)
+    g = torch.Generator().manual_seed(3)
+    B, n = 29, 13
+    M, F = B * n, ocfg.rgb.feature_size
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1)
+    feat = torch.randn(M, F, generator=g)
+    ref = orc.rgb_forward(dbl(sd), ocfg.rgb, dirs.double().unsqueeze(1).repeat(1, n, 1).reshape(-1, 3), feat.double())
+    Mp = eng.pad_rows(M)
+    featp = torch.zeros(Mp, F)
+    featp[:M] = feat
+    rgb, rs = eng.rgb_forward(dirs.cuda(), n, featp.cuda(), M)
+    assert_close(rgb.cpu(), ref, TOL, "rgb")
+
+
+def test_rgb_forward_golden(golden):
+    from i2sdf_amd.config import plumbing_conf
+    z = golden("g4_rgb")
+    ocfg = orc.plumbing_cfg()
+    sd = orc.init_params(ocfg)
+    sd.update({"rendering_network." + k: v for k, v in sd_from_npz(z, "sd.").items()})
+    eng = make_engine(plumbing_conf(), sd)
+    M = z["feat"].shape[0]
+    featp = torch.zeros(eng.pad_rows(M), 64)
+    featp[:M] = t(z["feat"])
+    rgb, _ = eng.rgb_forward(t(z["dirs"]).cuda(), 1, featp.cuda(), M)
+    assert_close(rgb.cpu(), z["rgb"], 2e-5, "RenderingNetwork.forward")
