@@ -91,3 +91,48 @@ class RenderEngine:
         L_.check(self._lib.i2sdf_rgb_forward(self._plan, L_.ptr(self.packed), L_.ptr(dirs.contiguous()), n_per_ray, L_.ptr(feat), M, Mp,
                                              L_.ptr(rgb), L_.ptr(rs), L_.stream_ptr()), "i2sdf_rgb_forward")
         return rgb, rs
+
+    # -- per-ray kernels -------------------------------------------------------------------------
+    def ray_setup(self, uv, pose, intrinsics):
+        uv, pose, intrinsics = (t.detach().to(torch.float32).contiguous() for t in (uv, pose, intrinsics))
+        batch, pixels = uv.shape[0], uv.shape[1]
+        N = batch * pixels
+        cam = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
+        dirs = torch.empty_like(cam)
+        dnorm = torch.empty(N, dtype=torch.float32, device=uv.device)
+        L_.check(self._lib.i2sdf_ray_setup(L_.ptr(uv), L_.ptr(pose), L_.ptr(intrinsics), batch, pixels, L_.ptr(cam), L_.ptr(dirs),
+                                           L_.ptr(dnorm), L_.stream_ptr()), "i2sdf_ray_setup")
+        return cam, dirs, dnorm
+
+    def composite_forward(self, beta_param, z_all, sdf, rgb, grad, lmask, dnorm, want_normal, save=True):
+        B, n = z_all.shape[0], z_all.shape[1] - 1
+        dev = z_all.device
+        o = {"rgb": torch.empty(B, 3, device=dev), "depth": torch.empty(B, device=dev), "wsum": torch.empty(B, 1, device=dev)}
+        o["normal"] = torch.empty(B, 3, device=dev) if want_normal else None
+        o["lmask"] = torch.empty(B, 1, device=dev) if lmask is not None else None
+        o["w"] = torch.empty(B, n, device=dev) if save else None
+        o["nsum"] = torch.empty(B, 3, device=dev) if (save and want_normal) else None
+        L_.check(self._lib.i2sdf_composite_forward(L_.ptr(beta_param), self.cfg.beta_min, L_.ptr(z_all), z_all.shape[1], L_.ptr(sdf),
+                                                   L_.ptr(rgb), L_.ptr(grad) if want_normal else None, L_.ptr(lmask), L_.ptr(dnorm), B, n,
+                                                   L_.ptr(o["rgb"]), L_.ptr(o["depth"]), L_.ptr(o["wsum"]), L_.ptr(o["normal"]),
+                                                   L_.ptr(o["lmask"]), L_.ptr(o["w"]), L_.ptr(o["nsum"]), L_.stream_ptr()),
+                 "i2sdf_composite_forward")
+        return o
+
+    def composite_backward(self, beta_param, z_all, sdf, rgb, grad, dnorm, nsum, g_rgb, g_depth, g_wsum, g_normal, g_lmask,
+                           beta_grad_accum=None):
+        B, n = z_all.shape[0], z_all.shape[1] - 1
+        dev = z_all.device
+        M = B * n
+        o = {"sdf_bar": torch.empty(M, device=dev), "rgb_bar": torch.empty(M, 3, device=dev)}
+        o["grad_bar"] = torch.empty(M, 3, device=dev) if g_normal is not None else None
+        o["lmask_bar"] = torch.empty(M, device=dev) if g_lmask is not None else None
+        part = torch.empty(B, device=dev)
+        c = lambda t: None if t is None else t.contiguous()
+        L_.check(self._lib.i2sdf_composite_backward(L_.ptr(beta_param), self.cfg.beta_min, L_.ptr(z_all), z_all.shape[1], L_.ptr(sdf),
+                                                    L_.ptr(rgb), L_.ptr(grad), L_.ptr(dnorm), L_.ptr(nsum), B, n, L_.ptr(c(g_rgb)),
+                                                    L_.ptr(c(g_depth)), L_.ptr(c(g_wsum)), L_.ptr(c(g_normal)), L_.ptr(c(g_lmask)),
+                                                    L_.ptr(o["sdf_bar"]), L_.ptr(o["rgb_bar"]), L_.ptr(o["grad_bar"]), L_.ptr(o["lmask_bar"]),
+                                                    L_.ptr(part), L_.ptr(beta_grad_accum), L_.stream_ptr()), "i2sdf_composite_backward")
+        o["beta_partial"] = part
+        return o

@@ -41,6 +41,9 @@ SIGNATURES = {
     "i2sdf_pack_weights": (C.c_int, [_P, _P, _P, _P]),
     "i2sdf_sdf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
     "i2sdf_sdf_forward_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "i2sdf_rgb_forward": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I64, _P, _P, _P]),
 }
 

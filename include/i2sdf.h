@@ -124,6 +124,41 @@ int i2sdf_sdf_forward_grad(const i2sdf_plan* plan, const float* packed, const fl
 int i2sdf_rgb_forward(const i2sdf_plan* plan, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
                       int64_t M, int64_t Mp, float* rgb, float* rs, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray set-up -- utils/rend_util.py:92-147 (get_camera_params + lift, pose-matrix form) and
+ * model/network/__init__.py:88-93 (per-pixel cam_loc, ||d||, F.normalize).
+ *   uv (batch, pixels, 2) pixel coords ; pose (batch,4,4) cam->world ; intrinsics (batch,4,4)
+ *   -> cam_loc (N,3), dirs (N,3) unit, dnorm (N) with N = batch*pixels
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_ray_setup(const float* uv, const float* pose, const float* intrinsics, int64_t batch, int32_t pixels,
+                    float* cam_loc, float* dirs, float* dnorm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Laplace density + log-space alpha compositing -- LaplaceDensity (density.py:21-30),
+ * I2SDFNetwork.volume_rendering (model/network/__init__.py:223-240) and the weighted sums (:120-125,
+ * :169, :204-219).  beta = |*beta_param| + beta_min is read on the device (no host sync).
+ *   z (B, ldz): n sample depths followed by z_max in column n ; sdf (B*n) ; rgb (B*n,3) ;
+ *   grad (B*n,3) raw d sdf/dx (needed iff o_normal) ; lmask (B*n) (needed iff o_lmask) ; dnorm (B)
+ *   -> o_rgb (B,3), o_depth (B), o_wsum (B), o_normal (B,3)|NULL, o_lmask (B)|NULL,
+ *      w_save (B,n)|NULL weights, nsum_save (B,3)|NULL un-normalised normal sum (for the backward)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_composite_forward(const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf,
+                            const float* rgb, const float* grad, const float* lmask, const float* dnorm, int64_t B, int32_t n,
+                            float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* w_save,
+                            float* nsum_save, void* stream);
+
+/* Backward of the above (what loss.backward() does through :118-125,:169,:204-209).
+ * Upstream: g_rgb (B,3), g_depth (B)|NULL, g_wsum (B)|NULL, g_normal (B,3)|NULL (w.r.t. normal_values),
+ * g_lmask (B)|NULL.  The normal / light composites use w.detach() as the reference does in training.
+ *   -> sdf_bar (B*n), rgb_bar (B*n,3), grad_bar (B*n,3)|NULL, lmask_bar (B*n)|NULL,
+ *      beta_partial (B) scratch; if beta_grad_accum != NULL: *beta_grad_accum += d loss / d density.beta */
+int i2sdf_composite_backward(const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf,
+                             const float* rgb, const float* grad, const float* dnorm, const float* nsum_save, int64_t B, int32_t n,
+                             const float* g_rgb, const float* g_depth, const float* g_wsum, const float* g_normal,
+                             const float* g_lmask, float* sdf_bar, float* rgb_bar, float* grad_bar, float* lmask_bar,
+                             float* beta_partial, float* beta_grad_accum, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
