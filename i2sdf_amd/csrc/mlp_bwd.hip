@@ -1,0 +1,303 @@
+// Backward kernels of the two MLPs (what loss.backward() computes through model/network/mlp.py via autograd in the
+// reference; the explicit sweeps are SURVEY.md appendix A.3/A.4).  Same execution model as the forward kernels:
+// 32 points per wave, activations/adjoints in registers, weights streamed through LDS.
+//   sdf_bwd : sweep 1 (adjoint of the d sdf/dx chain, bottom-up, forward-direction weights) followed by
+//             sweep 2 (ordinary backward, top-down, transposed weights).  Emits per layer the operands of the
+//             weight-gradient GEMMs (G(ubar_l), G(a_l)); the GEMMs themselves run in wgrad.hip.
+//   rgb_bwd : first-order backward of the radiance net; emits G(a_l) and the feature gradient fbar.
+#include "mlp_common.h"
+
+using namespace i2sdf;
+
+int i2sdf_hip_check(hipError_t e, const char* what);
+
+struct SdfBwdArgs {
+  const float* fwd; int n_fwd;          // forward stream up to (excluding) the last layer
+  const float* rev; int n_rev;          // reverse stream from W_feat^T down to W_1^T
+  int L, skip;
+  PointSpec pts;
+  int64_t M, Mp;
+  const float* hs; const float* abars;  // from sdf_train_fwd
+  const float* sbar;                    // (M) d loss / d sdf            (nullptr = 0)
+  const float* fbar; int64_t m_fbar;    // (Mp,F) d loss / d feature, rows >= m_fbar are zero (nullptr = 0)
+  const float* nbar;                    // (M,3) d loss / d grad         (nullptr = 0)
+  float* gus;                           // (L, Mp, H)  G(hbar_l): slot l = h-part of G(ubar_l), l = 1..L-1 (slot 0 unused)
+  float* gpbar;                         // (Mp, PEC*8) G(pbar)
+  float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (holds G2(a_l) between the sweeps)
+  float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
+  float* ones4;                         // (Mp,4) {1,0,0,0}
+};
+
+namespace {
+
+__host__ __device__ constexpr int sdf_fwd_hidden_stages(int H, int PEC, int L, bool has_skip) {
+  int c = op_chunks(H / 32, PEC);
+  for (int l = 1; l < L - 1; ++l) c += op_chunks(H / 32, H / 8);
+  if (has_skip) c += op_chunks(H / 32, H / 8 + PEC) - op_chunks(H / 32, H / 8);
+  return c / SC;
+}
+// reverse stream: [W_feat^T][w_sdf][W_{L-2}^T .. W_1^T]  (W_0^T is not needed: the points carry no gradient)
+__host__ __device__ constexpr int sdf_rev_bwd_stages(int H, int F, int PEC, int L, bool has_skip) {
+  const int PT = cdiv(PEC * 8, 32);
+  int c = bwd_op_chunks(H / 32, F / 8) + rowvec_chunks(H / 8, 1);
+  for (int l = L - 2; l >= 1; --l) c += bwd_op_chunks(H / 32, H / 8);
+  if (has_skip) c += bwd_op_chunks(H / 32 + PT, H / 8) - bwd_op_chunks(H / 32, H / 8);
+  return c / SC;
+}
+
+template <int H, int F, int LF>
+__global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FC = F / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float gp[PEC * 4];
+  {
+    float px, py, pz, full[PEC * 8], coef[PEC * 8], nb[3] = {0.f, 0.f, 0.f};
+    fetch_point(a.pts, mc, px, py, pz);
+    pe_full<LF>(px, py, pz, full);
+    pe_coef<LF>(full, coef);
+    if (a.nbar) { nb[0] = a.nbar[mc * 3 + 0]; nb[1] = a.nbar[mc * 3 + 1]; nb[2] = a.nbar[mc * 3 + 2]; }
+    pe_j_apply<LF>(coef, nb, hi, gp);
+    store_regs<PEC>(a.gpbar + m * (PEC * 8), hi, valid, gp);
+  }
+  WStream ws;
+  // ------------------------------ sweep 1: bottom-up ------------------------------
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  float gh[KC * 4];
+  f32x16 acc[NT];
+  for (int l = 0; l < a.L - 1; ++l) {
+    if (l == 0) {
+      dense_op<NT, PEC, 1>(ws, gp, acc, tid);
+    } else if (l == a.skip) {
+      float u[(KC + PEC) * 4];
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) u[i] = gh[i] * RS2;
+#pragma unroll
+      for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = gp[i] * RS2;
+      dense_op<NT, KC + PEC, 1>(ws, u, acc, tid);
+    } else {
+      dense_op<NT, KC, 1>(ws, gh, acc, tid);
+    }
+    // epilogue: G(hbar_{l+1}) = G(abar_l) * sigma_l ; G2(a_l) = G(abar_l) * abar_l * 100 (1 - sigma_l)
+    const float* hrow = a.hs + l * lstride + mc * H;
+    const float* arow = a.abars + l * lstride + mc * H;
+    float* g2row = a.gas + l * lstride + m * H;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 8 * c + 4 * hi);
+      const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * c + 4 * hi);
+      f32x4 g2;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float ga = acc[c / 4][(c % 4) * 4 + t];
+        const float sg = sp_sigma_from_h(hv[t]);
+        gh[c * 4 + t] = ga * sg;
+        g2[t] = ga * av[t] * (100.f * (1.0f - sg));
+      }
+      if (valid) *reinterpret_cast<f32x4*>(g2row + 8 * c + 4 * hi) = g2;
+    }
+    store_regs<KC>(a.gus + (l + 1) * lstride + m * H, hi, valid, gh);
+  }
+  // ------------------------------ sweep 2: top-down ------------------------------
+  __syncthreads();
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  {
+    float fb[FC * 4];
+    const bool hasf = a.fbar != nullptr && mc < a.m_fbar;
+    if (hasf) load_regs<FC>(a.fbar + mc * F, hi, fb);
+    else {
+#pragma unroll
+      for (int i = 0; i < FC * 4; ++i) fb[i] = 0.f;
+    }
+    dense_op_nobias<NT, FC, 1>(ws, fb, acc, tid);
+    float wv[KC * 4];
+    f32x4 sc;
+    rowvec_load<KC>(ws, wv, sc, tid);
+    const float sb = a.sbar ? a.sbar[mc] : 0.f;
+    if (valid && hi == 0) {
+      *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a.ones4 + m * 4) = f32x4{1.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < KC * 4; ++i) gh[i] = acc[i / 16][i % 16] + sb * wv[i];       // G(h_{L-1})
+  }
+  for (int l = a.L - 2; l >= 0; --l) {
+    const float* hrow = a.hs + l * lstride + mc * H;
+    float* grow = a.gas + l * lstride + m * H;
+    const float* growc = a.gas + l * lstride + mc * H;
+    float ga[KC * 4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 8 * c + 4 * hi);
+      const f32x4 g2 = *reinterpret_cast<const f32x4*>(growc + 8 * c + 4 * hi);
+      f32x4 o;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        o[t] = fmaf(gh[c * 4 + t], sp_sigma_from_h(hv[t]), g2[t]);
+        ga[c * 4 + t] = o[t];
+      }
+      if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
+    }
+    if (l == 0) break;
+    if (l == a.skip) {
+      f32x16 as[NT + PT];
+      dense_op_nobias<NT + PT, KC, 1>(ws, ga, as, tid);
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) gh[i] = as[i / 16][i % 16] * RS2;
+    } else {
+      dense_op_nobias<NT, KC, 1>(ws, ga, acc, tid);
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) gh[i] = acc[i / 16][i % 16];
+    }
+  }
+}
+
+}  // namespace
+
+// ---- radiance net backward ---------------------------------------------------------------------------------
+struct RgbBwdArgs {
+  const float* rev; int n_rev; int L;
+  int64_t M, Mp;
+  const float* rgb;         // (M,3) forward output
+  const float* rgb_bar;     // (M,3)
+  const float* rs;          // (L-1, Mp, H)
+  float* gar;               // (L-1, Mp, H)  G(a_l), l = 0..L-2
+  float* ga_last;           // (Mp, 4)       G(a_{L-1}) (3 used)
+  float* fbar;              // (Mp, F)
+};
+
+namespace {
+
+__host__ __device__ constexpr int rgb_rev_stages(int H, int F, int L) {
+  int c = rowvec_chunks(H / 8, 3);
+  for (int l = L - 2; l >= 1; --l) c += bwd_op_chunks(H / 32, H / 8);
+  c += bwd_op_chunks(F / 32, H / 8);
+  return c / SC;
+}
+
+template <int H, int F>
+__global__ __launch_bounds__(256) void rgb_bwd_kernel(RgbBwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, FT = F / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float g3[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float c = a.rgb[mc * 3 + j];
+    g3[j] = a.rgb_bar[mc * 3 + j] * c * (1.0f - c);
+  }
+  if (valid && hi == 0) *reinterpret_cast<f32x4*>(a.ga_last + m * 4) = f32x4{g3[0], g3[1], g3[2], 0.f};
+  WStream ws;
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float gr[KC * 4];
+  {
+    // G(r_{L-1}) = W_last^T G(a_last): three row vectors
+    constexpr int NW = 3 * KC, TOT = rowvec_chunks(KC, 3), NS = TOT / SC;
+#pragma unroll
+    for (int i = 0; i < KC * 4; ++i) gr[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+#pragma unroll
+      for (int j = 0; j < SC; ++j) {
+        const int c = s * SC + j;
+        if (c < NW) {
+          const int row = c / KC, kc = c % KC;
+          const f32x4 w = cur[j * 64];
+          gr[kc * 4 + 0] = fmaf(w.x, g3[row], gr[kc * 4 + 0]);
+          gr[kc * 4 + 1] = fmaf(w.y, g3[row], gr[kc * 4 + 1]);
+          gr[kc * 4 + 2] = fmaf(w.z, g3[row], gr[kc * 4 + 2]);
+          gr[kc * 4 + 3] = fmaf(w.w, g3[row], gr[kc * 4 + 3]);
+        }
+      }
+    }
+  }
+  f32x16 acc[NT];
+  for (int l = a.L - 2; l >= 0; --l) {
+    const float* rrow = a.rs + l * lstride + mc * H;
+    float* grow = a.gar + l * lstride + m * H;
+    float ga[KC * 4];
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(rrow + 8 * c + 4 * hi);
+      f32x4 o;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { o[t] = rv[t] > 0.f ? gr[c * 4 + t] : 0.f; ga[c * 4 + t] = o[t]; }
+      if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
+    }
+    if (l == 0) {
+      f32x16 fa[FT];
+      dense_op_nobias<FT, KC, 1>(ws, ga, fa, tid);
+      store_tile<FT>(a.fbar + m * F, hi, valid, fa);
+    } else {
+      dense_op_nobias<NT, KC, 1>(ws, ga, acc, tid);
+#pragma unroll
+      for (int i = 0; i < KC * 4; ++i) gr[i] = acc[i / 16][i % 16];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, const float* points, const float* cam, const float* dirs,
+                                  const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M, int64_t Mp,
+                                  const float* hs, const float* abars, const float* sbar, const float* fbar, int64_t m_fbar,
+                                  const float* nbar, float* gus, float* gpbar, float* gas, float* ga_last4, float* ones4, void* stream) {
+  if (!p || !packed || !hs || !abars || !gus || !gpbar || !gas || !ga_last4 || !ones4 || M < 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  if (n_ray_pts < 0 || n_ray_pts > M || (n_ray_pts > 0 && (!cam || !dirs || !z || n_per_ray <= 0)) || (n_ray_pts < M && !points))
+    return I2SDF_EINVAL;
+  const i2sdf_mlp_desc& d = p->sdf.d;
+  if (d.multires != 6) return I2SDF_EINVAL;
+  SdfBwdArgs a{};
+  const float* base = packed + p->scale_floats;
+  a.fwd = base + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
+  a.rev = base + p->sdf.rev_chunk0 * CHUNK_FLOATS;
+  a.L = d.n_lin; a.skip = d.skip_layer;
+  a.pts = PointSpec{points, cam, dirs, z, ldz, n_ray_pts, n_per_ray > 0 ? n_per_ray : 1};
+  a.M = M; a.Mp = Mp; a.hs = hs; a.abars = abars; a.sbar = sbar; a.fbar = fbar; a.m_fbar = m_fbar; a.nbar = nbar;
+  a.gus = gus; a.gpbar = gpbar; a.gas = gas; a.ga_last4 = ga_last4; a.ones4 = ones4;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  const bool has_skip = d.skip_layer > 0;
+  if (p->H == 256 && p->F == 256) {
+    a.n_fwd = sdf_fwd_hidden_stages(256, PE<6>::PEC, d.n_lin, has_skip);
+    a.n_rev = sdf_rev_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
+    sdf_bwd_kernel<256, 256, 6><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else if (p->H == 64 && p->F == 64) {
+    a.n_fwd = sdf_fwd_hidden_stages(64, PE<6>::PEC, d.n_lin, has_skip);
+    a.n_rev = sdf_rev_bwd_stages(64, 64, PE<6>::PEC, d.n_lin, has_skip);
+    sdf_bwd_kernel<64, 64, 6><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else return I2SDF_EINVAL;
+  return i2sdf_hip_check(hipGetLastError(), "sdf_backward launch");
+}
+
+extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, const float* rgb, const float* rgb_bar, const float* rs,
+                                  int64_t M, int64_t Mp, float* gar, float* ga_last, float* fbar, void* stream) {
+  if (!p || !packed || !rgb || !rgb_bar || !rs || !gar || !ga_last || !fbar || M < 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  const i2sdf_mlp_desc& d = p->rgb.d;
+  RgbBwdArgs a{};
+  a.rev = packed + p->scale_floats + p->rgb.rev_chunk0 * CHUNK_FLOATS;
+  a.L = d.n_lin; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rgb_bar = rgb_bar; a.rs = rs; a.gar = gar; a.ga_last = ga_last; a.fbar = fbar;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (d.hidden == 256 && p->F == 256) {
+    a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
+    rgb_bwd_kernel<256, 256><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else if (d.hidden == 64 && p->F == 64) {
+    a.n_rev = rgb_rev_stages(64, 64, d.n_lin);
+    rgb_bwd_kernel<64, 64><<<grid, 256, LDS_BYTES, st>>>(a);
+  } else return I2SDF_EINVAL;
+  return i2sdf_hip_check(hipGetLastError(), "rgb_backward launch");
+}

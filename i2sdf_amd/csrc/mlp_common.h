@@ -102,6 +102,28 @@ __device__ __forceinline__ void rowvec_load(WStream& ws, float (&w)[KC * 4], f32
   }
 }
 
+// point m of a batch laid out as [n_ray_pts points generated from rays | explicit points]:
+//   m <  n_ray_pts : x = cam[r] + z[r*ldz + j] * dirs[r], r = m / n_per_ray, j = m % n_per_ray  (mul then add, two
+//                    roundings, as `cam_loc + z_vals * ray_dirs` does, model/network/__init__.py:103)
+//   m >= n_ray_pts : x = points[m - n_ray_pts]
+struct PointSpec {
+  const float* points; const float* cam; const float* dirs; const float* z;
+  int64_t ldz; int64_t n_ray_pts; int32_t n_per_ray;
+};
+__device__ __forceinline__ void fetch_point(const PointSpec& a, int64_t m, float& x, float& y, float& z) {
+  if (m < a.n_ray_pts) {
+    const int64_t ray = m / a.n_per_ray;
+    const int j = (int)(m - ray * a.n_per_ray);
+    const float t = a.z[ray * a.ldz + j];
+    x = __fadd_rn(a.cam[ray * 3 + 0], __fmul_rn(t, a.dirs[ray * 3 + 0]));
+    y = __fadd_rn(a.cam[ray * 3 + 1], __fmul_rn(t, a.dirs[ray * 3 + 1]));
+    z = __fadd_rn(a.cam[ray * 3 + 2], __fmul_rn(t, a.dirs[ray * 3 + 2]));
+  } else {
+    const int64_t i = m - a.n_ray_pts;
+    x = a.points[i * 3 + 0]; y = a.points[i * 3 + 1]; z = a.points[i * 3 + 2];
+  }
+}
+
 // ---- positional-encoding Jacobian helpers -----------------------------------------------------------
 // coefficient d PE_k / d x_axis(k) for every k of the padded PE space, from the PE values themselves:
 //   identity: 1 ; sin(f x): f cos(f x) = f * PE[k+3] ; cos(f x): -f sin(f x) = -f * PE[k-3]

@@ -14,31 +14,17 @@ struct SdfTrainFwdArgs {
   const float* fwd; int n_fwd;
   const float* rev; int n_rev;          // starts at the w_sdf row vector
   int L, skip;
-  const float* points;                  // (M,3) or nullptr -> ray mode
-  const float* cam; const float* dirs; const float* z; int64_t ldz; int n_per_ray;   // ray mode: x = cam[r] + z[r,j]*dirs[r]
+  PointSpec pts;
   int64_t M, Mp;
   float* sdf;                           // (M)
   float* feat;                          // (Mp, F)
   float* grad;                          // (M,3) or nullptr
   float* hs;                            // (L-1, Mp, H)  h_1..h_{L-1}   or nullptr (no saves: eval)
   float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
+  float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
 };
 
 namespace {
-
-__device__ __forceinline__ void fetch_point(const SdfTrainFwdArgs& a, int64_t mc, float& x, float& y, float& z) {
-  if (a.points != nullptr) {
-    x = a.points[mc * 3 + 0]; y = a.points[mc * 3 + 1]; z = a.points[mc * 3 + 2];
-  } else {
-    const int64_t ray = mc / a.n_per_ray;
-    const int j = (int)(mc - ray * a.n_per_ray);
-    const float t = a.z[ray * a.ldz + j];
-    // mul then add, two roundings, as `cam_loc + z_vals * ray_dirs` does (model/network/__init__.py:103)
-    x = __fadd_rn(a.cam[ray * 3 + 0], __fmul_rn(t, a.dirs[ray * 3 + 0]));
-    y = __fadd_rn(a.cam[ray * 3 + 1], __fmul_rn(t, a.dirs[ray * 3 + 1]));
-    z = __fadd_rn(a.cam[ray * 3 + 2], __fmul_rn(t, a.dirs[ray * 3 + 2]));
-  }
-}
 
 template <int H, int F, int LF, bool GRAD>
 __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
@@ -49,13 +35,14 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   float px, py, pz;
-  fetch_point(a, mc, px, py, pz);
+  fetch_point(a.pts, mc, px, py, pz);
   float pe[PEC * 4];
   {
     float full[PEC * 8];
     pe_full<LF>(px, py, pz, full);
     to_b_layout<PEC>(full, pe, hi);
   }
+  if (a.pe_save) store_regs<PEC>(a.pe_save + m * (PEC * 8), hi, valid, pe);
   const int64_t lstride = a.Mp * H;
   WStream ws;
   ws.begin(a.fwd, lds, a.n_fwd, tid);
@@ -151,6 +138,7 @@ struct RgbFwdArgs {
   int64_t M, Mp;
   float* rgb;                           // (M,3)
   float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
+  float* pev_save;                      // (Mp, PECV*8) PE(view dir), or nullptr
 };
 
 namespace {
@@ -176,6 +164,7 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
     float full[PECV * 8], pv[PECV * 4];
     pe_full<LFV>(a.dirs[ray * 3 + 0], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2], full);
     to_b_layout<PECV>(full, pv, hi);
+    if (a.pev_save) store_regs<PECV>(a.pev_save + m * (PECV * 8), hi, valid, pv);
     float ft[FC * 4];
     load_regs<FC>(a.feat + mc * F, hi, ft);
 #pragma unroll
@@ -214,12 +203,15 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
 
 // =============================================================================================================
 extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, const float* points, const float* cam,
-                                      const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t M, int64_t Mp,
-                                      float* sdf, float* feat, float* grad, float* hs, float* abars, void* stream) {
+                                      const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M,
+                                      int64_t Mp, float* sdf, float* feat, float* grad, float* hs, float* abars, float* pe_save,
+                                      void* stream) {
   if (!p || !packed || M < 0 || !sdf) return I2SDF_EINVAL;
   if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
-  if (!points && (!cam || !dirs || !z || n_per_ray <= 0)) return I2SDF_EINVAL;
+  if (n_ray_pts < 0 || n_ray_pts > M) return I2SDF_EINVAL;
+  if (n_ray_pts > 0 && (!cam || !dirs || !z || n_per_ray <= 0)) return I2SDF_EINVAL;
+  if (n_ray_pts < M && !points) return I2SDF_EINVAL;
   if (grad && !hs) return I2SDF_EINVAL;          // the reverse chain re-reads h_l
   const i2sdf_mlp_desc& d = p->sdf.d;
   if (d.multires != 6) return I2SDF_EINVAL;
@@ -228,8 +220,8 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
   a.fwd = base + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
   a.rev = base + p->sdf.rev_wsdf_chunk * CHUNK_FLOATS;
   a.L = d.n_lin; a.skip = d.skip_layer;
-  a.points = points; a.cam = cam; a.dirs = dirs; a.z = z; a.ldz = ldz; a.n_per_ray = n_per_ray;
-  a.M = M; a.Mp = Mp; a.sdf = sdf; a.feat = feat; a.grad = grad; a.hs = hs; a.abars = abars;
+  a.pts = PointSpec{points, cam, dirs, z, ldz, n_ray_pts, n_per_ray > 0 ? n_per_ray : 1};
+  a.M = M; a.Mp = Mp; a.sdf = sdf; a.feat = feat; a.grad = grad; a.hs = hs; a.abars = abars; a.pe_save = pe_save;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   const bool has_skip = d.skip_layer > 0;
@@ -248,7 +240,7 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
 }
 
 extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
-                                 int64_t M, int64_t Mp, float* rgb, float* rs, void* stream) {
+                                 int64_t M, int64_t Mp, float* rgb, float* rs, float* pev_save, void* stream) {
   if (!p || !packed || !dirs || !feat || !rgb || M < 0 || n_per_ray <= 0) return I2SDF_EINVAL;
   if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
@@ -256,7 +248,7 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   if (d.multires != 4) return I2SDF_EINVAL;
   RgbFwdArgs a{};
   a.fwd = packed + p->scale_floats + p->rgb.fwd_chunk0 * CHUNK_FLOATS;
-  a.L = d.n_lin; a.dirs = dirs; a.n_per_ray = n_per_ray; a.feat = feat; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rs = rs;
+  a.L = d.n_lin; a.dirs = dirs; a.n_per_ray = n_per_ray; a.feat = feat; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rs = rs; a.pev_save = pev_save;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {

@@ -171,15 +171,30 @@ int build_light(i2sdf_plan* p, Builder& b) {
   return I2SDF_OK;
 }
 
-void assign_scales_and_wgrad(i2sdf_plan* p, NetPlan& np) {
-  for (int l = 0; l < np.d.n_lin; ++l) {
+// kind: 0 = sdf net, 1 = radiance net, 2 = light head
+void assign_scales_and_wgrad(i2sdf_plan* p, NetPlan& np, int kind) {
+  const i2sdf_mlp_desc& d = np.d;
+  const int PEC8 = pe_chunks(d) * 8;
+  for (int l = 0; l < d.n_lin; ++l) {
     np.scale_off[l] = p->n_scale;
-    p->n_scale += np.d.out_dim[l];
-    // effective-weight gradient block: padded [rows32][cols(+pad to 32)]
-    np.wg_rows[l] = round_up(np.d.out_dim[l], 32);
-    np.wg_cols[l] = round_up(np.d.in_dim[l] + 32, 32);
+    p->n_scale += d.out_dim[l];
+    // effective-weight gradient block [rowsP][colsP] in the layer's padded input space, followed by the bias-grad row
+    const bool last = (l == d.n_lin - 1);
+    int rowsP = d.hidden, colsP = d.hidden;
+    if (kind == 0) {
+      if (l == 0) colsP = PEC8;
+      else if (l == d.skip_layer) colsP = d.hidden + PEC8;
+      if (last) rowsP = 32 + (d.d_out - 1);
+    } else if (kind == 1) {
+      if (l == 0) colsP = PEC8 + (d.in0 - pe_dim(d));
+      if (last) rowsP = 32;
+    } else {
+      if (l == 0) colsP = d.in0;
+      if (last) rowsP = 32;
+    }
+    np.wg_rows[l] = rowsP; np.wg_cols[l] = colsP;
     np.wgrad_off[l] = p->wgrad_floats;
-    p->wgrad_floats += (int64_t)np.wg_rows[l] * np.wg_cols[l] + np.wg_rows[l];   // + bias-grad row
+    p->wgrad_floats += (int64_t)rowsP * colsP + rowsP;
   }
 }
 
@@ -190,9 +205,9 @@ extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
   i2sdf_plan* p = new i2sdf_plan();
   p->desc = *desc;
   p->sdf.d = desc->sdf; p->rgb.d = desc->rgb; p->light.d = desc->light;
-  assign_scales_and_wgrad(p, p->sdf);
-  assign_scales_and_wgrad(p, p->rgb);
-  if (desc->light.n_lin) assign_scales_and_wgrad(p, p->light);
+  assign_scales_and_wgrad(p, p->sdf, 0);
+  assign_scales_and_wgrad(p, p->rgb, 1);
+  if (desc->light.n_lin) assign_scales_and_wgrad(p, p->light, 2);
   p->scale_floats = round_up(p->n_scale, CHUNK_FLOATS);
   Builder b{p->segs, 0};
   int rc = build_sdf(p, b);
@@ -202,16 +217,23 @@ extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
   { Seg z{}; z.type = SEG_ZERO; z.nchunks = SC; b.add(z); }   // slack: the DMA look-ahead may touch one stage past the end
   p->total_chunks = b.chunk;
   p->n_segs = (int32_t)p->segs.size();
+  // Device copy of the segment table.  On a host without a GPU the plan is still usable for layout queries
+  // (sizes, argument validation); every launch entry point then fails with I2SDF_EHIP.
   hipError_t e = hipMalloc((void**)&p->d_segs, sizeof(Seg) * p->segs.size());
   if (e == hipSuccess) e = hipMemcpy(p->d_segs, p->segs.data(), sizeof(Seg) * p->segs.size(), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { rc = i2sdf_hip_check(e, "plan table upload"); if (p->d_segs) hipFree(p->d_segs); delete p; return rc; }
+  if (e != hipSuccess) {
+    (void)i2sdf_hip_check(e, "plan table upload");
+    if (p->d_segs) (void)hipFree(p->d_segs);
+    p->d_segs = nullptr;
+    (void)hipGetLastError();
+  }
   *out = p;
   return I2SDF_OK;
 }
 
 extern "C" void i2sdf_plan_destroy(i2sdf_plan* p) {
   if (!p) return;
-  if (p->d_segs) hipFree(p->d_segs);
+  if (p->d_segs) (void)hipFree(p->d_segs);
   delete p;
 }
 

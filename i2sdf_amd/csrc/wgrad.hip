@@ -1,0 +1,294 @@
+// Weight-gradient GEMMs  dW[n][k] = sum_m X[m][n] * Y[m][k]  over the per-point tensors the backward kernels saved,
+// followed by the split-M reduction fused with the weight-norm backward.
+// In the reference these are the `mm`/`addmm` backward nodes autograd runs for every nn.Linear (mlp.py:97,222) plus
+// the _weight_norm backward.  X, Y are point-major ([Mp][ld]); a wave owns a 128x128 output tile and streams
+// point pairs straight from HBM into MFMA operands (fp32 32x32x2: the reduction index of the MFMA is the point).
+#include <algorithm>
+#include "plan.h"
+
+using namespace i2sdf;
+
+int i2sdf_hip_check(hipError_t e, const char* what);
+
+namespace {
+
+constexpr int WG_CH = 1024;          // points per split-M chunk
+constexpr int PFW = 4;               // point pairs in flight
+constexpr int MAX_TASKS = 30;
+
+struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; };
+struct WgTask {
+  WgJob j[2];
+  int32_t njobs, relu_b, has_bias, rows_store, cols_store, ldo;
+  int64_t out_off, bias_off;
+};
+struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t pad; int64_t chunk_stride; float* partials; };
+
+__global__ __launch_bounds__(256) void wgrad_kernel(WgLaunch L) {
+  const int lane = threadIdx.x & 63;
+  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (tile >= L.n) return;
+  const WgTask& t = L.t[tile];
+  const int64_t chunk = blockIdx.y;
+  const int i32 = lane & 31, hi = lane >> 5;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const WgJob job = t.j[jb];
+    const int64_t m_lo = chunk * WG_CH;
+    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
+    if (m_hi <= m_lo) continue;
+    const int npairs = (int)((m_hi - m_lo + 1) / 2);
+    const bool a_ok = 4 * i32 < job.a_w, b_ok = 4 * i32 < job.b_w;
+    const float* Ap = job.A + (m_lo + hi) * job.lda + 4 * i32;
+    const float* Bp = job.B + (m_lo + hi) * job.ldb + 4 * i32;
+    const int64_t a_step = 2 * (int64_t)job.lda, b_step = 2 * (int64_t)job.ldb;
+    const bool relu = t.relu_b != 0;
+    const bool do_bias = t.has_bias && jb == 0;
+    f32x4 ab[PFW], bb[PFW];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < PFW; ++u) {
+      const bool in = (m_lo + 2 * u + hi) < m_hi;
+      ab[u] = (in && a_ok) ? *reinterpret_cast<const f32x4*>(Ap + u * a_step) : zero;
+      bb[u] = (in && b_ok) ? *reinterpret_cast<const f32x4*>(Bp + u * b_step) : zero;
+    }
+    for (int p = 0; p < npairs; p += PFW) {
+#pragma unroll
+      for (int u = 0; u < PFW; ++u) {
+        f32x4 a = ab[u], b = bb[u];
+        const int pn = p + u + PFW;
+        const bool in = (m_lo + 2 * (int64_t)pn + hi) < m_hi;
+        ab[u] = (in && a_ok) ? *reinterpret_cast<const f32x4*>(Ap + pn * a_step) : zero;
+        bb[u] = (in && b_ok) ? *reinterpret_cast<const f32x4*>(Bp + pn * b_step) : zero;
+        if (relu) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
+        if (do_bias) bsum += a;
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma(a[ta], b[tb], acc[ta][tb]);
+      }
+    }
+  }
+  float* out = L.partials + chunk * L.chunk_stride;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = 4 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + ta;
+      if (n < t.rows_store && 4 * i32 < t.cols_store) {
+        const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+        *reinterpret_cast<f32x4*>(out + t.out_off + (int64_t)n * t.ldo + 4 * i32) = v;
+      }
+    }
+  if (t.has_bias) {
+    f32x4 tot;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tot[q] = bsum[q] + __shfl_xor(bsum[q], 32);
+    if (hi == 0 && 4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = tot;
+  }
+}
+
+// ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
+struct WnLayer {
+  int64_t off_v, off_g, off_bias, blk_off, bias_blk_off;
+  int32_t rows, cols, row0, ldo, rsplit, rbase, split, base1, valid0;
+  float mult;
+};
+struct WnTab { WnLayer l[3 * I2SDF_MAX_LAYERS]; int32_t n; int32_t n_rows; };
+
+__global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float* __restrict__ params, const float* __restrict__ partials,
+                                                           int n_chunks, int64_t chunk_stride, float* __restrict__ grad) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= tab.n_rows) return;
+  int e = 0;
+  while (e + 1 < tab.n && row >= tab.l[e + 1].row0) ++e;
+  const WnLayer& y = tab.l[e];
+  const int r = row - y.row0;
+  const int brow = r < y.rsplit ? r : r - y.rsplit + y.rbase;
+  const float* v = params + y.off_v + (int64_t)r * y.cols;
+  constexpr int MAXC = 5;      // cols <= 320
+  float dw[MAXC], vv[MAXC];
+  float dot = 0.f, nrm2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = lane + 64 * q;
+    dw[q] = 0.f; vv[q] = 0.f;
+    if (c < y.cols) {
+      const int kp = c < y.valid0 ? c : y.split + (c - y.base1);
+      const float* src = partials + y.blk_off + (int64_t)brow * y.ldo + kp;
+      float s = 0.f;
+      for (int ch = 0; ch < n_chunks; ++ch) s += src[ch * chunk_stride];
+      dw[q] = s * y.mult;
+      vv[q] = v[c];
+      dot = fmaf(dw[q], vv[q], dot);
+      nrm2 = fmaf(vv[q], vv[q], nrm2);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o); nrm2 += __shfl_xor(nrm2, o); }
+  const float nrm = sqrtf(nrm2);
+  const float g = params[y.off_g + r];
+  const float gs = g / nrm, dn = dot / nrm2;
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = lane + 64 * q;
+    if (c < y.cols) grad[y.off_v + (int64_t)r * y.cols + c] = gs * (dw[q] - vv[q] * dn);
+  }
+  if (lane == 0) {
+    grad[y.off_g + r] = dot / nrm;
+    float b = 0.f;
+    const float* bs = partials + y.bias_blk_off + brow;
+    for (int ch = 0; ch < n_chunks; ++ch) b += bs[ch * chunk_stride];
+    grad[y.off_bias + r] = b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Src { const float* p; int ld; int w; };     // a [Mp][ld] matrix and the width used from it
+
+struct TaskList {
+  std::vector<WgTask> tasks;
+  // Emit the tiles of one weight block.  rows: segments of A (one per source, stacked in block rows at row0[i]);
+  // cols: segments of B.  job 0 = (A0[i], B0[k]) over m0 points, job 1 = (A1[i], B1[k]) over m1 points (optional).
+  void add_block(int64_t blk_off, int ldo, int64_t bias_off, const std::vector<Src>& A0, const std::vector<Src>& A1,
+                 const std::vector<int>& row0, const std::vector<int64_t>& mA0, const std::vector<Src>& B0, const std::vector<Src>& B1,
+                 int64_t m1, bool relu_b) {
+    int col0 = 0;
+    for (size_t k = 0; k < B0.size(); ++k) {
+      for (int ct = 0; ct * 128 < B0[k].w; ++ct) {
+        for (size_t i = 0; i < A0.size(); ++i) {
+          for (int rt = 0; rt * 128 < A0[i].w; ++rt) {
+            WgTask t{};
+            const int aw = std::min(128, A0[i].w - rt * 128), bw = std::min(128, B0[k].w - ct * 128);
+            t.j[0] = WgJob{A0[i].p + rt * 128, B0[k].p + ct * 128, A0[i].ld, B0[k].ld, aw, bw, mA0[i]};
+            t.njobs = 1;
+            if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
+              t.j[1] = WgJob{A1[i].p + rt * 128, B1[k].p + ct * 128, A1[i].ld, B1[k].ld, aw, bw, m1};
+              t.njobs = 2;
+            }
+            t.relu_b = relu_b ? 1 : 0;
+            t.has_bias = (k == 0 && ct == 0) ? 1 : 0;
+            t.rows_store = aw; t.cols_store = bw; t.ldo = ldo;
+            t.out_off = blk_off + (int64_t)(row0[i] + rt * 128) * ldo + col0 + ct * 128;
+            t.bias_off = bias_off + row0[i] + rt * 128;
+            tasks.push_back(t);
+          }
+        }
+      }
+      col0 += B0[k].w;
+    }
+  }
+};
+
+void fill_wn(WnTab& tab, const NetPlan& np, int kind, int& row0) {
+  const i2sdf_mlp_desc& d = np.d;
+  const int PEC8 = (d.multires > 0 ? cdiv(d.d_in + 2 * d.d_in * d.multires, 8) : 0) * 8;
+  const int PED = d.multires > 0 ? d.d_in + 2 * d.d_in * d.multires : d.d_in;
+  for (int l = 0; l < d.n_lin; ++l) {
+    WnLayer& y = tab.l[tab.n++];
+    y.off_v = d.off_v[l]; y.off_g = d.off_g[l]; y.off_bias = d.off_bias[l];
+    y.rows = d.out_dim[l]; y.cols = d.in_dim[l]; y.row0 = row0; row0 += y.rows;
+    y.ldo = np.wg_cols[l];
+    y.blk_off = np.wgrad_off[l];
+    y.bias_blk_off = np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l];
+    y.rsplit = 1 << 30; y.rbase = 0; y.split = 0; y.base1 = 0; y.valid0 = y.cols; y.mult = 1.0f;
+    const bool last = l == d.n_lin - 1;
+    if (kind == 0) {
+      if (l == d.skip_layer) { y.valid0 = y.cols - PED; y.split = d.hidden; y.base1 = y.cols - PED; y.mult = 0.70710678118654752440f; }
+      if (last) { y.rsplit = 1; y.rbase = 32; }
+    } else if (kind == 1) {
+      if (l == 0) { y.valid0 = PED; y.split = PEC8; y.base1 = PED; }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t i2sdf_wgrad_chunk_points(void) { return WG_CH; }
+
+extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers* tb, const float* params, float* partials,
+                                  int64_t n_chunks_cap, float* grad_flat, void* stream) {
+  if (!p || !tb || !params || !partials || !grad_flat) return I2SDF_EINVAL;
+  const int64_t Mp = tb->Mp, Ms = tb->M_sdf, Mm = tb->M_main;
+  if (Ms <= 0 || Mm < 0 || Mm > Ms || Mp < Ms) return I2SDF_EINVAL;
+  const int n_chunks = (int)((Ms + WG_CH - 1) / WG_CH);
+  if (n_chunks > n_chunks_cap) return I2SDF_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  TaskList tl;
+  {  // ---- SDF net
+    const NetPlan& np = p->sdf;
+    const i2sdf_mlp_desc& d = np.d;
+    const int L = d.n_lin, H = d.hidden, F = p->F, PEC8 = cdiv(d.in0, 8) * 8;
+    const int64_t ls = Mp * H;
+    for (int l = 0; l < L - 1; ++l) {
+      std::vector<Src> B0, B1;
+      if (l == 0) { B0 = {{tb->pe, PEC8, PEC8}}; B1 = {{tb->gpbar, PEC8, PEC8}}; }
+      else {
+        B0 = {{tb->hs + (l - 1) * ls, H, H}}; B1 = {{tb->gus + l * ls, H, H}};
+        if (l == d.skip_layer) { B0.push_back({tb->pe, PEC8, PEC8}); B1.push_back({tb->gpbar, PEC8, PEC8}); }
+      }
+      tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l],
+                   {{tb->gas + l * ls, H, H}}, {{tb->abars + l * ls, H, H}}, {0}, {Ms}, B0, B1, Ms, false);
+    }
+    {
+      const int l = L - 1;
+      std::vector<Src> A0 = {{tb->ga_last4, 4, 4}}, A1 = {{tb->ones4, 4, 4}};
+      std::vector<int> row0 = {0};
+      std::vector<int64_t> mA0 = {Ms};
+      if (F > 0 && Mm > 0 && tb->fbar) { A0.push_back({tb->fbar, F, F}); A1.push_back({nullptr, 0, 0}); row0.push_back(32); mA0.push_back(Mm); }
+      tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l], A0, A1, row0, mA0,
+                   {{tb->hs + (L - 2) * ls, H, H}}, {{tb->gus + (L - 1) * ls, H, H}}, Ms, false);
+    }
+  }
+  if (Mm > 0 && tb->gar) {  // ---- radiance net
+    const NetPlan& np = p->rgb;
+    const i2sdf_mlp_desc& d = np.d;
+    const int L = d.n_lin, H = d.hidden, F = p->F, PV8 = cdiv(d.in0 - F, 8) * 8;
+    const int64_t ls = Mp * H;
+    for (int l = 0; l < L; ++l) {
+      std::vector<Src> B0;
+      if (l == 0) B0 = {{tb->pev, PV8, PV8}, {tb->feat, F, F}};
+      else B0 = {{tb->rs + (l - 1) * ls, H, H}};
+      std::vector<Src> A0;
+      if (l < L - 1) A0 = {{tb->gar + l * ls, H, H}};
+      else A0 = {{tb->ga_last_rgb, 4, 4}};
+      tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l], A0, {}, {0}, {Mm}, B0, {}, 0,
+                   false);
+    }
+  }
+  const bool has_light = p->light.d.n_lin > 0 && Mm > 0 && tb->gal0;
+  size_t light_first = tl.tasks.size();
+  if (has_light) {  // ---- light head: l=0: A = G(a_0), B = relu(feature) ; l=1: A = G(a_1), B = softplus acts
+    const NetPlan& np = p->light;
+    const int H = np.d.hidden, F = p->F;
+    tl.add_block(np.wgrad_off[0], np.wg_cols[0], np.wgrad_off[0] + (int64_t)np.wg_rows[0] * np.wg_cols[0], {{tb->gal0, H, H}}, {}, {0}, {Mm},
+                 {{tb->feat, F, F}}, {}, 0, true);
+    tl.add_block(np.wgrad_off[1], np.wg_cols[1], np.wgrad_off[1] + (int64_t)np.wg_rows[1] * np.wg_cols[1], {{tb->gal_last, 4, 4}}, {}, {0},
+                 {Mm}, {{tb->hl, H, H}}, {}, 0, false);
+  }
+  (void)light_first;
+  for (size_t off = 0; off < tl.tasks.size(); off += MAX_TASKS) {
+    WgLaunch L{};
+    L.n = (int32_t)std::min<size_t>(MAX_TASKS, tl.tasks.size() - off);
+    for (int i = 0; i < L.n; ++i) L.t[i] = tl.tasks[off + i];
+    L.chunk_stride = p->wgrad_floats; L.partials = partials;
+    dim3 grid((unsigned)cdiv(L.n, 4), (unsigned)n_chunks);
+    wgrad_kernel<<<grid, 256, 0, st>>>(L);
+  }
+  WnTab tab{};
+  int row0 = 0;
+  fill_wn(tab, p->sdf, 0, row0);
+  if (Mm > 0 && tb->gar) fill_wn(tab, p->rgb, 1, row0);
+  if (has_light) fill_wn(tab, p->light, 2, row0);
+  tab.n_rows = row0;
+  wn_backward_kernel<<<cdiv(row0, 4), 256, 0, st>>>(tab, params, partials, n_chunks, p->wgrad_floats, grad_flat);
+  return i2sdf_hip_check(hipGetLastError(), "weight_grads launch");
+}

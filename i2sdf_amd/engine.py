@@ -59,28 +59,31 @@ class RenderEngine:
         return (M + 127) // 128 * 128
 
     def sdf_forward_grad(self, points=None, rays=None, want_grad=True, save=True, want_feat=True):
-        """points (M,3) or rays=(cam (B,3), dirs (B,3), z (B,n)).  Returns dict(sdf, feat, grad, hs, abars, Mp)."""
+        """Point batch = [points generated from rays=(cam (B,3), dirs (B,3), z (B,n)) | explicit points (P,3)]; either may be None.
+        Returns dict(sdf, feat, grad, hs, abars, pe, Mp, M, n_ray_pts)."""
         cfgs = self.cfg.sdf
         H, L = cfgs.hidden, cfgs.n_lin
+        pts = cam = dirs = z = None
+        n_ray, ldz, npr = 0, 0, 1
+        if rays is not None:
+            cam, dirs, z = (t.detach().to(torch.float32).contiguous() for t in rays)
+            n_ray, ldz, npr = z.shape[0] * z.shape[1], z.shape[1], z.shape[1]
+            dev = z.device
         if points is not None:
             pts = points.detach().to(torch.float32).contiguous()
-            M, dev = pts.shape[0], pts.device
-            cam = dirs = z = None
-            ldz, npr = 0, 1
-        else:
-            cam, dirs, z = (t.detach().to(torch.float32).contiguous() for t in rays)
-            pts = None
-            M, dev = z.shape[0] * z.shape[1], z.device
-            ldz, npr = z.shape[1], z.shape[1]
+            dev = pts.device
+        M = n_ray + (pts.shape[0] if pts is not None else 0)
         Mp = self.pad_rows(M)
-        out = {"Mp": Mp, "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
+        out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
         out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
         out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
         out["hs"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
         out["abars"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
+        out["pe"] = torch.empty(Mp, 40, dtype=torch.float32, device=dev) if save else None
         L_.check(self._lib.i2sdf_sdf_forward_grad(self._plan, L_.ptr(self.packed), L_.ptr(pts), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
-                                                  ldz, npr, M, Mp, L_.ptr(out["sdf"]), L_.ptr(out["feat"]), L_.ptr(out["grad"]),
-                                                  L_.ptr(out["hs"]), L_.ptr(out["abars"]), L_.stream_ptr()), "i2sdf_sdf_forward_grad")
+                                                  ldz, npr, n_ray, M, Mp, L_.ptr(out["sdf"]), L_.ptr(out["feat"]), L_.ptr(out["grad"]),
+                                                  L_.ptr(out["hs"]), L_.ptr(out["abars"]), L_.ptr(out["pe"]), L_.stream_ptr()),
+                 "i2sdf_sdf_forward_grad")
         return out
 
     def rgb_forward(self, dirs, n_per_ray, feat, M, save=True):
@@ -88,9 +91,59 @@ class RenderEngine:
         rgb = torch.empty(M, 3, dtype=torch.float32, device=feat.device)
         Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
         rs = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=feat.device) if save else None
+        pev = torch.empty(Mp, 32, dtype=torch.float32, device=feat.device) if save else None
         L_.check(self._lib.i2sdf_rgb_forward(self._plan, L_.ptr(self.packed), L_.ptr(dirs.contiguous()), n_per_ray, L_.ptr(feat), M, Mp,
-                                             L_.ptr(rgb), L_.ptr(rs), L_.stream_ptr()), "i2sdf_rgb_forward")
-        return rgb, rs
+                                             L_.ptr(rgb), L_.ptr(rs), L_.ptr(pev), L_.stream_ptr()), "i2sdf_rgb_forward")
+        return rgb, rs, pev
+
+    def rgb_backward(self, rgb, rgb_bar, rs, M):
+        Mp, dev = rs.shape[1], rs.device
+        Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
+        gar = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=dev)
+        ga_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
+        fbar = torch.empty(Mp, self.F, dtype=torch.float32, device=dev)
+        L_.check(self._lib.i2sdf_rgb_backward(self._plan, L_.ptr(self.packed), L_.ptr(rgb), L_.ptr(rgb_bar.contiguous()), L_.ptr(rs), M, Mp,
+                                              L_.ptr(gar), L_.ptr(ga_last), L_.ptr(fbar), L_.stream_ptr()), "i2sdf_rgb_backward")
+        return gar, ga_last, fbar
+
+    def sdf_backward(self, fw, sbar=None, fbar=None, m_fbar=0, nbar=None):
+        """fw = dict from sdf_forward_grad(save=True).  Returns the weight-gradient operands."""
+        cfgs = self.cfg.sdf
+        H, L = cfgs.hidden, cfgs.n_lin
+        Mp, M, dev = fw["Mp"], fw["M"], fw["hs"].device
+        cam, dirs, z = fw["rays"]
+        o = {"gus": torch.empty(L, Mp, H, dtype=torch.float32, device=dev), "gpbar": torch.empty(Mp, 40, dtype=torch.float32, device=dev),
+             "gas": torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
+             "ones4": torch.empty(Mp, 4, dtype=torch.float32, device=dev)}
+        c = lambda t: None if t is None else t.contiguous()
+        L_.check(self._lib.i2sdf_sdf_backward(self._plan, L_.ptr(self.packed), L_.ptr(fw["pts"]), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
+                                              z.shape[1] if z is not None else 0, z.shape[1] if z is not None else 1, fw["n_ray_pts"], M, Mp,
+                                              L_.ptr(fw["hs"]), L_.ptr(fw["abars"]), L_.ptr(c(sbar)), L_.ptr(c(fbar)), m_fbar, L_.ptr(c(nbar)),
+                                              L_.ptr(o["gus"]), L_.ptr(o["gpbar"]), L_.ptr(o["gas"]), L_.ptr(o["ga_last4"]), L_.ptr(o["ones4"]),
+                                              L_.stream_ptr()), "i2sdf_sdf_backward")
+        return o
+
+    def weight_grads(self, flat_params, grad_flat, fw, bw, M_main=0, fbar=None, rgb_fw=None, rgb_bw=None, light=None):
+        """Runs the weight-gradient GEMMs + weight-norm backward; writes into grad_flat (layout of flat_params)."""
+        tb = L_.TrainBuffers()
+        tb.M_sdf, tb.M_main, tb.Mp = fw["M"], M_main, fw["Mp"]
+        P = lambda t: None if t is None else t.data_ptr()
+        tb.pe, tb.hs, tb.abars = P(fw["pe"]), P(fw["hs"]), P(fw["abars"])
+        tb.gus, tb.gpbar, tb.gas, tb.ga_last4, tb.ones4 = P(bw["gus"]), P(bw["gpbar"]), P(bw["gas"]), P(bw["ga_last4"]), P(bw["ones4"])
+        tb.fbar = P(fbar)
+        tb.feat = P(fw["feat"])
+        if rgb_fw is not None:
+            tb.pev, tb.rs = P(rgb_fw["pev"]), P(rgb_fw["rs"])
+            tb.gar, tb.ga_last_rgb = P(rgb_bw["gar"]), P(rgb_bw["ga_last"])
+        if light is not None:
+            tb.hl, tb.gal0, tb.gal_last = P(light["hl"]), P(light["gal0"]), P(light["gal_last"])
+        ch = int(self._lib.i2sdf_wgrad_chunk_points())
+        n_chunks = (fw["M"] + ch - 1) // ch
+        partials = torch.empty(n_chunks * self.wgrad_floats, dtype=torch.float32, device=flat_params.device)
+        import ctypes as C_
+        L_.check(self._lib.i2sdf_weight_grads(self._plan, C_.byref(tb), L_.ptr(flat_params), L_.ptr(partials), n_chunks, L_.ptr(grad_flat),
+                                              L_.stream_ptr()), "i2sdf_weight_grads")
+        return partials
 
     # -- per-ray kernels -------------------------------------------------------------------------
     def ray_setup(self, uv, pose, intrinsics):

@@ -22,6 +22,12 @@ class NetDesc(C.Structure):
                 ("beta_min", C.c_float), ("scene_bounding_sphere", C.c_float)]
 
 
+class TrainBuffers(C.Structure):
+    _fields_ = [("M_sdf", C.c_int64), ("M_main", C.c_int64), ("Mp", C.c_int64)] + [(n, C.c_void_p) for n in (
+        "pe", "hs", "abars", "gus", "gpbar", "gas", "ga_last4", "ones4", "fbar", "pev", "feat", "rs", "gar", "ga_last_rgb",
+        "hl", "gal0", "gal_last")]
+
+
 class I2SDFError(RuntimeError):
     pass
 
@@ -40,11 +46,20 @@ SIGNATURES = {
     "i2sdf_plan_wgrad_floats": (_I64, [_P]),
     "i2sdf_pack_weights": (C.c_int, [_P, _P, _P, _P]),
     "i2sdf_sdf_forward": (C.c_int, [_P, _P, _P, _I64, _P, _P, _I64, _P]),
-    "i2sdf_sdf_forward_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    # plan, packed, points, cam, dirs, z, ldz, n_per_ray, n_ray_pts, M, Mp, sdf, feat, grad, hs, abars, pe_save, stream
+    "i2sdf_sdf_forward_grad": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 7),
+    # plan, packed, dirs, n_per_ray, feat, M, Mp, rgb, rs, pev_save, stream
+    "i2sdf_rgb_forward": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I64, _P, _P, _P, _P]),
+    # plan, packed, rgb, rgb_bar, rs, M, Mp, gar, ga_last, fbar, stream
+    "i2sdf_rgb_backward": (C.c_int, [_P] * 5 + [_I64, _I64] + [_P] * 4),
+    # plan, packed, points, cam, dirs, z, ldz, n_per_ray, n_ray_pts, M, Mp, hs, abars, sbar, fbar, m_fbar, nbar, gus, gpbar, gas,
+    # ga_last4, ones4, stream
+    "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
+    "i2sdf_wgrad_chunk_points": (_I64, []),
+    "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
-    "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "i2sdf_rgb_forward": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _I64, _P, _P, _P]),
+    "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
+    "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),
 }
 
 

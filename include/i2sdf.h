@@ -101,29 +101,54 @@ int i2sdf_sdf_forward(const i2sdf_plan* plan, const float* packed, const float* 
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Point batches.  The training kernels take a batch laid out as
+ *     [ n_ray_pts points generated from rays | (M - n_ray_pts) explicit points ]
+ * ray part:  x[m] = cam[r] + z[r*ldz + j]*dirs[r], r = m / n_per_ray, j = m % n_per_ray (model/network/__init__.py:103)
+ * explicit:  x[m] = points[m - n_ray_pts]        (eikonal / neighbour / bubble points, :178-201)
+ * Every per-point workspace below has Mp rows (Mp multiple of 128, >= M); rows >= M are never read.
+ *
  * SDF network forward WITH d sdf/dx and saved activations -- ImplicitNetwork.get_outputs / .gradient
  * (mlp.py:107-143) as called by the main render pass (model/network/__init__.py:113) and the eikonal pass
  * (:188).  The reference obtains d sdf/dx from torch.autograd.grad(create_graph=True); here the reverse
  * chain is explicit and fused into the same kernel.
- *   points (M,3), or NULL for ray mode: x[m] = cam[r] + z[r*ldz + j]*dirs[r], r = m / n_per_ray, j = m % n_per_ray
- *                                        (model/network/__init__.py:103)
- *   Mp      row count of the workspaces, multiple of 128, >= M
  *   sdf (M) ; feat (Mp,F) or NULL ; grad (M,3) or NULL
- *   hs    (L-1, Mp, H)  h_l = softplus100(a_{l-1}), l = 1..L-1   (needed when grad != NULL; NULL otherwise ok)
- *   abars (L-1, Mp, H)  d sdf / d a_l, l = 0..L-2                (NULL if no backward will follow)
+ *   hs      (L-1, Mp, H)  h_l = softplus100(a_{l-1}), l = 1..L-1   (required when grad != NULL)
+ *   abars   (L-1, Mp, H)  d sdf / d a_l, l = 0..L-2                (NULL if no backward will follow)
+ *   pe_save (Mp, 40)      PE(x), an operand of the weight-gradient GEMMs (NULL if no backward will follow)
  * ---------------------------------------------------------------------------------------------- */
 int i2sdf_sdf_forward_grad(const i2sdf_plan* plan, const float* packed, const float* points, const float* cam,
-                           const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t M, int64_t Mp,
-                           float* sdf, float* feat, float* grad, float* hs, float* abars, void* stream);
+                           const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M,
+                           int64_t Mp, float* sdf, float* feat, float* grad, float* hs, float* abars, float* pe_save,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Radiance network forward, 'nerf' mode -- RenderingNetwork.forward (mlp.py:208-229):
  * rgb = sigmoid(MLP([PE4(view_dir) | feature])).  dirs (B,3) unit view directions, point m uses dirs[m / n_per_ray].
- *   rgb (M,3) ; rs (L-1, Mp, H) post-ReLU activations (NULL if no backward will follow)
+ *   rgb (M,3) ; rs (L-1, Mp, H) post-ReLU activations and pev_save (Mp,32) PE(view) (NULL if no backward follows)
  * ---------------------------------------------------------------------------------------------- */
 int i2sdf_rgb_forward(const i2sdf_plan* plan, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
-                      int64_t M, int64_t Mp, float* rgb, float* rs, void* stream);
+                      int64_t M, int64_t Mp, float* rgb, float* rs, float* pev_save, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the radiance network (autograd through mlp.py:208-229).
+ *   rgb (M,3) forward output, rgb_bar (M,3) upstream, rs from the forward
+ *   -> gar (L-1, Mp, H) G(a_l) l=0..L-2 ; ga_last (Mp,4) G(a_{L-1}) ; fbar (Mp,F) d loss / d feature
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_rgb_backward(const i2sdf_plan* plan, const float* packed, const float* rgb, const float* rgb_bar, const float* rs,
+                       int64_t M, int64_t Mp, float* gar, float* ga_last, float* fbar, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the SDF network including the double backward through d sdf/dx (what loss.backward() does through
+ * mlp.py:84-143 with create_graph=True): sweep 1 = adjoint of the d sdf/dx chain, sweep 2 =
+ * ordinary backward.  Upstream: sbar (M) d/d sdf, fbar (Mp,F) d/d feature (rows >= m_fbar are zero), nbar (M,3) d/d grad;
+ * any of them may be NULL (= 0).  Emits the operands of the weight-gradient GEMMs:
+ *   gus (L, Mp, H)  G(hbar_l) for l = 1..L-1 (slot 0 unused) ; gpbar (Mp,40) G(pbar) ;
+ *   gas (L-1, Mp, H) G(a_l), l = 0..L-2 ; ga_last4 (Mp,4) {sbar,0,0,0} ; ones4 (Mp,4) {1,0,0,0}
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_sdf_backward(const i2sdf_plan* plan, const float* packed, const float* points, const float* cam, const float* dirs,
+                       const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M, int64_t Mp,
+                       const float* hs, const float* abars, const float* sbar, const float* fbar, int64_t m_fbar,
+                       const float* nbar, float* gus, float* gpbar, float* gas, float* ga_last4, float* ones4, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ray set-up -- utils/rend_util.py:92-147 (get_camera_params + lift, pose-matrix form) and
@@ -158,6 +183,26 @@ int i2sdf_composite_backward(const float* beta_param, float beta_min, const floa
                              const float* g_rgb, const float* g_depth, const float* g_wsum, const float* g_normal,
                              const float* g_lmask, float* sdf_bar, float* rgb_bar, float* grad_bar, float* lmask_bar,
                              float* beta_partial, float* beta_grad_accum, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Weight gradients: the dW = G^T U GEMMs of every nn.Linear (autograd's mm/addmm backward nodes for mlp.py:97,222),
+ * reduced over all points, then the weight-norm backward (d/dg, d/dv of W = g v/||v||) and bias gradients, written
+ * into `grad_flat` (same layout as `params`; entries of nets that took no part are left untouched).
+ * All pointers are the per-point workspaces the kernels above produced ([Mp][ld], see their comments).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_train_buffers {
+  int64_t M_sdf;    /* points that went through the SDF network (render + eikonal + bubble points) */
+  int64_t M_main;   /* leading points that also went through the radiance (and light) network        */
+  int64_t Mp;
+  const float *pe, *hs, *abars, *gus, *gpbar, *gas, *ga_last4, *ones4, *fbar;   /* SDF network   */
+  const float *pev, *feat, *rs, *gar, *ga_last_rgb;                             /* radiance net  */
+  const float *hl, *gal0, *gal_last;                                            /* light head (NULL if absent) */
+} i2sdf_train_buffers;
+
+int64_t i2sdf_wgrad_chunk_points(void);   /* points per split-M chunk: partials needs ceil(M_sdf/chunk) * wgrad_floats floats */
+int i2sdf_weight_grads(const i2sdf_plan* plan, const i2sdf_train_buffers* bufs, const float* params, float* partials,
+                       int64_t n_chunks_cap, float* grad_flat, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ def test_rgb_forward(which):
     Mp = eng.pad_rows(M)
     featp = torch.zeros(Mp, F)
     featp[:M] = feat
-    rgb, rs = eng.rgb_forward(dirs.cuda(), n, featp.cuda(), M)
+    rgb, rs, _ = eng.rgb_forward(dirs.cuda(), n, featp.cuda(), M)
     assert_close(rgb.cpu(), ref, TOL, "rgb")
 
 
@@ -101,5 +101,5 @@ def test_rgb_forward_golden(golden):
     M = z["feat"].shape[0]
     featp = torch.zeros(eng.pad_rows(M), 64)
     featp[:M] = t(z["feat"])
-    rgb, _ = eng.rgb_forward(t(z["dirs"]).cuda(), 1, featp.cuda(), M)
+    rgb, _, _ = eng.rgb_forward(t(z["dirs"]).cuda(), 1, featp.cuda(), M)
     assert_close(rgb.cpu(), z["rgb"], 2e-5, "RenderingNetwork.forward")
