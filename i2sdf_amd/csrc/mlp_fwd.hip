@@ -9,16 +9,18 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 namespace {
 
 template <int H, int F, int LF, bool FULL>
-__global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ stream, int n_stages, int L, int skip,
-                                                       const float* __restrict__ points, int64_t M, float* __restrict__ sdf_out,
+__global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
+                                                       const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out,
                                                        float* __restrict__ feat_out, int64_t ld_feat) {
   constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (skip_flag != nullptr && skip_flag[0] != 0) return;      // batch already converged (sampler)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < M;
   const int64_t mc = valid ? m : M - 1;
-  const float px = points[mc * 3 + 0], py = points[mc * 3 + 1], pz = points[mc * 3 + 2];
+  float px, py, pz;
+  fetch_point(ps, mc, px, py, pz);
   float pe[PEC * 4];
   {
     float full[PEC * 8];
@@ -57,17 +59,17 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
 }
 
 template <int H, int F, int LF>
-int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, const float* points, int64_t M, float* sdf_out, float* feat_out,
-                   int64_t ld_feat, hipStream_t st) {
+int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, const int* skip_flag, int64_t M, float* sdf_out,
+                   float* feat_out, int64_t ld_feat, hipStream_t st) {
   const i2sdf_mlp_desc& d = p->sdf.d;
   const float* stream = packed + p->scale_floats + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
   const bool full = feat_out != nullptr;
   const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (full)
-    sdf_fwd_kernel<H, F, LF, true><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, M, sdf_out, feat_out, ld_feat);
+    sdf_fwd_kernel<H, F, LF, true><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, feat_out, ld_feat);
   else
-    sdf_fwd_kernel<H, F, LF, false><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, M, sdf_out, nullptr, 0);
+    sdf_fwd_kernel<H, F, LF, false><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, nullptr, 0);
   return i2sdf_hip_check(hipGetLastError(), "sdf_forward launch");
 }
 
@@ -80,7 +82,20 @@ extern "C" int i2sdf_sdf_forward(const i2sdf_plan* p, const float* packed, const
   if (feat_out && (ld_feat < p->F || ld_feat % 4)) return I2SDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (p->sdf.d.multires != 6) return I2SDF_EINVAL;
-  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, points, M, sdf_out, feat_out, ld_feat, st);
-  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, points, M, sdf_out, feat_out, ld_feat, st);
+  const PointSpec ps{points, nullptr, nullptr, nullptr, 0, 0, 1};
+  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, ps, nullptr, M, sdf_out, feat_out, ld_feat, st);
+  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, ps, nullptr, M, sdf_out, feat_out, ld_feat, st);
+  return I2SDF_EINVAL;
+}
+
+// internal (sampler): sdf at x = cam[r] + z[r*ldz + j]*dirs[r] for j < n_per_ray; whole launch is a no-op when *skip_flag != 0
+int i2sdf_sdf_forward_rays_flagged(const i2sdf_plan* p, const float* packed, const float* cam, const float* dirs, const float* z, int64_t ldz,
+                                   int32_t n_per_ray, int64_t B, float* sdf_out, const int* skip_flag, void* stream) {
+  if (p->sdf.d.multires != 6) return I2SDF_EINVAL;
+  const int64_t M = B * n_per_ray;
+  const PointSpec ps{nullptr, cam, dirs, z, ldz, M, n_per_ray};
+  hipStream_t st = (hipStream_t)stream;
+  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st);
+  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st);
   return I2SDF_EINVAL;
 }

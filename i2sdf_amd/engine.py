@@ -27,6 +27,20 @@ class RenderEngine:
         self.wgrad_floats = int(self._lib.i2sdf_plan_wgrad_floats(plan))
         self.packed = torch.zeros(self.pack_floats, dtype=torch.float32, device=self.device)
         self.F = cfg.feature_size
+        sc = cfg.sampler
+        self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
+                                  N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
+        # deterministic tables the reference builds with torch.linspace on every call (ray_sampler.py:30,188,225)
+        dev = self.device
+        self.t_lin = torch.linspace(0.0, 1.0, steps=sc.N_samples_eval, device=dev)
+        self.u_more = torch.linspace(0.0, 1.0, steps=sc.N_samples_eval, device=dev)
+        self.u_final = torch.linspace(0.0, 1.0, steps=sc.N_samples, device=dev)
+        if sc.N_samples_extra > 0:
+            self.extra_tab = torch.stack([torch.linspace(0, sc.N_samples_eval * (it + 1) - 1, sc.N_samples_extra).long()
+                                          for it in range(sc.max_total_iters)]).to(torch.int32).to(dev).contiguous()
+        else:
+            self.extra_tab = None
+        self.n_z = sc.N_samples + sc.N_samples_extra + 2
 
     def __del__(self):
         try:
@@ -189,3 +203,26 @@ class RenderEngine:
                                                     L_.ptr(part), L_.ptr(beta_grad_accum), L_.stream_ptr()), "i2sdf_composite_backward")
         o["beta_partial"] = part
         return o
+
+    # -- sampler -----------------------------------------------------------------------------------
+    def sample_rays(self, flat_params, cam, dirs, training=False, strat_u=None, cdf_u=None, extra_idx=None, eik_idx=None, force_iters=0):
+        """ErrorBoundSampler.get_z_vals on the device.  Returns z_all (B, N_samples+N_extra+2), z_eik (B,1), iters (device int32)."""
+        B, dev = cam.shape[0], cam.device
+        ws = torch.empty(int(self._lib.i2sdf_sampler_workspace_floats(B)), dtype=torch.float32, device=dev)
+        z_out = torch.empty(B, self.n_z, dtype=torch.float32, device=dev)
+        z_eik = torch.empty(B, 1, dtype=torch.float32, device=dev)
+        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        i32 = lambda t: None if t is None else t.to(torch.int32).contiguous()
+        if training:
+            u_final, ldu = cdf_u.contiguous(), cdf_u.shape[1]
+        else:
+            u_final, ldu = self.u_final, 0
+        ex, ek = i32(extra_idx), i32(eik_idx)
+        su = None if strat_u is None else strat_u.contiguous()
+        L_.check(self._lib.i2sdf_sample_rays(self._plan, L_.ptr(self.packed), L_.ptr(flat_params), C.byref(self._scfg), L_.ptr(cam.contiguous()),
+                                             L_.ptr(dirs.contiguous()), B, 1 if training else 0, L_.ptr(self.t_lin), L_.ptr(self.u_more),
+                                             L_.ptr(u_final), ldu, L_.ptr(self.extra_tab), L_.ptr(su), L_.ptr(ex), L_.ptr(ek), force_iters,
+                                             L_.ptr(ws), L_.ptr(z_out), self.n_z, L_.ptr(z_eik), L_.ptr(iters), L_.stream_ptr()),
+                 "i2sdf_sample_rays")
+        self._last_sampler_ws = ws
+        return z_out, z_eik, iters

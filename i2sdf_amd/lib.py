@@ -28,6 +28,11 @@ class TrainBuffers(C.Structure):
         "hl", "gal0", "gal_last")]
 
 
+class SamplerCfg(C.Structure):
+    _fields_ = [("near", C.c_float), ("eps", C.c_float), ("add_tiny", C.c_float), ("N_samples", C.c_int32), ("N_samples_eval", C.c_int32),
+                ("N_samples_extra", C.c_int32), ("beta_iters", C.c_int32), ("max_total_iters", C.c_int32)]
+
+
 class I2SDFError(RuntimeError):
     pass
 
@@ -57,6 +62,11 @@ SIGNATURES = {
     "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
     "i2sdf_wgrad_chunk_points": (_I64, []),
     "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
+    "i2sdf_sampler_workspace_floats": (_I64, [_I64]),
+    # plan, packed, params, cfg, cam, dirs, B, training, t_lin, u_more, u_final, ldu_final, extra_tab, strat_u, extra_idx, eik_idx,
+    # force_iters, workspace, z_out, ldz, z_eik, iters_out, stream
+    "i2sdf_sample_rays": (C.c_int, [_P, _P, _P, C.POINTER(SamplerCfg), _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
+                                    _I64, _P, _P, _P]),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
     "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),

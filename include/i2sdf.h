@@ -204,6 +204,32 @@ int64_t i2sdf_wgrad_chunk_points(void);   /* points per split-M chunk: partials 
 int i2sdf_weight_grads(const i2sdf_plan* plan, const i2sdf_train_buffers* bufs, const float* params, float* partials,
                        int64_t n_chunks_cap, float* grad_flat, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Error-bounded ray sampler -- ErrorBoundSampler.get_z_vals incl. UniformSampler and get_error_bound
+ * (model/network/ray_sampler.py:22-43,67-251), bg disabled.  Runs the whole Algorithm-1 loop on the device:
+ * all max_total_iters iterations are enqueued, a device flag turns the remaining ones into no-ops once the
+ * batch-global test `beta.max() > beta0` (ray_sampler.py:151) fails, so there is no host synchronisation.
+ * Random draws are inputs (training): strat_u (B,N_eval) [:39], u_final (B,N_samples) [:190],
+ * extra_idx (N_extra) = randperm(row)[:N_extra] [:223], eik_idx (B) [:233].  Deterministic tables (eval and the
+ * error-proportional up-sampling): t_lin = linspace(0,1,N_eval) [:30], u_more = linspace(0,1,N_eval) [:188],
+ * u_final = linspace(0,1,N_samples) with ldu_final = 0 [:188], extra_tab (max_total_iters, N_extra) =
+ * linspace(0, N_eval*(it+1)-1, N_extra).long() per possible row length [:225].
+ *   force_iters > 0 replaces the data-dependent test by "exactly force_iters iterations" (fixed-work benchmarks).
+ *   -> z_out (B, ldz): N_samples + N_extra + 2 sorted depths (last = far) ; z_eik (B)|NULL ; iters_out device int|NULL
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_sampler_cfg {
+  float near, eps, add_tiny;
+  int32_t N_samples, N_samples_eval, N_samples_extra, beta_iters, max_total_iters;
+} i2sdf_sampler_cfg;
+
+int64_t i2sdf_sampler_workspace_floats(int64_t B);
+int i2sdf_sample_rays(const i2sdf_plan* plan, const float* packed, const float* params, const i2sdf_sampler_cfg* cfg,
+                      const float* cam, const float* dirs, int64_t B, int32_t training, const float* t_lin, const float* u_more,
+                      const float* u_final, int64_t ldu_final, const int32_t* extra_tab, const float* strat_u,
+                      const int32_t* extra_idx, const int32_t* eik_idx, int32_t force_iters, float* workspace, float* z_out,
+                      int64_t ldz, float* z_eik, int32_t* iters_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

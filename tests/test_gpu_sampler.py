@@ -1,0 +1,112 @@
+"""GPU: the error-bounded sampler (device loop) vs the oracle / the reference's golden z_vals.
+
+Individual depths are ill-conditioned where the inverse CDF is flat (pdf = weights + 1e-5 with weights ~ 0): a 1-ulp
+change of an SDF value moves such a sample by ~1e-3 while the rendering is unaffected (those samples carry ~zero
+weight); see DESIGN.md.  So depths are compared with a robust criterion (median / 99th percentile + bounded outlier
+fraction), the iteration count exactly, and the rendered outputs through the end-to-end tests."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import i2sdf_oracle as orc
+from helpers import sd_from_npz, t, make_draws
+from test_gpu_train_forward import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def frac_off(z, ref, far=6.0):
+    err = (z.detach().cpu().double() - torch.as_tensor(ref).double()).abs() / far
+    return (err > 1e-4).double().mean().item(), err.median().item()
+
+
+def robust_z_check(z, ref, far=6.0, what="", noise=0.0):
+    """`noise` = fraction of depths by which the oracle itself moves between fp32 and fp64 arithmetic (same inputs):
+    the HIP path must not be further from the reference than twice that, plus 2 %."""
+    z = z.detach().cpu().double()
+    ref = torch.as_tensor(ref).double()
+    assert z.shape == ref.shape, (z.shape, ref.shape)
+    assert torch.isfinite(z).all()
+    assert (z[:, 1:] >= z[:, :-1]).all(), "rows must be sorted"
+    frac_bad, med = frac_off(z, ref, far)
+    assert med <= 1e-6, f"{what}: median |dz|/far {med:.2e}"
+    assert frac_bad <= 2 * noise + 0.02, f"{what}: {frac_bad*100:.2f}% of depths differ by more than 1e-4*far (fp32 noise {noise*100:.2f}%)"
+    return frac_bad
+
+
+def _eval_rays(tvec, B=1024, W=32, H=32, f=30.0):
+    K = torch.eye(4); K[0, 0], K[1, 1], K[0, 2], K[1, 2] = f, f, W / 2, H / 2
+    pose = torch.eye(4); pose[:3, 3] = torch.as_tensor(tvec)
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    uv = torch.stack([xs, ys], -1).float().reshape(1, -1, 2)[:, :B]
+    return {"uv": uv, "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0)}
+
+
+@pytest.mark.parametrize("tag", ["in", "out"])
+def test_sampler_eval_vs_reference_golden(golden, tag):
+    from i2sdf_amd.config import plumbing_conf
+    z = golden("g7_g8_eval")
+    sd = sd_from_npz(z, "sd.")
+    sd["density.beta"] = torch.tensor(float(z[f"{tag}.beta_param"]))
+    eng = make_engine(plumbing_conf(), sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    inp = _eval_rays(z[f"{tag}.t"])
+    cam, dirs, _ = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    zo, zeik, iters = eng.sample_rays(flat, cam, dirs, training=False)
+    assert int(iters.item()) == int(z[f"{tag}.iters"])
+    robust_z_check(zo, z[f"{tag}.z_vals"], what=f"z_vals[{tag}]")
+
+
+@pytest.mark.parametrize("which,tvec,beta,B", [("synthetic", (0.1, -0.2, 0.3), 0.1, 256), ("synthetic", (0.0, 0.0, -2.0), 0.02, 256),
+                                               ("light", (0.0, 0.0, -2.0), 0.02, 200)])
+def test_sampler_eval_full_size(which, tvec, beta, B):
+    from i2sdf_amd.config import synthetic_conf
+    from helpers import camera_inputs
+    light = which == "light"
+    ocfg = orc.synthetic_cfg(light)
+    sd = orc.init_params(ocfg, seed=21)
+    sd["density.beta"] = torch.tensor(beta)
+    eng = make_engine(synthetic_conf(light), sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    inp = camera_inputs(B, tvec, train_layout=False)
+    cam_o, dirs_o, _ = orc.prepare_rays(inp["uv"], inp["pose"], inp["intrinsics"])
+    tr = orc.SamplerTrace()
+    z_ref, _ = orc.sample_z_vals(sd, ocfg, dirs_o, cam_o, training=False, trace=tr)
+    z64, _ = orc.sample_z_vals({k: v.double() for k, v in sd.items()}, ocfg, dirs_o.double(), cam_o.double(), training=False)
+    noise, _ = frac_off(z_ref, z64)
+    cam, dirs, _ = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    zo, zeik, iters = eng.sample_rays(flat, cam, dirs, training=False)
+    assert int(iters.item()) == tr.iters
+    robust_z_check(zo, z64, what="z_vals", noise=noise)
+
+
+@pytest.mark.parametrize("force", [0, 1, 3])
+def test_sampler_train_with_draws(force):
+    from i2sdf_amd.config import plumbing_conf
+    from helpers import camera_inputs
+    ocfg = orc.plumbing_cfg(skip=True)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=23), 0.05, seed=24)
+    sd["density.beta"] = torch.tensor(0.03)
+    eng = make_engine(plumbing_conf(skip=True), sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    B = 333
+    inp = camera_inputs(B, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=3)
+    cam_o, dirs_o, _ = orc.prepare_rays(inp["uv"], inp["pose"], inp["intrinsics"])
+    # row length that extra_idx indexes depends on the iteration count: take it from the oracle run
+    tr = orc.SamplerTrace()
+    dr = make_draws(ocfg, B, n_row=32, seed=1)
+    z_probe, _ = orc.sample_z_vals(sd, ocfg, dirs_o, cam_o, training=True, draws=dr, force_iters=force or None, trace=tr)
+    dr = make_draws(ocfg, B, n_row=32 * tr.iters, seed=1)      # same strat_u/cdf_u (same seed order), valid extra_idx
+    tr = orc.SamplerTrace()
+    z_ref, zeik_ref = orc.sample_z_vals(sd, ocfg, dirs_o, cam_o, training=True, draws=dr, force_iters=force or None, trace=tr)
+    cam, dirs, _ = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    zo, zeik, iters = eng.sample_rays(flat, cam, dirs, training=True, strat_u=dr.strat_u.cuda(), cdf_u=dr.cdf_u.cuda(),
+                                      extra_idx=dr.extra_idx.cuda(), eik_idx=dr.eik_idx.cuda(), force_iters=force)
+    assert int(iters.item()) == tr.iters
+    d64 = orc.Draws(strat_u=dr.strat_u.double(), cdf_u=dr.cdf_u.double(), extra_idx=dr.extra_idx, eik_idx=dr.eik_idx)
+    z64, _ = orc.sample_z_vals({k: v.double() for k, v in sd.items()}, ocfg, dirs_o.double(), cam_o.double(), training=True, draws=d64,
+                               force_iters=force or None)
+    noise, _ = frac_off(z_ref, z64)
+    robust_z_check(zo, z64, what="z_vals(train)", noise=noise)
+    got = torch.gather(zo.cpu(), 1, dr.eik_idx.long().unsqueeze(-1))
+    assert torch.equal(got, zeik.cpu()), "z_eik must be z_vals[eik_idx]"
