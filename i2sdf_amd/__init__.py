@@ -1,3 +1,17 @@
 """i2sdf_amd -- MI355X-native volume-rendering core for I2-SDF (hand-written HIP kernels behind the reference's
 `I2SDFNetwork` module contract).  See DESIGN.md / INTEGRATION.md."""
 from .config import NetConfig, SamplerConfig, synthetic_conf, plumbing_conf  # noqa: F401
+
+
+def __getattr__(name):
+    # torch-dependent pieces are imported lazily so that `import i2sdf_amd` stays cheap
+    if name in ("I2SDFNetwork", "ImplicitNetwork", "RenderingNetwork", "LaplaceDensity"):
+        from . import network
+        return getattr(network, name)
+    if name == "I2SDFLoss":
+        from .loss import I2SDFLoss
+        return I2SDFLoss
+    if name == "RenderEngine":
+        from .engine import RenderEngine
+        return RenderEngine
+    raise AttributeError(name)

@@ -260,3 +260,103 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   } else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "rgb_forward launch");
 }
+
+// =============================================================================================================
+// light-mask head -- model/network/__init__.py:29-32,162-170: lm = sigmoid(W1 softplus100(W0 relu(feature).detach() + b0) + b1)
+// (an ImplicitNetwork without encoding, geometric_init False, sigmoid output).  The feature input is detached
+// (detach_light_feature=True, the default), so the backward stops at the head's own parameters.
+struct LightArgs {
+  const float* fwd; int n_fwd; const float* rev; int n_rev;
+  const float* feat; int64_t M, Mp;
+  float* lm;            // (M)
+  float* hl;            // (Mp, HL) softplus activations
+  const float* lm_bar;  // (M)   backward only
+  float* gal0;          // (Mp, HL)  G(a_0)
+  float* gal_last;      // (Mp, 4)   {G(a_1),0,0,0}
+};
+
+namespace {
+
+template <int HL, int F>
+__global__ __launch_bounds__(256) void light_fwd_kernel(LightArgs a) {
+  constexpr int NT = HL / 32, KC = HL / 8, FC = F / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  float in0[FC * 4];
+  load_regs<FC>(a.feat + mc * F, hi, in0);
+#pragma unroll
+  for (int i = 0; i < FC * 4; ++i) in0[i] = fmaxf(in0[i], 0.f);
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x16 acc[NT];
+  float h[NT * 16];
+  dense_op<NT, FC, 0>(ws, in0, acc, tid);
+  softplus_tiles<NT>(acc, h);
+  if (a.hl) store_regs<KC>(a.hl + m * HL, hi, valid, h);
+  float o[1];
+  rowvec_op<1, KC>(ws, h, o, tid);
+  if (valid && hi == 0) a.lm[m] = 1.0f / (1.0f + expf(-o[0]));
+}
+
+template <int HL>
+__global__ __launch_bounds__(256) void light_bwd_kernel(LightArgs a) {
+  constexpr int KC = HL / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const float l = a.lm[mc];
+  const float g1 = a.lm_bar[mc] * l * (1.0f - l);
+  if (valid && hi == 0) *reinterpret_cast<f32x4*>(a.gal_last + m * 4) = f32x4{g1, 0.f, 0.f, 0.f};
+  WStream ws;
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float wv[KC * 4], hv[KC * 4];
+  f32x4 sc;
+  rowvec_load<KC>(ws, wv, sc, tid);
+  load_regs<KC>(a.hl + mc * HL, hi, hv);
+#pragma unroll
+  for (int i = 0; i < KC * 4; ++i) wv[i] = g1 * wv[i] * sp_sigma_from_h(hv[i]);
+  store_regs<KC>(a.gal0 + m * HL, hi, valid, wv);
+}
+
+}  // namespace
+
+extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, const float* feat, int64_t M, int64_t Mp, float* lm, float* hl,
+                                   void* stream) {
+  if (!p || !packed || !feat || !lm || M < 0 || p->light.d.n_lin == 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  LightArgs a{};
+  const int HL = p->light.d.hidden, F = p->F;
+  a.fwd = packed + p->scale_floats + p->light.fwd_chunk0 * CHUNK_FLOATS;
+  a.n_fwd = (op_chunks(HL / 32, F / 8) + rowvec_chunks(HL / 8, 1)) / SC;
+  a.feat = feat; a.M = M; a.Mp = Mp; a.lm = lm; a.hl = hl;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (HL == 128 && F == 256) light_fwd_kernel<128, 256><<<grid, 256, LDS_BYTES, st>>>(a);
+  else if (HL == 32 && F == 64) light_fwd_kernel<32, 64><<<grid, 256, LDS_BYTES, st>>>(a);
+  else return I2SDF_EINVAL;
+  return i2sdf_hip_check(hipGetLastError(), "light_forward launch");
+}
+
+extern "C" int i2sdf_light_backward(const i2sdf_plan* p, const float* packed, const float* lm, const float* lm_bar, const float* hl, int64_t M,
+                                    int64_t Mp, float* gal0, float* gal_last, void* stream) {
+  if (!p || !packed || !lm || !lm_bar || !hl || !gal0 || !gal_last || M < 0 || p->light.d.n_lin == 0) return I2SDF_EINVAL;
+  if (M == 0) return I2SDF_OK;
+  if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
+  LightArgs a{};
+  const int HL = p->light.d.hidden;
+  a.rev = packed + p->scale_floats + p->light.rev_chunk0 * CHUNK_FLOATS;
+  a.n_rev = rowvec_chunks(HL / 8, 1) / SC;
+  a.M = M; a.Mp = Mp; a.lm = const_cast<float*>(lm); a.lm_bar = lm_bar; a.hl = const_cast<float*>(hl); a.gal0 = gal0; a.gal_last = gal_last;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (HL == 128) light_bwd_kernel<128><<<grid, 256, LDS_BYTES, st>>>(a);
+  else if (HL == 32) light_bwd_kernel<32><<<grid, 256, LDS_BYTES, st>>>(a);
+  else return I2SDF_EINVAL;
+  return i2sdf_hip_check(hipGetLastError(), "light_backward launch");
+}

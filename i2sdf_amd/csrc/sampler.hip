@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(int64_t B, const int
     else if (k < total) {
       const int e = k - N_final - 2;
       int id;
-      if (extra_idx) id = extra_idx[e];                              // train: randperm(n)[:N_extra], shared by all rays
+      if (extra_idx) id = extra_idx[(iters - 1) * N_extra + e];      // train: randperm(n)[:N_extra] per possible row length, shared by all rays
       else id = extra_tab[(iters - 1) * N_extra + e];               // eval: linspace(0, n-1, N_extra).long(), tabulated per row length
       id = id < 0 ? 0 : (id > n_row - 1 ? n_row - 1 : id);
       v = zr[id];

@@ -80,15 +80,16 @@ class RenderEngine:
         pts = cam = dirs = z = None
         n_ray, ldz, npr = 0, 0, 1
         if rays is not None:
-            cam, dirs, z = (t.detach().to(torch.float32).contiguous() for t in rays)
-            n_ray, ldz, npr = z.shape[0] * z.shape[1], z.shape[1], z.shape[1]
+            cam, dirs, z = (t.detach().to(torch.float32).contiguous() for t in rays[:3])
+            npr = rays[3] if len(rays) > 3 else z.shape[1]      # samples used per ray (z may carry z_max in its last column)
+            n_ray, ldz = z.shape[0] * npr, z.shape[1]
             dev = z.device
         if points is not None:
             pts = points.detach().to(torch.float32).contiguous()
             dev = pts.device
         M = n_ray + (pts.shape[0] if pts is not None else 0)
         Mp = self.pad_rows(M)
-        out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
+        out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z, npr), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
         out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
         out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
         out["hs"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
@@ -125,13 +126,13 @@ class RenderEngine:
         cfgs = self.cfg.sdf
         H, L = cfgs.hidden, cfgs.n_lin
         Mp, M, dev = fw["Mp"], fw["M"], fw["hs"].device
-        cam, dirs, z = fw["rays"]
+        cam, dirs, z, npr = fw["rays"]
         o = {"gus": torch.empty(L, Mp, H, dtype=torch.float32, device=dev), "gpbar": torch.empty(Mp, 40, dtype=torch.float32, device=dev),
              "gas": torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
              "ones4": torch.empty(Mp, 4, dtype=torch.float32, device=dev)}
         c = lambda t: None if t is None else t.contiguous()
         L_.check(self._lib.i2sdf_sdf_backward(self._plan, L_.ptr(self.packed), L_.ptr(fw["pts"]), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
-                                              z.shape[1] if z is not None else 0, z.shape[1] if z is not None else 1, fw["n_ray_pts"], M, Mp,
+                                              z.shape[1] if z is not None else 0, npr, fw["n_ray_pts"], M, Mp,
                                               L_.ptr(fw["hs"]), L_.ptr(fw["abars"]), L_.ptr(c(sbar)), L_.ptr(c(fbar)), m_fbar, L_.ptr(c(nbar)),
                                               L_.ptr(o["gus"]), L_.ptr(o["gpbar"]), L_.ptr(o["gas"]), L_.ptr(o["ga_last4"]), L_.ptr(o["ones4"]),
                                               L_.stream_ptr()), "i2sdf_sdf_backward")
@@ -187,12 +188,12 @@ class RenderEngine:
         return o
 
     def composite_backward(self, beta_param, z_all, sdf, rgb, grad, dnorm, nsum, g_rgb, g_depth, g_wsum, g_normal, g_lmask,
-                           beta_grad_accum=None):
+                           beta_grad_accum=None, sdf_bar_out=None, grad_bar_out=None):
         B, n = z_all.shape[0], z_all.shape[1] - 1
         dev = z_all.device
         M = B * n
-        o = {"sdf_bar": torch.empty(M, device=dev), "rgb_bar": torch.empty(M, 3, device=dev)}
-        o["grad_bar"] = torch.empty(M, 3, device=dev) if g_normal is not None else None
+        o = {"sdf_bar": sdf_bar_out if sdf_bar_out is not None else torch.empty(M, device=dev), "rgb_bar": torch.empty(M, 3, device=dev)}
+        o["grad_bar"] = (grad_bar_out if grad_bar_out is not None else torch.empty(M, 3, device=dev)) if g_normal is not None else None
         o["lmask_bar"] = torch.empty(M, device=dev) if g_lmask is not None else None
         part = torch.empty(B, device=dev)
         c = lambda t: None if t is None else t.contiguous()
@@ -226,3 +227,21 @@ class RenderEngine:
                  "i2sdf_sample_rays")
         self._last_sampler_ws = ws
         return z_out, z_eik, iters
+
+    # -- light-mask head ---------------------------------------------------------------------------
+    def light_forward(self, feat, M, save=True):
+        Mp, dev = feat.shape[0], feat.device
+        HL = self.cfg.light.hidden
+        lm = torch.empty(M, dtype=torch.float32, device=dev)
+        hl = torch.empty(Mp, HL, dtype=torch.float32, device=dev) if save else None
+        L_.check(self._lib.i2sdf_light_forward(self._plan, L_.ptr(self.packed), L_.ptr(feat), M, Mp, L_.ptr(lm), L_.ptr(hl), L_.stream_ptr()),
+                 "i2sdf_light_forward")
+        return lm, hl
+
+    def light_backward(self, lm, lm_bar, hl, M):
+        Mp, dev = hl.shape[0], hl.device
+        gal0 = torch.empty(Mp, hl.shape[1], dtype=torch.float32, device=dev)
+        gal_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
+        L_.check(self._lib.i2sdf_light_backward(self._plan, L_.ptr(self.packed), L_.ptr(lm), L_.ptr(lm_bar.contiguous()), L_.ptr(hl), M, Mp,
+                                                L_.ptr(gal0), L_.ptr(gal_last), L_.stream_ptr()), "i2sdf_light_backward")
+        return gal0, gal_last

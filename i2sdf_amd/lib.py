@@ -67,6 +67,8 @@ SIGNATURES = {
     # force_iters, workspace, z_out, ldz, z_eik, iters_out, stream
     "i2sdf_sample_rays": (C.c_int, [_P, _P, _P, C.POINTER(SamplerCfg), _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
                                     _I64, _P, _P, _P]),
+    "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
     "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),

@@ -1,0 +1,370 @@
+"""Drop-in replacement of the reference's `model.I2SDFNetwork` (model/network/__init__.py:19-286) for the shipped
+configurations: same constructor argument (the yaml `model:` node), same call form `net(input, predict_only=False)`,
+same output dict, same sub-module surface (`implicit_network(x)`, `density.beta`, `get_param_groups`,
+`rendering_network.mode`) and the same `state_dict` keys (`implicit_network.lin3.weight_v`, ...), so the reference's
+Lightning trainer and its checkpoints work unchanged.  The arithmetic runs in the HIP library (i2sdf_amd/csrc) through
+the C ABI of include/i2sdf.h; there is no CPU / eager-torch fallback for it.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .config import MlpShape, NetConfig
+from .engine import RenderEngine
+from .params import ParamLayout
+
+
+class _WNLinear(nn.Module):
+    """Parameter container with the names torch.nn.utils.weight_norm(nn.Linear) produces (mlp.py:53,71-74)."""
+
+    def __init__(self, out_dim: int, in_dim: int):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(out_dim))
+        self.weight_g = nn.Parameter(torch.ones(out_dim, 1))
+        self.weight_v = nn.Parameter(torch.zeros(out_dim, in_dim))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, shape: MlpShape):
+        super().__init__()
+        self.shape = shape
+        self.num_layers = shape.n_lin + 1
+        for l, (out, inn) in enumerate(shape.dims):
+            setattr(self, f"lin{l}", _WNLinear(out, inn))
+
+    def get_param_groups(self, lr):
+        return [{"params": self.parameters(), "lr": lr}]
+
+
+class ImplicitNetwork(_Mlp):
+    """model/network/mlp.py:10-151.  Calls are forwarded to the owning I2SDFNetwork's engine."""
+
+    def __init__(self, shape: MlpShape, owner: "I2SDFNetwork"):
+        super().__init__(shape)
+        object.__setattr__(self, "_owner", owner)
+        self.skip_in = (shape.skip_layer,) if shape.skip_layer >= 0 else ()
+
+    def forward(self, x):
+        """(M,3) -> (M, 1 + feature): [sdf | feature], no autograd graph (marching cubes / grid queries)."""
+        eng = self._owner._engine_for(x.device)
+        sdf, feat = eng.sdf_forward(x, want_features=True)
+        return torch.cat([sdf, feat], dim=1)
+
+    def get_sdf_vals(self, x):
+        return self._owner._engine_for(x.device).sdf_forward(x)
+
+    def gradient(self, x):
+        """d sdf / d x without a graph.  (With a graph it is part of I2SDFNetwork.forward.)"""
+        eng = self._owner._engine_for(x.device)
+        return eng.sdf_forward_grad(points=x, save=False, want_feat=False)["grad"]
+
+    def get_outputs(self, x, returns_grad=True):
+        eng = self._owner._engine_for(x.device)
+        o = eng.sdf_forward_grad(points=x, want_grad=returns_grad, save=False)
+        return o["sdf"], o["feat"][: x.shape[0]], o["grad"]
+
+
+class RenderingNetwork(_Mlp):
+    def __init__(self, shape: MlpShape, mode: str):
+        super().__init__(shape)
+        self.mode = mode
+
+
+class LaplaceDensity(nn.Module):
+    """model/network/density.py:16-30 (parameter container + the closed form for callers that use it directly)."""
+
+    def __init__(self, beta_init: float, beta_min: float):
+        super().__init__()
+        self.beta = nn.Parameter(torch.tensor(float(beta_init)))
+        self.beta_min = torch.tensor(float(beta_min))
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min.to(self.beta.device)
+
+    def forward(self, sdf, beta=None):
+        if beta is None:
+            beta = self.get_beta()
+        return (1 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+class _RenderFn(torch.autograd.Function):
+    """The whole differentiable core as one autograd node: HIP forward, HIP backward."""
+
+    @staticmethod
+    def forward(ctx, net, st, *params):
+        eng: RenderEngine = st["eng"]
+        flat = net._flat
+        B, n = st["z_all"].shape[0], st["z_all"].shape[1] - 1
+        M_main = B * n
+        fw = eng.sdf_forward_grad(points=st["extra_pts"], rays=(st["cam"], st["dirs"], st["z_all"], n), want_grad=True, save=True)
+        rgb, rs, pev = eng.rgb_forward(st["dirs"], n, fw["feat"], M_main, save=True)
+        lm = hl = None
+        if net.use_light:
+            lm, hl = eng.light_forward(fw["feat"], M_main, save=True)
+        beta_param = flat[eng.layout.offset("density.beta"):]
+        comp = eng.composite_forward(beta_param, st["z_all"], fw["sdf"], rgb, fw["grad"], lm, st["dnorm"], want_normal=st["want_normal"])
+        ctx.net, ctx.st, ctx.fw, ctx.rgb, ctx.rs, ctx.pev, ctx.lm, ctx.hl, ctx.comp = net, st, fw, rgb, rs, pev, lm, hl, comp
+        ctx.M_main = M_main
+        outs = [comp["rgb"], comp["depth"], comp["wsum"]]
+        outs.append(comp["normal"] if st["want_normal"] else torch.zeros(0, device=rgb.device))
+        outs.append(comp["lmask"] if net.use_light else torch.zeros(0, device=rgb.device))
+        n_eik = st["n_eik"]
+        outs.append(fw["grad"][M_main:M_main + n_eik] if n_eik else torch.zeros(0, 3, device=rgb.device))
+        n_pc = st["n_pc"]
+        outs.append(fw["sdf"][M_main + n_eik:M_main + n_eik + n_pc] if n_pc else torch.zeros(0, 1, device=rgb.device))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_wsum, g_normal, g_lmask, g_eik, g_surf):
+        net, st, fw, comp, M_main = ctx.net, ctx.st, ctx.fw, ctx.comp, ctx.M_main
+        eng: RenderEngine = st["eng"]
+        flat = net._flat
+        dev = flat.device
+        gflat = torch.zeros_like(flat)
+        M_sdf = fw["M"]
+        sbar = torch.zeros(M_sdf, device=dev)
+        nbar = torch.zeros(M_sdf, 3, device=dev)
+        off_beta = eng.layout.offset("density.beta")
+        want_normal = st["want_normal"]
+        cb = eng.composite_backward(flat[off_beta:], st["z_all"], fw["sdf"], ctx.rgb, fw["grad"], st["dnorm"], comp["nsum"],
+                                    g_rgb, g_depth, g_wsum.reshape(-1), g_normal if want_normal else None,
+                                    g_lmask.reshape(-1) if net.use_light else None, beta_grad_accum=gflat[off_beta:],
+                                    sdf_bar_out=sbar, grad_bar_out=nbar if want_normal else None)
+        gar, ga_last, fbar = eng.rgb_backward(ctx.rgb, cb["rgb_bar"], ctx.rs, M_main)
+        light = None
+        if net.use_light:
+            gal0, gal_last = eng.light_backward(ctx.lm, cb["lmask_bar"], ctx.hl, M_main)
+            light = {"hl": ctx.hl, "gal0": gal0, "gal_last": gal_last}
+        n_eik, n_pc = st["n_eik"], st["n_pc"]
+        if n_eik:
+            nbar[M_main:M_main + n_eik] = g_eik
+        if n_pc:
+            sbar[M_main + n_eik:M_main + n_eik + n_pc] = g_surf.reshape(-1)
+        bw = eng.sdf_backward(fw, sbar=sbar, fbar=fbar, m_fbar=M_main, nbar=nbar)
+        eng.weight_grads(flat, gflat, fw, bw, M_main=M_main, fbar=fbar, rgb_fw={"pev": ctx.pev, "rs": ctx.rs},
+                         rgb_bw={"gar": gar, "ga_last": ga_last}, light=light)
+        if net.grad_sync is not None:
+            net.grad_sync(gflat)
+        grads = []
+        for name, off, shape in eng.layout.entries:
+            cnt = 1
+            for s in shape:
+                cnt *= s
+            grads.append(gflat[off:off + cnt].view(shape))
+        ctx.net = ctx.st = ctx.fw = ctx.comp = None
+        return (None, None) + tuple(grads)
+
+
+class I2SDFNetwork(nn.Module):
+    def __init__(self, conf):
+        super().__init__()
+        cfg = conf if isinstance(conf, NetConfig) else NetConfig.from_conf(conf)
+        self.cfg = cfg
+        self.feature_vector_size = cfg.feature_size
+        self.scene_bounding_sphere = cfg.scene_bounding_sphere
+        self.implicit_network = ImplicitNetwork(cfg.sdf, self)
+        self.rendering_network = RenderingNetwork(cfg.rgb, cfg.rgb_mode)
+        self.use_light = cfg.light is not None
+        if self.use_light:
+            self.light_network = _Mlp(cfg.light)
+        self.density = LaplaceDensity(cfg.beta_init, cfg.beta_min)
+        self.use_bg = False
+        self.use_normal = cfg.use_normal
+        self.detach_light_feature = cfg.detach_light_feature
+        if not self.detach_light_feature:
+            raise NotImplementedError("detach_light_feature=False is not supported by the fused light head")
+        self.layout = ParamLayout(cfg)
+        self.force_iters = 0            # >0: fixed sampler iteration count (benchmarks); 0: the reference's data-dependent loop
+        self.grad_sync = None           # callable(flat_grad) for data-parallel training (i2sdf_amd.dist)
+        self.last_sampler_iters = None  # device int32 tensor of the last forward
+        object.__setattr__(self, "_engines", {})
+        object.__setattr__(self, "_flat", None)
+        object.__setattr__(self, "_packed_version", {})
+        self._init_parameters()
+
+    # ------------------------------------------------------------------------------------------
+    def _param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[name] for name, _, _ in self.layout.entries]
+
+    def _init_parameters(self, generator=None):
+        flat = self.layout.init_flat(generator)
+        with torch.no_grad():
+            for (name, off, shape), p in zip(self.layout.entries, self._param_list()):
+                p.copy_(flat[off:off + p.numel()].view(shape))
+
+    def get_param_groups(self, lr):
+        return [{"params": self.parameters(), "lr": lr}]
+
+    def _ensure_flat(self):
+        """Keep every parameter a view into one flat fp32 buffer (the layout the C ABI and the gradient all-reduce use)."""
+        params = self._param_list()
+        dev = params[0].device
+        flat = self._flat
+        ok = flat is not None and flat.device == dev
+        if ok:
+            base = flat.data_ptr()
+            for (name, off, shape), p in zip(self.layout.entries, params):
+                if p.data_ptr() != base + 4 * off or p.dtype != torch.float32:
+                    ok = False
+                    break
+        if not ok:
+            flat = torch.empty(self.layout.n_params, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                for (name, off, shape), p in zip(self.layout.entries, params):
+                    flat[off:off + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
+                    p.data = flat[off:off + p.numel()].view(shape)
+            object.__setattr__(self, "_flat", flat)
+            self._packed_version.clear()
+        return self._flat
+
+    def _engine_for(self, device) -> RenderEngine:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("i2sdf_amd.I2SDFNetwork runs on MI355X only (tensors must be on a cuda/HIP device); "
+                               "there is no CPU fallback -- use oracle/ for CPU reference numbers")
+        flat = self._ensure_flat()
+        if flat.device != device:
+            raise RuntimeError(f"module parameters are on {flat.device}, input on {device}")
+        key = str(device)
+        eng = self._engines.get(key)
+        if eng is None:
+            with torch.cuda.device(device):
+                eng = RenderEngine(self.cfg, device)
+            self._engines[key] = eng
+        ver = (flat.data_ptr(), flat._version)
+        if self._packed_version.get(key) != ver:
+            with torch.cuda.device(device):
+                eng.pack(flat)
+            self._packed_version[key] = ver
+        return eng
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, input: Dict[str, torch.Tensor], predict_only: bool = False, draws: Optional[dict] = None):
+        uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
+        eng = self._engine_for(uv.device)
+        flat = self._flat
+        sc = self.cfg.sampler
+        with torch.cuda.device(uv.device), torch.no_grad():
+            cam, dirs, dnorm = eng.ray_setup(uv, pose, K)
+        N = cam.shape[0]
+        dev = cam.device
+        training = self.training
+        draws = draws or {}
+        with torch.cuda.device(dev), torch.no_grad():
+            if training:
+                strat_u = draws.get("strat_u")
+                if strat_u is None:
+                    strat_u = torch.rand(N, sc.N_samples_eval, device=dev)
+                cdf_u = draws.get("cdf_u")
+                if cdf_u is None:
+                    cdf_u = torch.rand(N, sc.N_samples, device=dev)
+                extra = draws.get("extra_idx")
+                if extra is None and sc.N_samples_extra > 0:
+                    extra = torch.stack([torch.randperm(sc.N_samples_eval * (it + 1), device=dev)[: sc.N_samples_extra]
+                                         for it in range(sc.max_total_iters)])
+                elif extra is not None and extra.dim() == 1:
+                    extra = extra.repeat(sc.max_total_iters, 1)
+                eik_idx = draws.get("eik_idx")
+                if eik_idx is None:
+                    eik_idx = torch.randint(eng.n_z, (N,), device=dev)
+                z_all, z_eik, iters = eng.sample_rays(flat, cam, dirs, training=True, strat_u=strat_u, cdf_u=cdf_u, extra_idx=extra,
+                                                      eik_idx=eik_idx, force_iters=self.force_iters)
+            else:
+                z_all, z_eik, iters = eng.sample_rays(flat, cam, dirs, training=False, force_iters=self.force_iters)
+        self.last_sampler_iters = iters
+        return self.render(input, cam, dirs, dnorm, z_all, z_eik, predict_only, draws)
+
+    def render(self, input, cam, dirs, dnorm, z_all, z_eik, predict_only=False, draws=None):
+        """Everything after the sampler (model/network/__init__.py:99-221) for given depths z_all (N, n+1)."""
+        eng = self._engine_for(cam.device)
+        flat = self._flat
+        dev = cam.device
+        N, n = z_all.shape[0], z_all.shape[1] - 1
+        training = self.training
+        draws = draws or {}
+        need_graph = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        with_eik = training and not predict_only
+        with torch.cuda.device(dev):
+            if not need_graph:
+                return self._render_nograd(eng, flat, input, cam, dirs, dnorm, z_all, z_eik, predict_only, draws, with_eik)
+            extra_pts, n_eik, n_pc = None, 0, 0
+            if with_eik:
+                extra_pts, n_eik, n_pc = self._extra_points(input, cam, dirs, z_eik, draws)
+            want_normal = training and self.use_normal and not predict_only
+            st = {"eng": eng, "cam": cam, "dirs": dirs, "dnorm": dnorm, "z_all": z_all.contiguous(), "extra_pts": extra_pts, "n_eik": n_eik,
+                  "n_pc": n_pc, "want_normal": want_normal or (not training)}
+            rgb, depth, wsum, normal, lmask, g_eik, surf = _RenderFn.apply(self, st, *self._param_list())
+            out = {"rgb_values": rgb, "depth_values": depth, "weight_sum": wsum}
+            if self.use_light:
+                out["light_mask"] = lmask
+            if predict_only:
+                return out
+            if training:
+                self._eikonal_outputs(out, g_eik, surf, N, n_pc)
+                if self.use_normal:
+                    out["normal_values"] = normal
+            else:
+                out["normal_map"] = normal.detach()
+            return out
+
+    # ------------------------------------------------------------------------------------------
+    def _extra_points(self, input, cam, dirs, z_eik, draws):
+        """Eikonal / neighbour / bubble points (model/network/__init__.py:175-201)."""
+        N, dev, R = cam.shape[0], cam.device, self.scene_bounding_sphere
+        with torch.no_grad():
+            eik = draws.get("eik_pts")
+            if eik is None:
+                eik = torch.empty(N, 3, device=dev).uniform_(-R, R)
+            near = cam + z_eik * dirs
+            off = draws.get("nbr_off")
+            if off is None:
+                off = torch.empty_like(near).uniform_(-0.005, 0.005)
+            pts = [eik, near, near + off]
+            n_pc = 0
+            if "pointcloud" in input:
+                pts.append(input["pointcloud"].to(torch.float32))
+                n_pc = input["pointcloud"].shape[0]
+            return torch.cat(pts, 0).contiguous(), 3 * N, n_pc
+
+    @staticmethod
+    def _eikonal_outputs(out, g_all, surf, N, n_pc):
+        out["grad_theta"] = g_all[: 2 * N]
+        normals = F.normalize(g_all[N:], dim=1, eps=1e-6)
+        out["diff_norm"] = torch.norm(normals[:N] - normals[N:], dim=1)
+        if n_pc:
+            out["surface_sdf"] = surf
+
+    def _render_nograd(self, eng, flat, input, cam, dirs, dnorm, z_all, z_eik, predict_only, draws, with_eik):
+        with torch.no_grad():
+            N, n = z_all.shape[0], z_all.shape[1] - 1
+            training = self.training
+            M_main = N * n
+            extra_pts, n_eik, n_pc = (None, 0, 0)
+            if with_eik:
+                extra_pts, n_eik, n_pc = self._extra_points(input, cam, dirs, z_eik, draws)
+            returns_grad = self.use_normal or (not training) or with_eik
+            fw = eng.sdf_forward_grad(points=extra_pts, rays=(cam, dirs, z_all.contiguous(), n), want_grad=returns_grad, save=False)
+            rgb, _, _ = eng.rgb_forward(dirs, n, fw["feat"], M_main, save=False)
+            lm = None
+            if self.use_light:
+                lm, _ = eng.light_forward(fw["feat"], M_main, save=False)
+            want_normal = (not predict_only) and ((not training) or self.use_normal)
+            comp = eng.composite_forward(flat[eng.layout.offset("density.beta"):], z_all.contiguous(), fw["sdf"], rgb, fw["grad"], lm, dnorm,
+                                         want_normal=want_normal, save=False)
+            out = {"rgb_values": comp["rgb"], "depth_values": comp["depth"], "weight_sum": comp["wsum"]}
+            if self.use_light:
+                out["light_mask"] = comp["lmask"]
+            if predict_only:
+                return out
+            if training:
+                self._eikonal_outputs(out, fw["grad"][M_main:M_main + n_eik], fw["sdf"][M_main + n_eik:], N, n_pc)
+                if self.use_normal:
+                    out["normal_values"] = comp["normal"]
+            else:
+                out["normal_map"] = comp["normal"]
+            return out

@@ -211,7 +211,8 @@ int i2sdf_weight_grads(const i2sdf_plan* plan, const i2sdf_train_buffers* bufs, 
  * all max_total_iters iterations are enqueued, a device flag turns the remaining ones into no-ops once the
  * batch-global test `beta.max() > beta0` (ray_sampler.py:151) fails, so there is no host synchronisation.
  * Random draws are inputs (training): strat_u (B,N_eval) [:39], u_final (B,N_samples) [:190],
- * extra_idx (N_extra) = randperm(row)[:N_extra] [:223], eik_idx (B) [:233].  Deterministic tables (eval and the
+ * extra_idx (max_total_iters, N_extra): row it-1 = randperm(N_eval*it)[:N_extra], the draw for a loop that ran `it`
+ * iterations [:223] (the row length is only known on the device), eik_idx (B) [:233].  Deterministic tables (eval and the
  * error-proportional up-sampling): t_lin = linspace(0,1,N_eval) [:30], u_more = linspace(0,1,N_eval) [:188],
  * u_final = linspace(0,1,N_samples) with ldu_final = 0 [:188], extra_tab (max_total_iters, N_extra) =
  * linspace(0, N_eval*(it+1)-1, N_extra).long() per possible row length [:225].
@@ -229,6 +230,19 @@ int i2sdf_sample_rays(const i2sdf_plan* plan, const float* packed, const float* 
                       const float* u_final, int64_t ldu_final, const int32_t* extra_tab, const float* strat_u,
                       const int32_t* extra_idx, const int32_t* eik_idx, int32_t force_iters, float* workspace, float* z_out,
                       int64_t ldz, float* z_eik, int32_t* iters_out, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------
+ * Light-mask head -- model/network/__init__.py:29-32,162-170:
+ * lm = sigmoid(W1 softplus100(W0 relu(feature).detach() + b0) + b1).  Backward stops at the head's parameters
+ * (detach_light_feature = True, the reference default).
+ *   forward : feat (Mp,F) -> lm (M), hl (Mp,HL) softplus activations (NULL if no backward follows)
+ *   backward: lm_bar (M) -> gal0 (Mp,HL) G(a_0), gal_last (Mp,4) {G(a_1),0,0,0}   (weight-gradient operands)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_light_forward(const i2sdf_plan* plan, const float* packed, const float* feat, int64_t M, int64_t Mp, float* lm, float* hl,
+                        void* stream);
+int i2sdf_light_backward(const i2sdf_plan* plan, const float* packed, const float* lm, const float* lm_bar, const float* hl, int64_t M,
+                         int64_t Mp, float* gal0, float* gal_last, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,7 +101,7 @@ def test_sampler_train_with_draws(force):
     z_ref, zeik_ref = orc.sample_z_vals(sd, ocfg, dirs_o, cam_o, training=True, draws=dr, force_iters=force or None, trace=tr)
     cam, dirs, _ = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
     zo, zeik, iters = eng.sample_rays(flat, cam, dirs, training=True, strat_u=dr.strat_u.cuda(), cdf_u=dr.cdf_u.cuda(),
-                                      extra_idx=dr.extra_idx.cuda(), eik_idx=dr.eik_idx.cuda(), force_iters=force)
+                                      extra_idx=dr.extra_idx.repeat(ocfg.sampler.max_total_iters, 1).cuda(), eik_idx=dr.eik_idx.cuda(), force_iters=force)
     assert int(iters.item()) == tr.iters
     d64 = orc.Draws(strat_u=dr.strat_u.double(), cdf_u=dr.cdf_u.double(), extra_idx=dr.extra_idx, eik_idx=dr.eik_idx)
     z64, _ = orc.sample_z_vals({k: v.double() for k, v in sd.items()}, ocfg, dirs_o.double(), cam_o.double(), training=True, draws=d64,
