@@ -13,7 +13,7 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 namespace {
 
 constexpr int WG_CH = 1024;          // points per split-M chunk
-constexpr int PFW = 4;               // point pairs in flight
+constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
 
 struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; };
@@ -45,35 +45,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgLaunch L) {
     const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
     if (m_hi <= m_lo) continue;
     const int npairs = (int)((m_hi - m_lo + 1) / 2);
-    const bool a_ok = 4 * i32 < job.a_w, b_ok = 4 * i32 < job.b_w;
-    const float* Ap = job.A + (m_lo + hi) * job.lda + 4 * i32;
-    const float* Bp = job.B + (m_lo + hi) * job.ldb + 4 * i32;
-    const int64_t a_step = 2 * (int64_t)job.lda, b_step = 2 * (int64_t)job.ldb;
-    const bool relu = t.relu_b != 0;
-    const bool do_bias = t.has_bias && jb == 0;
-    f32x4 ab[PFW], bb[PFW];
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < PFW; ++u) {
-      const bool in = (m_lo + 2 * u + hi) < m_hi;
-      ab[u] = (in && a_ok) ? *reinterpret_cast<const f32x4*>(Ap + u * a_step) : zero;
-      bb[u] = (in && b_ok) ? *reinterpret_cast<const f32x4*>(Bp + u * b_step) : zero;
-    }
-    for (int p = 0; p < npairs; p += PFW) {
+    // Buffer loads with hardware range checking: rows >= m_hi and columns >= the operand width read as 0, so the
+    // loop body has no branches and the loads stay PFW pairs ahead of the MFMAs (a select around a load makes hipcc
+    // branch and drain vmcnt every iteration).
+    const int rows = (int)(m_hi - m_lo);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A + m_lo * job.lda), 0,
+                                                                      rows * job.lda * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.B + m_lo * job.ldb), 0,
+                                                                      rows * job.ldb * 4, 0x00020000);
+    const unsigned OOB = 0x7fffffffu;
+    const unsigned a_off = (4 * i32 < job.a_w) ? (unsigned)((hi * job.lda + 4 * i32) * 4) : OOB;
+    const unsigned b_off = (4 * i32 < job.b_w) ? (unsigned)((hi * job.ldb + 4 * i32) * 4) : OOB;
+    const unsigned a_step = 2u * job.lda * 4u, b_step = 2u * job.ldb * 4u;
+    const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;           // branch-free optional ReLU on the B operand
+    const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;       // branch-free optional column sums of A
+    // Group double buffering: while the 16*PFW MFMAs of one group of point pairs run, the loads of the NEXT group are
+    // already in flight (issued at the top of the group, ~6k cycles ahead of their first use).
+    f32x4 a0[PFW], b0[PFW], a1[PFW], b1[PFW];
+    auto load_group = [&](f32x4 (&A)[PFW], f32x4 (&Bv)[PFW], unsigned pbase) {
 #pragma unroll
       for (int u = 0; u < PFW; ++u) {
-        f32x4 a = ab[u], b = bb[u];
-        const int pn = p + u + PFW;
-        const bool in = (m_lo + 2 * (int64_t)pn + hi) < m_hi;
-        ab[u] = (in && a_ok) ? *reinterpret_cast<const f32x4*>(Ap + pn * a_step) : zero;
-        bb[u] = (in && b_ok) ? *reinterpret_cast<const f32x4*>(Bp + pn * b_step) : zero;
-        if (relu) { b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f); }
-        if (do_bias) bsum += a;
+        const unsigned pn = pbase + u;
+        A[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off == OOB ? OOB : a_off + pn * a_step, 0, 0));
+        Bv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off == OOB ? OOB : b_off + pn * b_step, 0, 0));
+      }
+    };
+    auto compute_group = [&](const f32x4 (&A)[PFW], const f32x4 (&Bv)[PFW]) {
+#pragma unroll
+      for (int u = 0; u < PFW; ++u) {
+        const f32x4 a = A[u];
+        f32x4 b = Bv[u];
+        b.x = fmaxf(b.x, relu_lo); b.y = fmaxf(b.y, relu_lo); b.z = fmaxf(b.z, relu_lo); b.w = fmaxf(b.w, relu_lo);
+        bsum.x = fmaf(a.x, bias_w, bsum.x); bsum.y = fmaf(a.y, bias_w, bsum.y); bsum.z = fmaf(a.z, bias_w, bsum.z); bsum.w = fmaf(a.w, bias_w, bsum.w);
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma(a[ta], b[tb], acc[ta][tb]);
       }
+    };
+    load_group(a0, b0, 0);
+    for (int p = 0; p < npairs; p += 2 * PFW) {
+      load_group(a1, b1, (unsigned)(p + PFW));
+      __builtin_amdgcn_sched_barrier(0);
+      compute_group(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      load_group(a0, b0, (unsigned)(p + 2 * PFW));
+      __builtin_amdgcn_sched_barrier(0);
+      compute_group(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   float* out = L.partials + chunk * L.chunk_stride;

@@ -42,6 +42,44 @@ class RenderEngine:
             self.extra_tab = None
         self.n_z = sc.N_samples + sc.N_samples_extra + 2
 
+    # -- live per-kernel timing (bench.py) -------------------------------------------------------------
+    def start_timing(self):
+        self._timing = []
+        self._orig_check = L_.check
+        eng = self
+
+        class _Timed:
+            def __init__(self, fn, name):
+                self.fn, self.name = fn, name
+
+            def __call__(self, *a):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = self.fn(*a)
+                e1.record()
+                eng._timing.append((self.name, e0, e1))
+                return rc
+
+        self._timed_lib = type("TimedLib", (), {})()
+        for name in L_.SIGNATURES:
+            fn = getattr(self._lib, name)
+            if name in ("i2sdf_sdf_forward", "i2sdf_sdf_forward_grad", "i2sdf_rgb_forward", "i2sdf_rgb_backward", "i2sdf_sdf_backward",
+                        "i2sdf_weight_grads", "i2sdf_sample_rays", "i2sdf_composite_forward", "i2sdf_composite_backward", "i2sdf_pack_weights",
+                        "i2sdf_ray_setup", "i2sdf_light_forward", "i2sdf_light_backward"):
+                fn = _Timed(fn, name)
+            setattr(self._timed_lib, name, fn)
+        self._real_lib, self._lib = self._lib, self._timed_lib
+
+    def stop_timing(self):
+        """-> {entry point: (total ms, launches)}; call after a device synchronisation."""
+        self._lib = self._real_lib
+        out = {}
+        for name, e0, e1 in self._timing:
+            tot, cnt = out.get(name, (0.0, 0))
+            out[name] = (tot + e0.elapsed_time(e1), cnt + 1)
+        self._timing = []
+        return out
+
     def __del__(self):
         try:
             if getattr(self, "_plan", None):

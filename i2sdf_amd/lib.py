@@ -80,6 +80,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be in the process before our library so that both bind to the
+    # SAME HIP runtime instance (streams and device pointers are shared between them).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise I2SDFError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
