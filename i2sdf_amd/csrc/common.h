@@ -143,10 +143,108 @@ __device__ __forceinline__ void dense_op(WStream& ws, const float (&in)[KC * 4],
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       if (j >= j0 && j < j1) {
-        I2SDF_SGB(I2SDF_MASK_MFMA, 4);
+        I2SDF_SGB(I2SDF_MASK_MFMA, 1);
         if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+        I2SDF_SGB(I2SDF_MASK_MFMA, 3);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Dense op with an INTERLEAVED per-tile epilogue.
+//   stream layout: [NB bias chunks (NB = NT*4 or 0)][NT*KC weight chunks] padded to whole stages
+//   MODE 0: acc = bias + W*in   MODE 1: acc = W*in   MODE 2: acc += W*in
+// Output tile nt is final once its last weight chunk has been consumed.  Its epilogue (activation function,
+// products with saved tensors, global stores -- `epi.apply(nt, acc[nt])`, in place on the accumulator) is emitted at
+// the start of the NEXT stage, in the same scheduling region as that stage's MFMAs, and sched_group_barrier
+// spreads its VALU work into the 64-cycle gaps between MFMAs; the global loads it needs (`epi.prefetch(nt)`) are
+// issued one stage earlier.  Only the epilogue of the tiles finishing in the last stage is exposed.
+//   Epi: struct with  void prefetch(int nt);  void apply(int nt, f32x16& acc);   (nt is a constant after unrolling)
+// ---------------------------------------------------------------------------------------------
+struct NoEpi {
+  __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void apply(int, f32x16&) {}
+};
+
+template <int NT, int KC, int NB, int MODE, int VALU_PER_CHUNK, class Epi>
+__device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC * 4], f32x16 (&acc)[NT], Epi& epi, int tid) {
+  static_assert(NB == 0 || NB == NT * 4, "bias chunks");
+  constexpr int NW = NT * KC, TOT = round_up(NB + NW, SC), NS = TOT / SC;
+  const int lane = tid & 63;
+  if (NB == 0 && MODE == 1) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+    // tile nt is complete before stage s  <=>  NB + (nt+1)*KC <= s*SC
+    // tiles completing during this stage: issue their operand loads now
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int last = NB + (nt + 1) * KC;           // one past the tile's last chunk
+      if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(nt);
+    }
+    // tiles that completed during the previous stage: epilogue now, under this stage's MFMAs
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int last = NB + (nt + 1) * KC;
+      if (s > 0 && last > (s - 1) * SC && last <= s * SC) epi.apply(nt, acc[nt]);
+    }
+    // ---- bias chunks of this stage
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < NB) {
+        const int nt = c / 4, q = c % 4;
+        if (MODE == 0) {
+          f32x4 b = cur[j * 64];
+          acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+        } else if (MODE == 1) {
+          acc[nt][4 * q + 0] = 0.f; acc[nt][4 * q + 1] = 0.f; acc[nt][4 * q + 2] = 0.f; acc[nt][4 * q + 3] = 0.f;
+        }
+      }
+    }
+    const int j0 = (s * SC < NB) ? ((NB - s * SC < SC) ? NB - s * SC : SC) : 0;
+    const int j1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? NB + NW - s * SC : 0) : SC;
+    f32x4 ab[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (j0 + i < j1) ab[i] = cur[(j0 + i) * 64];
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j >= j0 && j < j1) {
+        const int w = s * SC + j - NB;
+        const int nt = w / KC, kc = w % KC;
+        f32x4 a = ab[(j - j0) % PF];
+        if (j + PF < j1) ab[(j - j0) % PF] = cur[(j + PF) * 64];
+        acc[nt] = mfma(a.x, in[kc * 4 + 0], acc[nt]);
+        acc[nt] = mfma(a.y, in[kc * 4 + 1], acc[nt]);
+        acc[nt] = mfma(a.z, in[kc * 4 + 2], acc[nt]);
+        acc[nt] = mfma(a.w, in[kc * 4 + 3], acc[nt]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (j0 + i < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      if (j >= j0 && j < j1) {
+        I2SDF_SGB(I2SDF_MASK_MFMA, 1);
+        if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+        I2SDF_SGB(I2SDF_MASK_MFMA, 3);
+        if (VALU_PER_CHUNK > 0) I2SDF_SGB(0x002, VALU_PER_CHUNK);
+      }
+    }
+  }
+  // tiles that completed in the last stage (their loads were issued at its start)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int last = NB + (nt + 1) * KC;
+    if (last > (NS - 1) * SC) epi.apply(nt, acc[nt]);
   }
 }
 

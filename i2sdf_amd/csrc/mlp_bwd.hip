@@ -5,7 +5,7 @@
 //             sweep 2 (ordinary backward, top-down, transposed weights).  Emits per layer the operands of the
 //             weight-gradient GEMMs (G(ubar_l), G(a_l)); the GEMMs themselves run in wgrad.hip.
 //   rgb_bwd : first-order backward of the radiance net; emits G(a_l) and the feature gradient fbar.
-#include "mlp_common.h"
+#include "epi.h"
 
 using namespace i2sdf;
 
@@ -36,10 +36,10 @@ __host__ __device__ constexpr int sdf_fwd_hidden_stages(int H, int PEC, int L, b
   if (has_skip) c += op_chunks(H / 32, H / 8 + PEC) - op_chunks(H / 32, H / 8);
   return c / SC;
 }
-// reverse stream: [W_feat^T][w_sdf][W_{L-2}^T .. W_1^T]  (W_0^T is not needed: the points carry no gradient)
+// reverse stream: [w_sdf][W_feat^T][w_sdf][W_{L-2}^T .. W_1^T]  (W_0^T is not needed: the points carry no gradient)
 __host__ __device__ constexpr int sdf_rev_bwd_stages(int H, int F, int PEC, int L, bool has_skip) {
   const int PT = cdiv(PEC * 8, 32);
-  int c = bwd_op_chunks(H / 32, F / 8) + rowvec_chunks(H / 8, 1);
+  int c = bwd_op_chunks(H / 32, F / 8) + 2 * rowvec_chunks(H / 8, 1);
   for (int l = L - 2; l >= 1; --l) c += bwd_op_chunks(H / 32, H / 8);
   if (has_skip) c += bwd_op_chunks(H / 32 + PT, H / 8) - bwd_op_chunks(H / 32, H / 8);
   return c / SC;
@@ -64,48 +64,43 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
     pe_j_apply<LF>(coef, nb, hi, gp);
     store_regs<PEC>(a.gpbar + m * (PEC * 8), hi, valid, gp);
   }
+  constexpr bool PRE = KC >= SC;
   WStream ws;
   // ------------------------------ sweep 1: bottom-up ------------------------------
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   float gh[KC * 4];
   f32x16 acc[NT];
   for (int l = 0; l < a.L - 1; ++l) {
+    // epilogue: G(hbar_{l+1}) = G(abar_l) * sigma_l ; G2(a_l) = G(abar_l) * abar_l * 100 (1 - sigma_l)
+    const float* hrow = a.hs + l * lstride + mc * H;
+    const float* arow = a.abars + l * lstride + mc * H;
+    float* g2row = a.gas + l * lstride + m * H;
+    float* gurow = a.gus + (l + 1) * lstride + m * H;
     if (l == 0) {
-      dense_op<NT, PEC, 1>(ws, gp, acc, tid);
+      Sweep1Epi<false> e{hrow, arow, g2row, gurow, hi, valid};
+      dense_op_epi<NT, PEC, NT * 4, 1, 0, Sweep1Epi<false>>(ws, gp, acc, e, tid);
     } else if (l == a.skip) {
       float u[(KC + PEC) * 4];
 #pragma unroll
       for (int i = 0; i < KC * 4; ++i) u[i] = gh[i] * RS2;
 #pragma unroll
       for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = gp[i] * RS2;
-      dense_op<NT, KC + PEC, 1>(ws, u, acc, tid);
+      Sweep1Epi<PRE> e{hrow, arow, g2row, gurow, hi, valid};
+      dense_op_epi<NT, KC + PEC, NT * 4, 1, 0, Sweep1Epi<PRE>>(ws, u, acc, e, tid);
     } else {
-      dense_op<NT, KC, 1>(ws, gh, acc, tid);
+      Sweep1Epi<PRE> e{hrow, arow, g2row, gurow, hi, valid};
+      dense_op_epi<NT, KC, NT * 4, 1, 0, Sweep1Epi<PRE>>(ws, gh, acc, e, tid);
     }
-    // epilogue: G(hbar_{l+1}) = G(abar_l) * sigma_l ; G2(a_l) = G(abar_l) * abar_l * 100 (1 - sigma_l)
-    const float* hrow = a.hs + l * lstride + mc * H;
-    const float* arow = a.abars + l * lstride + mc * H;
-    float* g2row = a.gas + l * lstride + m * H;
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 8 * c + 4 * hi);
-      const f32x4 av = *reinterpret_cast<const f32x4*>(arow + 8 * c + 4 * hi);
-      f32x4 g2;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float ga = acc[c / 4][(c % 4) * 4 + t];
-        const float sg = sp_sigma_from_h(hv[t]);
-        gh[c * 4 + t] = ga * sg;
-        g2[t] = ga * av[t] * (100.f * (1.0f - sg));
-      }
-      if (valid) *reinterpret_cast<f32x4*>(g2row + 8 * c + 4 * hi) = g2;
-    }
-    store_regs<KC>(a.gus + (l + 1) * lstride + m * H, hi, valid, gh);
+    commit_tiles<NT>(acc, gh);
   }
   // ------------------------------ sweep 2: top-down ------------------------------
   __syncthreads();
   ws.begin(a.rev, lds, a.n_rev, tid);
+  float ga[KC * 4];
   {
+    float wv[KC * 4];
+    f32x4 sc;
+    rowvec_load<KC>(ws, wv, sc, tid);
     float fb[FC * 4];
     const bool hasf = a.fbar != nullptr && mc < a.m_fbar;
     if (hasf) load_regs<FC>(a.fbar + mc * F, hi, fb);
@@ -113,45 +108,33 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
 #pragma unroll
       for (int i = 0; i < FC * 4; ++i) fb[i] = 0.f;
     }
-    dense_op_nobias<NT, FC, 1>(ws, fb, acc, tid);
-    float wv[KC * 4];
-    f32x4 sc;
-    rowvec_load<KC>(ws, wv, sc, tid);
     const float sb = a.sbar ? a.sbar[mc] : 0.f;
     if (valid && hi == 0) {
       *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(a.ones4 + m * 4) = f32x4{1.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < KC * 4; ++i) gh[i] = acc[i / 16][i % 16] + sb * wv[i];       // G(h_{L-1})
+    const int lt = a.L - 2;
+    constexpr bool PRET = FC >= SC;
+    Sweep2TopEpi<NT, PRET> te{a.hs + lt * lstride + mc * H, a.gas + lt * lstride + mc * H, a.gas + lt * lstride + m * H, hi, valid, sb, wv};
+    dense_op_epi<NT, FC, 0, 1, 0, Sweep2TopEpi<NT, PRET>>(ws, fb, acc, te, tid);      // -> G(a_{L-2})
+    commit_tiles<NT>(acc, ga);
+    ws.skip(rowvec_chunks(KC, 1) / SC, tid);                                             // the chain's copy of w_sdf
   }
-  for (int l = a.L - 2; l >= 0; --l) {
-    const float* hrow = a.hs + l * lstride + mc * H;
-    float* grow = a.gas + l * lstride + m * H;
-    const float* growc = a.gas + l * lstride + mc * H;
-    float ga[KC * 4];
-#pragma unroll
-    for (int c = 0; c < KC; ++c) {
-      const f32x4 hv = *reinterpret_cast<const f32x4*>(hrow + 8 * c + 4 * hi);
-      const f32x4 g2 = *reinterpret_cast<const f32x4*>(growc + 8 * c + 4 * hi);
-      f32x4 o;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        o[t] = fmaf(gh[c * 4 + t], sp_sigma_from_h(hv[t]), g2[t]);
-        ga[c * 4 + t] = o[t];
-      }
-      if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
-    }
-    if (l == 0) break;
+  for (int l = a.L - 2; l >= 1; --l) {
+    // G(h_l) = W_l^T G(a_l); epilogue -> G(a_{l-1}) = G(h_l) * sigma_{l-1} + G2(a_{l-1})
+    const float* hrow = a.hs + (l - 1) * lstride + mc * H;
+    const float* g2row = a.gas + (l - 1) * lstride + mc * H;
+    float* grow = a.gas + (l - 1) * lstride + m * H;
     if (l == a.skip) {
       f32x16 as[NT + PT];
-      dense_op_nobias<NT + PT, KC, 1>(ws, ga, as, tid);
+      Sweep2Epi<NT, PRE> e{hrow, g2row, grow, hi, valid, RS2};
+      dense_op_epi<NT + PT, KC, 0, 1, 0, Sweep2Epi<NT, PRE>>(ws, ga, as, e, tid);
 #pragma unroll
-      for (int i = 0; i < KC * 4; ++i) gh[i] = as[i / 16][i % 16] * RS2;
+      for (int i = 0; i < KC * 4; ++i) ga[i] = as[i / 16][i % 16];
     } else {
-      dense_op_nobias<NT, KC, 1>(ws, ga, acc, tid);
-#pragma unroll
-      for (int i = 0; i < KC * 4; ++i) gh[i] = acc[i / 16][i % 16];
+      Sweep2Epi<NT, PRE> e{hrow, g2row, grow, hi, valid, 1.0f};
+      dense_op_epi<NT, KC, 0, 1, 0, Sweep2Epi<NT, PRE>>(ws, ga, acc, e, tid);
+      commit_tiles<NT>(acc, ga);
     }
   }
 }
@@ -220,11 +203,13 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(RgbBwdArgs a) {
       }
     }
   }
-  f32x16 acc[NT];
-  for (int l = a.L - 2; l >= 0; --l) {
+  // top mask (exposed, VALU only): G(a_{L-2}) = G(r_{L-1}) where r_{L-1} > 0
+  constexpr bool PRE = KC >= SC;
+  float ga[KC * 4];
+  {
+    const int l = a.L - 2;
     const float* rrow = a.rs + l * lstride + mc * H;
     float* grow = a.gar + l * lstride + m * H;
-    float ga[KC * 4];
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       const f32x4 rv = *reinterpret_cast<const f32x4*>(rrow + 8 * c + 4 * hi);
@@ -233,15 +218,17 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(RgbBwdArgs a) {
       for (int t = 0; t < 4; ++t) { o[t] = rv[t] > 0.f ? gr[c * 4 + t] : 0.f; ga[c * 4 + t] = o[t]; }
       if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
     }
-    if (l == 0) {
-      f32x16 fa[FT];
-      dense_op_nobias<FT, KC, 1>(ws, ga, fa, tid);
-      store_tile<FT>(a.fbar + m * F, hi, valid, fa);
-    } else {
-      dense_op_nobias<NT, KC, 1>(ws, ga, acc, tid);
-#pragma unroll
-      for (int i = 0; i < KC * 4; ++i) gr[i] = acc[i / 16][i % 16];
-    }
+  }
+  f32x16 acc[NT];
+  for (int l = a.L - 2; l >= 1; --l) {
+    MaskEpi<PRE> e{a.rs + (l - 1) * lstride + mc * H, a.gar + (l - 1) * lstride + m * H, hi, valid};
+    dense_op_epi<NT, KC, 0, 1, 0, MaskEpi<PRE>>(ws, ga, acc, e, tid);
+    commit_tiles<NT>(acc, ga);
+  }
+  {
+    f32x16 fa[FT];
+    StoreEpi se{a.fbar + m * F, hi, valid};
+    dense_op_epi<FT, KC, 0, 1, 0, StoreEpi>(ws, ga, fa, se, tid);
   }
 }
 
@@ -272,11 +259,11 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
   if (p->H == 256 && p->F == 256) {
     a.n_fwd = sdf_fwd_hidden_stages(256, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
-    sdf_bwd_kernel<256, 256, 6><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(sdf_bwd_kernel<256, 256, 6>, grid, st, a);
   } else if (p->H == 64 && p->F == 64) {
     a.n_fwd = sdf_fwd_hidden_stages(64, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(64, 64, PE<6>::PEC, d.n_lin, has_skip);
-    sdf_bwd_kernel<64, 64, 6><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(sdf_bwd_kernel<64, 64, 6>, grid, st, a);
   } else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "sdf_backward launch");
 }
@@ -294,10 +281,10 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
-    rgb_bwd_kernel<256, 256><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(rgb_bwd_kernel<256, 256>, grid, st, a);
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_rev = rgb_rev_stages(64, 64, d.n_lin);
-    rgb_bwd_kernel<64, 64><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(rgb_bwd_kernel<64, 64>, grid, st, a);
   } else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "rgb_backward launch");
 }

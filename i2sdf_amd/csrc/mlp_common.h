@@ -2,7 +2,25 @@
 #pragma once
 #include "plan.h"
 
+#include <mutex>
+#include <unordered_set>
+
 namespace i2sdf {
+
+// launch a 256-thread kernel with the double-buffered weight stage in dynamic LDS (> 64 KB needs the attribute once)
+template <class K, class... A>
+inline void launch_lds(K kern, unsigned grid, hipStream_t st, A... args) {
+  static std::mutex mu;
+  static std::unordered_set<const void*> done;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count((const void*)kern)) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      done.insert((const void*)kern);
+    }
+  }
+  kern<<<grid, 256, LDS_BYTES, st>>>(args...);
+}
 
 constexpr float RS2 = 0.70710678118654752440f;
 
@@ -74,8 +92,9 @@ __device__ __forceinline__ void dense_op_nobias(WStream& ws, const float (&in)[N
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       if (j < j1) {
-        I2SDF_SGB(I2SDF_MASK_MFMA, 4);
+        I2SDF_SGB(I2SDF_MASK_MFMA, 1);
         if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+        I2SDF_SGB(I2SDF_MASK_MFMA, 3);
       }
     }
   }

@@ -1,6 +1,6 @@
 // SDF network forward without gradient: ImplicitNetwork.forward / get_sdf_vals
 // (model/network/mlp.py:84-105,145-151).  MFMA-bound: 2*524544 FLOP per point at synthetic.yml shapes.
-#include "mlp_common.h"
+#include "epi.h"
 
 using namespace i2sdf;
 
@@ -31,8 +31,9 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
   ws.begin(stream, lds, n_stages, tid);
   f32x16 acc[NT];
   float h[NT * 16];
-  dense_op<NT, PEC, 0>(ws, pe, acc, tid);
-  softplus_tiles<NT>(acc, h);
+  SoftplusEpi sp{nullptr, hi, valid};
+  dense_op_epi<NT, PEC, NT * 4, 0, 0, SoftplusEpi>(ws, pe, acc, sp, tid);
+  commit_tiles<NT>(acc, h);
   for (int l = 1; l < L - 1; ++l) {
     if (l == skip) {
       constexpr float rs2 = RS2;
@@ -41,11 +42,11 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
       for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * rs2;
 #pragma unroll
       for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = pe[i] * rs2;
-      dense_op<NT, KC + PEC, 0>(ws, u, acc, tid);
+      dense_op_epi<NT, KC + PEC, NT * 4, 0, 0, SoftplusEpi>(ws, u, acc, sp, tid);
     } else {
-      dense_op<NT, KC, 0>(ws, h, acc, tid);
+      dense_op_epi<NT, KC, NT * 4, 0, 0, SoftplusEpi>(ws, h, acc, sp, tid);
     }
-    softplus_tiles<NT>(acc, h);
+    commit_tiles<NT>(acc, h);
   }
   float s[1];
   rowvec_op<1, KC>(ws, h, s, tid);
@@ -67,9 +68,9 @@ int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, c
   const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (full)
-    sdf_fwd_kernel<H, F, LF, true><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, feat_out, ld_feat);
+    launch_lds(sdf_fwd_kernel<H, F, LF, true>, grid, st, stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, feat_out, ld_feat);
   else
-    sdf_fwd_kernel<H, F, LF, false><<<grid, 256, LDS_BYTES, st>>>(stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, nullptr, 0);
+    launch_lds(sdf_fwd_kernel<H, F, LF, false>, grid, st, stream, ns, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, nullptr, 0);
   return i2sdf_hip_check(hipGetLastError(), "sdf_forward launch");
 }
 

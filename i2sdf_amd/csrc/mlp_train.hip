@@ -4,7 +4,7 @@
 //                    is evaluated explicitly in the same kernel, in registers.
 //                   Saves h_l = softplus(a_{l-1}) and abar_l = d sdf / d a_l for the backward kernels.
 //   rgb_fwd       : RenderingNetwork.forward, 'nerf' mode (mlp.py:208-229), saves the post-ReLU activations.
-#include "mlp_common.h"
+#include "epi.h"
 
 using namespace i2sdf;
 
@@ -44,26 +44,27 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
   }
   if (a.pe_save) store_regs<PEC>(a.pe_save + m * (PEC * 8), hi, valid, pe);
   const int64_t lstride = a.Mp * H;
+  constexpr bool PRE = KC >= SC;          // at most one tile completes per LDS stage -> prefetching epilogues are legal
   WStream ws;
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 acc[NT];
   float h[NT * 16];
-  dense_op<NT, PEC, 0>(ws, pe, acc, tid);
-  softplus_tiles<NT>(acc, h);
-  if (a.hs) store_regs<KC>(a.hs + m * H, hi, valid, h);
+  SoftplusEpi fe{a.hs ? a.hs + m * H : nullptr, hi, valid};
+  dense_op_epi<NT, PEC, NT * 4, 0, 0, SoftplusEpi>(ws, pe, acc, fe, tid);
+  commit_tiles<NT>(acc, h);
   for (int l = 1; l < a.L - 1; ++l) {
+    fe.row = a.hs ? a.hs + l * lstride + m * H : nullptr;
     if (l == a.skip) {
       float u[(KC + PEC) * 4];
 #pragma unroll
       for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * RS2;
 #pragma unroll
       for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = pe[i] * RS2;
-      dense_op<NT, KC + PEC, 0>(ws, u, acc, tid);
+      dense_op_epi<NT, KC + PEC, NT * 4, 0, 0, SoftplusEpi>(ws, u, acc, fe, tid);
     } else {
-      dense_op<NT, KC, 0>(ws, h, acc, tid);
+      dense_op_epi<NT, KC, NT * 4, 0, 0, SoftplusEpi>(ws, h, acc, fe, tid);
     }
-    softplus_tiles<NT>(acc, h);
-    if (a.hs) store_regs<KC>(a.hs + l * lstride + m * H, hi, valid, h);
+    commit_tiles<NT>(acc, h);
   }
   {
     float s[1];
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
   }
   if (a.feat != nullptr) {
     f32x16 fa[FT];
-    dense_op<FT, KC, 0>(ws, h, fa, tid);
-    store_tile<FT>(a.feat + m * F, hi, valid, fa);
+    StoreEpi se{a.feat + m * F, hi, valid};
+    dense_op_epi<FT, KC, FT * 4, 0, 0, StoreEpi>(ws, h, fa, se, tid);
   }
   if (!GRAD) return;
   // ---------------- reverse chain: n = d sdf / d x  (appendix A.2) ----------------
@@ -94,29 +95,20 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) pt[i][r] = 0.f;
   for (int l = a.L - 2; l >= 1; --l) {
-    float hl[KC * 4];
+    const float* hrow = a.hs + (l - 1) * lstride + mc * H;
+    float* abrow = a.abars ? a.abars + (l - 1) * lstride + m * H : nullptr;
     if (l == a.skip) {
       f32x16 as[NT + PT];
-      dense_op_nobias<NT + PT, KC, 1>(ws, ab, as, tid);
-      load_regs<KC>(a.hs + (l - 1) * lstride + mc * H, hi, hl);
+      RevEpi<NT, PT, PRE> re{hrow, abrow, hi, valid, RS2, pt};
+      dense_op_epi<NT + PT, KC, 0, 1, 0, RevEpi<NT, PT, PRE>>(ws, ab, as, re, tid);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ab[nt * 16 + r] = as[nt][r] * RS2 * sp_sigma_from_h(hl[nt * 16 + r]);
-#pragma unroll
-      for (int i = 0; i < PT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pt[i][r] += as[NT + i][r] * RS2;
+      for (int i = 0; i < KC * 4; ++i) ab[i] = as[i / 16][i % 16];
     } else {
       f32x16 a2[NT];
-      dense_op_nobias<NT, KC, 1>(ws, ab, a2, tid);
-      load_regs<KC>(a.hs + (l - 1) * lstride + mc * H, hi, hl);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ab[nt * 16 + r] = a2[nt][r] * sp_sigma_from_h(hl[nt * 16 + r]);
+      RevEpi<NT, PT, PRE> re{hrow, abrow, hi, valid, 1.0f, pt};
+      dense_op_epi<NT, KC, 0, 1, 0, RevEpi<NT, PT, PRE>>(ws, ab, a2, re, tid);
+      commit_tiles<NT>(a2, ab);
     }
-    if (a.abars) store_regs<KC>(a.abars + (l - 1) * lstride + m * H, hi, valid, ab);
   }
   dense_op_nobias<PT, KC, 2>(ws, ab, pt, tid);       // pbar += W_0^T abar_0
   {
@@ -177,19 +169,13 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 acc[NT];
   float r[NT * 16];
-  dense_op<NT, PECV + FC, 0>(ws, in0, acc, tid);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) r[nt * 16 + q] = fmaxf(acc[nt][q], 0.f);
-  if (a.rs) store_regs<KC>(a.rs + m * H, hi, valid, r);
+  ReluEpi re{a.rs ? a.rs + m * H : nullptr, hi, valid};
+  dense_op_epi<NT, PECV + FC, NT * 4, 0, 0, ReluEpi>(ws, in0, acc, re, tid);
+  commit_tiles<NT>(acc, r);
   for (int l = 1; l < a.L - 1; ++l) {
-    dense_op<NT, KC, 0>(ws, r, acc, tid);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) r[nt * 16 + q] = fmaxf(acc[nt][q], 0.f);
-    if (a.rs) store_regs<KC>(a.rs + l * lstride + m * H, hi, valid, r);
+    re.row = a.rs ? a.rs + l * lstride + m * H : nullptr;
+    dense_op_epi<NT, KC, NT * 4, 0, 0, ReluEpi>(ws, r, acc, re, tid);
+    commit_tiles<NT>(acc, r);
   }
   float o[3];
   rowvec_op<3, KC>(ws, r, o, tid);
@@ -229,8 +215,8 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
   do {                                                                                               \
     a.n_fwd = sdf_fwd_stages(HH, FF, PE<6>::PEC, d.n_lin, has_skip, feat != nullptr);                \
     a.n_rev = sdf_rev_stages(HH, PE<6>::PEC, d.n_lin, has_skip);                                     \
-    if (grad) sdf_train_fwd_kernel<HH, FF, 6, true><<<grid, 256, LDS_BYTES, st>>>(a);                \
-    else sdf_train_fwd_kernel<HH, FF, 6, false><<<grid, 256, LDS_BYTES, st>>>(a);                    \
+    if (grad) launch_lds(sdf_train_fwd_kernel<HH, FF, 6, true>, grid, st, a);                \
+    else launch_lds(sdf_train_fwd_kernel<HH, FF, 6, false>, grid, st, a);                    \
   } while (0)
   if (p->H == 256 && p->F == 256) LAUNCH(256, 256);
   else if (p->H == 64 && p->F == 64) LAUNCH(64, 64);
@@ -253,10 +239,10 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
-    rgb_fwd_kernel<256, 256, 4><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(rgb_fwd_kernel<256, 256, 4>, grid, st, a);
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_fwd = rgb_fwd_stages(64, 64, PE<4>::PEC, d.n_lin);
-    rgb_fwd_kernel<64, 64, 4><<<grid, 256, LDS_BYTES, st>>>(a);
+    launch_lds(rgb_fwd_kernel<64, 64, 4>, grid, st, a);
   } else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "rgb_forward launch");
 }
@@ -293,9 +279,9 @@ __global__ __launch_bounds__(256) void light_fwd_kernel(LightArgs a) {
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 acc[NT];
   float h[NT * 16];
-  dense_op<NT, FC, 0>(ws, in0, acc, tid);
-  softplus_tiles<NT>(acc, h);
-  if (a.hl) store_regs<KC>(a.hl + m * HL, hi, valid, h);
+  SoftplusEpi le{a.hl ? a.hl + m * HL : nullptr, hi, valid};
+  dense_op_epi<NT, FC, NT * 4, 0, 0, SoftplusEpi>(ws, in0, acc, le, tid);
+  commit_tiles<NT>(acc, h);
   float o[1];
   rowvec_op<1, KC>(ws, h, o, tid);
   if (valid && hi == 0) a.lm[m] = 1.0f / (1.0f + expf(-o[0]));
@@ -337,8 +323,8 @@ extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, con
   a.feat = feat; a.M = M; a.Mp = Mp; a.lm = lm; a.hl = hl;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
-  if (HL == 128 && F == 256) light_fwd_kernel<128, 256><<<grid, 256, LDS_BYTES, st>>>(a);
-  else if (HL == 32 && F == 64) light_fwd_kernel<32, 64><<<grid, 256, LDS_BYTES, st>>>(a);
+  if (HL == 128 && F == 256) launch_lds(light_fwd_kernel<128, 256>, grid, st, a);
+  else if (HL == 32 && F == 64) launch_lds(light_fwd_kernel<32, 64>, grid, st, a);
   else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "light_forward launch");
 }
@@ -355,8 +341,8 @@ extern "C" int i2sdf_light_backward(const i2sdf_plan* p, const float* packed, co
   a.M = M; a.Mp = Mp; a.lm = const_cast<float*>(lm); a.lm_bar = lm_bar; a.hl = const_cast<float*>(hl); a.gal0 = gal0; a.gal_last = gal_last;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
-  if (HL == 128) light_bwd_kernel<128><<<grid, 256, LDS_BYTES, st>>>(a);
-  else if (HL == 32) light_bwd_kernel<32><<<grid, 256, LDS_BYTES, st>>>(a);
+  if (HL == 128) launch_lds(light_bwd_kernel<128>, grid, st, a);
+  else if (HL == 32) launch_lds(light_bwd_kernel<32>, grid, st, a);
   else return I2SDF_EINVAL;
   return i2sdf_hip_check(hipGetLastError(), "light_backward launch");
 }

@@ -116,8 +116,11 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
   emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
   if (F > 0) emit_dense_fwd(b, np, L - 1, F / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F);
   np.fwd_chunks = b.chunk - np.fwd_chunk0;
-  // reverse (transposed) stream: [Wfeat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
+  // reverse (transposed) stream: [w_sdf][Wfeat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
+  //   backward sweep 2 starts at rev_chunk0 (needs w_sdf before the feature op so that the op's epilogue can use it) and
+  //   skips the second copy; the d sdf/dx chain starts at rev_wsdf_chunk.
   np.rev_chunk0 = b.chunk;
+  emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
   if (F > 0) emit_dense_bwd(b, np, L - 1, H / 32, F / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F);
   np.rev_wsdf_chunk = b.chunk;
   emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
