@@ -24,12 +24,11 @@ struct WgTask {
 };
 struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t pad; int64_t chunk_stride; float* partials; };
 
-__global__ __launch_bounds__(256) void wgrad_kernel(WgLaunch L) {
+__global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
   const int lane = threadIdx.x & 63;
-  const int tile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (tile >= L.n) return;
+  const int tile = blockIdx.y;
   const WgTask& t = L.t[tile];
-  const int64_t chunk = blockIdx.y;
+  const int64_t chunk = blockIdx.x;
   const int i32 = lane & 31, hi = lane >> 5;
   f32x16 acc[4][4];
 #pragma unroll
@@ -294,13 +293,18 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
                  {Mm}, {{tb->hl, H, H}}, {}, 0, false);
   }
   (void)light_first;
+  // longest tiles first (2-job tiles, then wide ones): the tail of the launch is then made of short tiles
+  std::stable_sort(tl.tasks.begin(), tl.tasks.end(), [](const WgTask& x, const WgTask& y) {
+    const int64_t cx = (int64_t)x.njobs * 1000 + x.rows_store + x.cols_store, cy = (int64_t)y.njobs * 1000 + y.rows_store + y.cols_store;
+    return cx > cy;
+  });
   for (size_t off = 0; off < tl.tasks.size(); off += MAX_TASKS) {
     WgLaunch L{};
     L.n = (int32_t)std::min<size_t>(MAX_TASKS, tl.tasks.size() - off);
     for (int i = 0; i < L.n; ++i) L.t[i] = tl.tasks[off + i];
     L.chunk_stride = p->wgrad_floats; L.partials = partials;
-    dim3 grid((unsigned)cdiv(L.n, 4), (unsigned)n_chunks);
-    wgrad_kernel<<<grid, 256, 0, st>>>(L);
+    dim3 grid((unsigned)n_chunks, (unsigned)L.n);
+    wgrad_kernel<<<grid, 64, 0, st>>>(L);
   }
   WnTab tab{};
   int row0 = 0;
