@@ -1,0 +1,121 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/i2sdf.h declares, and its host-side logic
+(plan construction, argument validation, error codes) behaves -- no compute call needs a GPU here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def lib():
+    from i2sdf_amd import lib as L
+    if not os.path.exists(L.LIB_PATH):
+        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True)
+    return L
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "i2sdf.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(i2sdf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    syms = header_symbols()
+    assert len(syms) >= 20
+    raw = C.CDLL(lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/i2sdf.h but not exported"
+        assert s in lib.SIGNATURES, f"{s} has no ctypes signature in i2sdf_amd/lib.py"
+    for s in lib.SIGNATURES:
+        assert s in syms, f"{s} bound in lib.py but not declared in the header"
+
+
+def test_version_and_error_strings(lib):
+    h = lib.load()
+    assert h.i2sdf_version() == 100
+    assert h.i2sdf_strerror(0) == b"ok"
+    assert b"invalid" in h.i2sdf_strerror(-1)
+    assert h.i2sdf_wgrad_chunk_points() == 1024
+    assert h.i2sdf_sampler_workspace_floats(10) > 10 * 640 * 6
+
+
+def _plan(lib, conf):
+    from i2sdf_amd.config import NetConfig
+    from i2sdf_amd.params import ParamLayout
+    lay = ParamLayout(NetConfig.from_conf(conf))
+    desc = lay.net_desc()
+    plan = C.c_void_p()
+    rc = lib.load().i2sdf_plan_create(C.byref(desc), C.byref(plan))
+    return rc, plan, lay, desc
+
+
+def test_plan_layout_sizes(lib):
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    h = lib.load()
+    for conf, n_params in ((synthetic_conf(), 800955), (synthetic_conf(True), 635965), (plumbing_conf(), None), (plumbing_conf(True, True), None)):
+        rc, plan, lay, _ = _plan(lib, conf)
+        assert rc == 0
+        if n_params:
+            assert lay.n_params == n_params          # SURVEY.md appendix B [probed on the reference]
+        pack = h.i2sdf_plan_pack_floats(plan)
+        # forward + transposed streams (+ padding) hold every weight about twice
+        assert 2 * lay.n_params * 0.9 < pack < 2 * lay.n_params * 1.6 + 64 * 8192
+        assert h.i2sdf_plan_wgrad_floats(plan) >= lay.n_params - 1
+        h.i2sdf_plan_destroy(plan)
+
+
+def test_unsupported_shapes_are_rejected(lib):
+    from i2sdf_amd.config import synthetic_conf
+    conf = synthetic_conf()
+    rc, plan, lay, desc = _plan(lib, conf)
+    assert rc == 0
+    lib.load().i2sdf_plan_destroy(plan)
+    bad = type(desc)()
+    C.memmove(C.byref(bad), C.byref(desc), C.sizeof(desc))
+    bad.sdf.hidden = 250                                  # not a multiple of 32
+    p2 = C.c_void_p()
+    assert lib.load().i2sdf_plan_create(C.byref(bad), C.byref(p2)) == -1
+    C.memmove(C.byref(bad), C.byref(desc), C.sizeof(desc))
+    bad.sdf.skip_layer = 0
+    assert lib.load().i2sdf_plan_create(C.byref(bad), C.byref(p2)) == -1
+    assert lib.load().i2sdf_plan_create(None, C.byref(p2)) == -1
+
+
+def test_entry_points_validate_arguments_without_a_gpu(lib):
+    from i2sdf_amd.config import plumbing_conf
+    h = lib.load()
+    rc, plan, lay, _ = _plan(lib, plumbing_conf())
+    assert rc == 0
+    P = C.c_void_p(4096)
+    assert h.i2sdf_sdf_forward(plan, P, None, 10, P, None, 0, None) == -1                    # no points
+    assert h.i2sdf_sdf_forward(plan, P, P, 0, P, None, 0, None) == 0                         # empty batch is a no-op
+    assert h.i2sdf_sdf_forward_grad(plan, P, P, None, None, None, 0, 1, 0, 300, 300, P, P, P, P, P, P, None) == -1   # Mp not x128
+    assert h.i2sdf_sdf_forward_grad(plan, P, None, None, None, None, 0, 1, 0, 300, 384, P, P, P, P, P, P, None) == -1  # no source
+    assert h.i2sdf_rgb_forward(plan, P, P, 0, P, 10, 128, P, P, P, None) == -1               # n_per_ray <= 0
+    assert h.i2sdf_composite_forward(P, 1e-4, P, 10, P, P, None, None, P, 4, 300, P, P, P, None, None, None, None, None) == -1  # n > 256
+    assert h.i2sdf_composite_forward(P, 1e-4, P, 10, P, P, None, None, P, 4, 9, P, P, P, P, None, None, None, None) == -1     # normal without grad
+    assert h.i2sdf_light_forward(plan, P, P, 10, 128, P, P, None) == -1                       # this net has no light head
+    assert h.i2sdf_ray_setup(P, P, P, 4, 0, P, P, P, None) == -1
+    h.i2sdf_plan_destroy(plan)
+
+
+def test_missing_library_fails_loudly(monkeypatch, lib):
+    from i2sdf_amd import lib as L
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", "/nonexistent/libi2sdf_hip.so")
+    with pytest.raises(L.I2SDFError):
+        L.load()
+
+
+def test_module_refuses_cpu_tensors():
+    import torch
+    from i2sdf_amd import I2SDFNetwork, plumbing_conf
+    net = I2SDFNetwork(plumbing_conf())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.implicit_network(torch.zeros(4, 3))
