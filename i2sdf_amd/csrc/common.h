@@ -62,6 +62,9 @@ struct WStream {
   __device__ __forceinline__ void issue(float* dst, int tid) {
     const float* src = g + tid * 4;
     float* d = dst + (tid & ~63) * 4;     // wave-uniform LDS base; hardware adds lane*16 B
+#ifdef I2SDF_ABL_NODMA
+    g += STAGE_FLOATS; (void)src; (void)d; return;
+#endif
 #pragma unroll
     for (int i = 0; i < STAGE_FLOATS / (WG_THREADS * 4); ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * WG_THREADS * 4),
@@ -76,7 +79,10 @@ struct WStream {
   }
   // Returns the LDS buffer holding the next stage.  All 4 waves must call this in lock step.
   __device__ __forceinline__ const float* advance(int tid) {
+#ifndef I2SDF_ABL_NOBARRIER
     __syncthreads();      // (a) my DMA for this stage landed (hipcc drains vmcnt before the barrier),
+#endif
+    // 
                           // (b) every wave's did, (c) every wave finished reading the other buffer
     const float* ret = lds + cur * STAGE_FLOATS;
     if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
@@ -287,16 +293,14 @@ __device__ __forceinline__ void rowvec_op(WStream& ws, const float (&in)[KC * 4]
 // activations
 // ---------------------------------------------------------------------------------------------
 // nn.Softplus(beta=100, threshold=20): log1p(exp(100a))/100, identity above the threshold (mlp.py:76).
-// log1p through the compensated form log(u) * z/(u-1), u = fl(1+z): ~1 ulp without a slow-path call.
+// Evaluated as max(a,0) + log1p(exp(-|100a|))/100 with the hardware exp2/log2: z = exp(-|100a|) is in (0,1], so 1+z is in
+// (1,2] and log2(1+z) has an ABSOLUTE error of ~1 ulp(1) = 6e-8, i.e. 6e-10 on h after the /100 -- below fp32 resolution of
+// the O(0.01..1) activations it is added to; above the threshold z < 2e-9 vanishes against 1 and h == a exactly (torch's
+// threshold branch).  6 VALU ops, 2 of them transcendental.
 __device__ __forceinline__ float softplus100(float a) {
-  const float t = 100.f * a;
-  const float z = __builtin_amdgcn_exp2f(t * 1.44269504088896341f);
-  const float u = 1.0f + z;
-  const float d = u - 1.0f;
-  const float lg = __builtin_amdgcn_logf(u) * (0.693147180559945309f * 0.01f);
-  float r = lg * (z * __builtin_amdgcn_rcpf(d));
-  r = (d == 0.f) ? z * 0.01f : r;
-  return (t > 20.f) ? a : r;
+  const float z = __builtin_amdgcn_exp2f(-fabsf(a) * (100.f * 1.44269504088896341f));
+  const float l = __builtin_amdgcn_logf(1.0f + z);                 // log2
+  return fmaf(l, 0.693147180559945309f * 0.01f, fmaxf(a, 0.f));
 }
 // sigma = softplus100'(a) recovered from h = softplus100(a):  1 - exp(-100 h)   (exactly 1 in the threshold
 // branch up to rounding: 1 - e^-20 rounds to 1.0f).
@@ -314,16 +318,28 @@ struct PE {
   static constexpr int PEC = cdiv(DIM, 8);
 };
 
+// sin/cos(2^k x) for k = 0..LF-1 with ONE range reduction: r = x/(2 pi) in revolutions as a hi+lo pair (fma residual),
+// 2^k r is exact, its fractional part is exact (t - rint(t)), and v_sin_f32 / v_cos_f32 take revolutions directly.
+// Reduction error <= 1.2e-7 abs for |x| <= 6 (numpy emulation); ~25x cheaper than 2*LF*3 libm calls.
 template <int LF>
 __device__ __forceinline__ void pe_full(float x, float y, float z, float (&full)[PE<LF>::PEC * 8]) {
 #pragma unroll
   for (int i = 0; i < PE<LF>::PEC * 8; ++i) full[i] = 0.f;
   full[0] = x; full[1] = y; full[2] = z;
+  constexpr float INV2PI_HI = 0.15915493667125702f, INV2PI_LO = 6.4206382432985265e-09f;
+  const float v[3] = {x, y, z};
 #pragma unroll
-  for (int k = 0; k < LF; ++k) {
-    const float f = (float)(1 << k);
-    full[3 + 6 * k + 0] = sinf(x * f); full[3 + 6 * k + 1] = sinf(y * f); full[3 + 6 * k + 2] = sinf(z * f);
-    full[3 + 6 * k + 3] = cosf(x * f); full[3 + 6 * k + 4] = cosf(y * f); full[3 + 6 * k + 5] = cosf(z * f);
+  for (int i = 0; i < 3; ++i) {
+    const float r_hi = v[i] * INV2PI_HI;
+    const float r_lo = fmaf(v[i], INV2PI_HI, -r_hi) + v[i] * INV2PI_LO;
+#pragma unroll
+    for (int k = 0; k < LF; ++k) {
+      const float sc = (float)(1 << k);
+      const float t = r_hi * sc;
+      const float ph = (t - rintf(t)) + r_lo * sc;
+      full[3 + 6 * k + i] = __builtin_amdgcn_sinf(ph);
+      full[3 + 6 * k + 3 + i] = __builtin_amdgcn_cosf(ph);
+    }
   }
 }
 template <int NC>
