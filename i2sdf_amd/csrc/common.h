@@ -170,6 +170,7 @@ __device__ __forceinline__ void dense_op(WStream& ws, const float (&in)[KC * 4],
 // ---------------------------------------------------------------------------------------------
 struct NoEpi {
   __device__ __forceinline__ void prefetch(int) {}
+  __device__ __forceinline__ void elem(int, f32x16&, int) {}
   __device__ __forceinline__ void apply(int, f32x16&) {}
 };
 
@@ -194,11 +195,24 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
       const int last = NB + (nt + 1) * KC;           // one past the tile's last chunk
       if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(nt);
     }
-    // tiles that completed during the previous stage: epilogue now, under this stage's MFMAs
+    // tiles that completed during the previous stage get their epilogue during this stage.  If it is exactly one tile,
+    // its 16 elements are dealt out between the stage's chunks (one element after every other chunk's MFMAs, where the
+    // 64-cycle MFMA gaps absorb the VALU work); otherwise the epilogues run here, in front of the MFMAs.
+    int pend = -1, npend = 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int last = NB + (nt + 1) * KC;
-      if (s > 0 && last > (s - 1) * SC && last <= s * SC) epi.apply(nt, acc[nt]);
+      if (s > 0 && last > (s - 1) * SC && last <= s * SC) { pend = nt; ++npend; }
+    }
+    const int j0 = (s * SC < NB) ? ((NB - s * SC < SC) ? NB - s * SC : SC) : 0;
+    const int j1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? NB + NW - s * SC : 0) : SC;
+    const bool deal = (npend == 1) && (j1 - j0 >= 32);
+    if (!deal) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int last = NB + (nt + 1) * KC;
+        if (s > 0 && last > (s - 1) * SC && last <= s * SC) epi.apply(nt, acc[nt]);
+      }
     }
     // ---- bias chunks of this stage
 #pragma unroll
@@ -214,12 +228,11 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
         }
       }
     }
-    const int j0 = (s * SC < NB) ? ((NB - s * SC < SC) ? NB - s * SC : SC) : 0;
-    const int j1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? NB + NW - s * SC : 0) : SC;
     f32x4 ab[PF];
 #pragma unroll
     for (int i = 0; i < PF; ++i)
       if (j0 + i < j1) ab[i] = cur[(j0 + i) * 64];
+    if (deal) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       if (j >= j0 && j < j1) {
@@ -231,18 +244,28 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
         acc[nt] = mfma(a.y, in[kc * 4 + 1], acc[nt]);
         acc[nt] = mfma(a.z, in[kc * 4 + 2], acc[nt]);
         acc[nt] = mfma(a.w, in[kc * 4 + 3], acc[nt]);
+        if (deal) {
+          const int jj = j - j0;
+          if ((jj & 1) == 0 && jj / 2 < 16) epi.elem(pend, acc[pend < 0 ? 0 : pend], jj / 2);
+          // per-chunk scheduling region: {MFMA, ds_read, 3 MFMA} then this chunk's share of the epilogue
+          I2SDF_SGB(I2SDF_MASK_MFMA, 1);
+          if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+          I2SDF_SGB(I2SDF_MASK_MFMA, 3);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
+    if (!deal) {
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-      if (j0 + i < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+      for (int i = 0; i < PF; ++i)
+        if (j0 + i < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
 #pragma unroll
-    for (int j = 0; j < SC; ++j) {
-      if (j >= j0 && j < j1) {
-        I2SDF_SGB(I2SDF_MASK_MFMA, 1);
-        if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
-        I2SDF_SGB(I2SDF_MASK_MFMA, 3);
-        if (VALU_PER_CHUNK > 0) I2SDF_SGB(0x002, VALU_PER_CHUNK);
+      for (int j = 0; j < SC; ++j) {
+        if (j >= j0 && j < j1) {
+          I2SDF_SGB(I2SDF_MASK_MFMA, 1);
+          if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
+          I2SDF_SGB(I2SDF_MASK_MFMA, 3);
+        }
       }
     }
   }

@@ -35,31 +35,45 @@ __device__ __forceinline__ void commit_tiles(const f32x16 (&acc)[N], float (&h)[
     for (int r = 0; r < 16; ++r) h[nt * 16 + r] = acc[nt][r];
 }
 
+__device__ __forceinline__ void store_quad(float* __restrict__ row, int nt, int q, int hi, bool valid, const f32x16& t) {
+  if (valid) *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q + 4 * hi) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+__device__ __forceinline__ void store_quad(float* __restrict__ row, int nt, int q, int hi, bool valid, const float (&t)[16]) {
+  if (valid) *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q + 4 * hi) = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+#define I2SDF_APPLY_FROM_ELEM                                             \
+  __device__ __forceinline__ void apply(int nt, f32x16& acc) {            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) elem(nt, acc, r);      \
+  }
+
 // h = softplus100(a) [+ store h]                      (forward, SDF net / light head)
 struct SoftplusEpi {
   float* row; int hi; bool valid;
   __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = softplus100(acc[r]);
-    if (row) store_tile16(row, nt, hi, valid, acc);
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    acc[r] = softplus100(acc[r]);
+    if (row && (r & 3) == 3) store_quad(row, nt, r >> 2, hi, valid, acc);
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 // r = max(a, 0) [+ store r]                            (forward, radiance net)
 struct ReluEpi {
   float* row; int hi; bool valid;
   __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.f);
-    if (row) store_tile16(row, nt, hi, valid, acc);
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    acc[r] = fmaxf(acc[r], 0.f);
+    if (row && (r & 3) == 3) store_quad(row, nt, r >> 2, hi, valid, acc);
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 // plain store                                          (feature tiles)
 struct StoreEpi {
   float* row; int hi; bool valid;
   __device__ __forceinline__ void prefetch(int) {}
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) { store_tile16(row, nt, hi, valid, acc); }
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    if ((r & 3) == 3) store_quad(row, nt, r >> 2, hi, valid, acc);
+  }
+  I2SDF_APPLY_FROM_ELEM
 };
 
 // d sdf/dx chain: abar_{l-1} = (W_l^T abar_l) * scale * sigma(h_l) [store]; tiles >= NT (skip layer) add into pbar
@@ -71,17 +85,16 @@ struct RevEpi {
   __device__ __forceinline__ void prefetch(int nt) {
     if (PRE && nt < NT) load_tile16(hrow, nt, hi, hb[nt & 1]);
   }
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
     if (nt < NT) {
-      if (!PRE) load_tile16(hrow, nt, hi, hb[nt & 1]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = acc[r] * scale * sp_sigma_from_h(hb[nt & 1][r]);
-      if (abrow) store_tile16(abrow, nt, hi, valid, acc);
+      if (!PRE && r == 0) load_tile16(hrow, nt, hi, hb[nt & 1]);
+      acc[r] = acc[r] * scale * sp_sigma_from_h(hb[nt & 1][r]);
+      if (abrow && (r & 3) == 3) store_quad(abrow, nt, r >> 2, hi, valid, acc);
     } else {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pt[nt - NT][r] += acc[r] * scale;
+      pt[nt - NT < 0 ? 0 : nt - NT][r] += acc[r] * scale;
     }
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 
 // backward sweep 1: G(hbar_{l+1}) = G(abar_l) * sigma_l [store, stays in acc]; G2(a_l) = G(abar_l) * abar_l * 100(1-sigma_l) [store]
@@ -89,25 +102,22 @@ template <bool PRE>
 struct Sweep1Epi {
   const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
   float hb[2][16], ab[2][16];
+  float g2[16];
   __device__ __forceinline__ void prefetch(int nt) {
     if (PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(arow, nt, hi, ab[nt & 1]); }
   }
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
-    if (!PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(arow, nt, hi, ab[nt & 1]); }
-    float g2[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float ga = acc[r];
-      const float sg = sp_sigma_from_h(hb[nt & 1][r]);
-      acc[r] = ga * sg;
-      g2[r] = ga * ab[nt & 1][r] * (100.f * (1.0f - sg));
-    }
-    store_tile16(g2row, nt, hi, valid, g2);
-    store_tile16(gurow, nt, hi, valid, acc);
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    if (!PRE && r == 0) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(arow, nt, hi, ab[nt & 1]); }
+    const float ga = acc[r];
+    const float sg = sp_sigma_from_h(hb[nt & 1][r]);
+    acc[r] = ga * sg;
+    g2[r] = ga * ab[nt & 1][r] * (100.f * (1.0f - sg));
+    if ((r & 3) == 3) { store_quad(g2row, nt, r >> 2, hi, valid, g2); store_quad(gurow, nt, r >> 2, hi, valid, acc); }
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 
-// backward sweep 2: G(a_l) = (W_{l+1}^T G(a_{l+1}) [+ sbar * w_sdf]) * scale * sigma_l + G2(a_l) [store]; tiles >= NT ignored
+// backward sweep 2: G(a_l) = (W_{l+1}^T G(a_{l+1})) * scale * sigma_l + G2(a_l) [store]; tiles >= NT ignored
 template <int NT, bool PRE>
 struct Sweep2Epi {
   const float* hrow; const float* g2row; float* grow; int hi; bool valid; float scale;
@@ -115,14 +125,14 @@ struct Sweep2Epi {
   __device__ __forceinline__ void prefetch(int nt) {
     if (PRE && nt < NT) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
   }
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
     if (nt < NT) {
-      if (!PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r] * scale, sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
-      store_tile16(grow, nt, hi, valid, acc);
+      if (!PRE && r == 0) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
+      acc[r] = fmaf(acc[r] * scale, sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
+      if ((r & 3) == 3) store_quad(grow, nt, r >> 2, hi, valid, acc);
     }
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 // top of sweep 2: G(h_{L-1}) = W_feat^T fbar + sbar * w_sdf, then as above
 template <int NT, bool PRE>
@@ -133,13 +143,12 @@ struct Sweep2TopEpi {
   __device__ __forceinline__ void prefetch(int nt) {
     if (PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
   }
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
-    if (!PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc[r] = fmaf(fmaf(sb, wv[nt * 16 + r], acc[r]), sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
-    store_tile16(grow, nt, hi, valid, acc);
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    if (!PRE && r == 0) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
+    acc[r] = fmaf(fmaf(sb, wv[nt * 16 + r], acc[r]), sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
+    if ((r & 3) == 3) store_quad(grow, nt, r >> 2, hi, valid, acc);
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 
 // radiance backward: G(a_l) = G(r_{l+1}) masked by r_{l+1} > 0 [store]
@@ -148,12 +157,12 @@ struct MaskEpi {
   const float* rrow; float* grow; int hi; bool valid;
   float rb[2][16];
   __device__ __forceinline__ void prefetch(int nt) { if (PRE) load_tile16(rrow, nt, hi, rb[nt & 1]); }
-  __device__ __forceinline__ void apply(int nt, f32x16& acc) {
-    if (!PRE) load_tile16(rrow, nt, hi, rb[nt & 1]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = rb[nt & 1][r] > 0.f ? acc[r] : 0.f;
-    store_tile16(grow, nt, hi, valid, acc);
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    if (!PRE && r == 0) load_tile16(rrow, nt, hi, rb[nt & 1]);
+    acc[r] = rb[nt & 1][r] > 0.f ? acc[r] : 0.f;
+    if ((r & 3) == 3) store_quad(grow, nt, r >> 2, hi, valid, acc);
   }
+  I2SDF_APPLY_FROM_ELEM
 };
 
 }  // namespace i2sdf

@@ -6,7 +6,7 @@
 #include "epi.h"
 using namespace i2sdf;
 
-struct IdEpi { __device__ __forceinline__ void prefetch(int) {} __device__ __forceinline__ void apply(int, f32x16&) {} };
+struct IdEpi { __device__ __forceinline__ void prefetch(int) {} __device__ __forceinline__ void elem(int, f32x16&, int) {} __device__ __forceinline__ void apply(int, f32x16&) {} };
 
 template <int VAR>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ stream, int n_stages, int L, int skip, const float* __restrict__ pts, int64_t M,
