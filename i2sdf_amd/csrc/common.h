@@ -89,6 +89,17 @@ struct WStream {
     cur ^= 1;
     return ret;
   }
+  // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
+  __device__ __forceinline__ const float* advance_barrier() {
+#ifndef I2SDF_ABL_NOBARRIER
+    __syncthreads();
+#endif
+    return lds + cur * STAGE_FLOATS;
+  }
+  __device__ __forceinline__ void advance_issue(int tid) {
+    if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
+    cur ^= 1;
+  }
   // skip `n` stages without computing (still in lock step)
   __device__ __forceinline__ void skip(int n, int tid) {
     for (int i = 0; i < n; ++i) (void)advance(tid);
@@ -187,17 +198,10 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
   }
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
     // tile nt is complete before stage s  <=>  NB + (nt+1)*KC <= s*SC
-    // tiles completing during this stage: issue their operand loads now
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int last = NB + (nt + 1) * KC;           // one past the tile's last chunk
-      if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(nt);
-    }
     // tiles that completed during the previous stage get their epilogue during this stage.  If it is exactly one tile,
     // its 16 elements are dealt out between the stage's chunks (one element after every other chunk's MFMAs, where the
-    // 64-cycle MFMA gaps absorb the VALU work); otherwise the epilogues run here, in front of the MFMAs.
+    // 64-cycle MFMA gaps absorb the VALU work); otherwise the epilogues run in front of the MFMAs.
     int pend = -1, npend = 0;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -207,6 +211,18 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
     const int j0 = (s * SC < NB) ? ((NB - s * SC < SC) ? NB - s * SC : SC) : 0;
     const int j1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? NB + NW - s * SC : 0) : SC;
     const bool deal = (npend == 1) && (j1 - j0 >= 32);
+    const f32x4* cur;
+    if (deal) {
+      cur = reinterpret_cast<const f32x4*>(ws.advance_barrier()) + lane;      // DMA + operand loads follow inside the chunk stream
+    } else {
+      cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+      // tiles completing during this stage: issue their operand loads now
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int last = NB + (nt + 1) * KC;
+        if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(nt);
+      }
+    }
     if (!deal) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -246,6 +262,14 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
         acc[nt] = mfma(a.w, in[kc * 4 + 3], acc[nt]);
         if (deal) {
           const int jj = j - j0;
+          if (jj == 1) ws.advance_issue(tid);                    // next stage's DMA, in the shadow of this chunk's MFMAs
+          if (jj == 3) {
+#pragma unroll
+            for (int n2 = 0; n2 < NT; ++n2) {
+              const int last = NB + (n2 + 1) * KC;
+              if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(n2);
+            }
+          }
           if ((jj & 1) == 0 && jj / 2 < 16) epi.elem(pend, acc[pend < 0 ? 0 : pend], jj / 2);
           // per-chunk scheduling region: {MFMA, ds_read, 3 MFMA} then this chunk's share of the epilogue
           I2SDF_SGB(I2SDF_MASK_MFMA, 1);
