@@ -124,10 +124,10 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    iters = int(net.last_sampler_iters.item())
     n_shaded = eng.n_z - 1
     ms = dt / args.steps * 1e3
     value = B * n_shaded * world / (dt / args.steps)
-    iters = int(net.last_sampler_iters.item())
 
     result = None
     if rank == 0:

@@ -1,0 +1,177 @@
+// I2SDFLoss forward + gradient w.r.t. the render outputs in three tiny launches:
+// model/network/__init__.py:289-406 with its quirks (angular term = the same L1 normal term, :368-369).
+// Replaces ~100 element-wise torch kernels (forward and autograd backward) per training step.
+#include <algorithm>
+#include "plan.h"
+
+using namespace i2sdf;
+
+int i2sdf_hip_check(hipError_t e, const char* what);
+
+namespace {
+
+enum { S_RGB = 0, S_EIK, S_SMOOTH, S_MASK, S_DEPTH, S_DEPTH_CNT, S_NORMAL, S_NORMAL_CNT, S_BUBBLE, S_LIGHT, S_N };
+constexpr int LOSS_BLOCKS = 64;
+
+struct LossArgs {
+  i2sdf_loss_cfg c;
+  int64_t B, n_pc;
+  const float *rgb, *depth, *wsum, *normal, *grad_theta, *diff_norm, *surface, *lmask;
+  const float *gt_rgb, *gt_depth, *gt_normal, *gt_mask, *gt_lmask;
+  const uint8_t *depth_mask, *normal_mask;
+  float* partial;      // (LOSS_BLOCKS, S_N)
+  float* sums;         // (S_N)
+  float* losses;       // (10): loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask
+  float *g_rgb, *g_depth, *g_wsum, *g_normal, *g_grad_theta, *g_diff_norm, *g_surface, *g_lmask;
+};
+
+__device__ __forceinline__ float bce(float p_raw, float y, float& dp) {
+  const float p = fminf(fmaxf(p_raw, 1e-3f), 1.0f - 1e-3f);
+  const bool inside = p_raw >= 1e-3f && p_raw <= 1.0f - 1e-3f;
+  const float l = -(y * fmaxf(logf(p), -100.f) + (1.0f - y) * fmaxf(logf(1.0f - p), -100.f));   // F.binary_cross_entropy clamps log at -100
+  dp = inside ? (-(y / p) + (1.0f - y) / (1.0f - p)) : 0.f;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
+  float s[S_N];
+#pragma unroll
+  for (int i = 0; i < S_N; ++i) s[i] = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.B; i += stride) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[S_RGB] += fabsf(a.rgb[i * 3 + k] - a.gt_rgb[i * 3 + k]);
+    if (a.diff_norm) s[S_SMOOTH] += a.diff_norm[i];
+    if (a.gt_mask) { float d; s[S_MASK] += bce(a.wsum[i], a.gt_mask[i], d); }
+    if (a.gt_depth) {
+      const float m = a.depth_mask[i] ? 1.f : 0.f, d = a.depth[i] - a.gt_depth[i];
+      s[S_DEPTH] += m * d * d; s[S_DEPTH_CNT] += m;
+    }
+    if (a.gt_normal && a.normal) {
+      const float m = a.normal_mask[i] ? 1.f : 0.f;
+      const float dot = a.normal[i * 3] * a.gt_normal[i * 3] + a.normal[i * 3 + 1] * a.gt_normal[i * 3 + 1] + a.normal[i * 3 + 2] * a.gt_normal[i * 3 + 2];
+      s[S_NORMAL] += m * fabsf(1.0f - dot); s[S_NORMAL_CNT] += m;
+    }
+    if (a.lmask && a.gt_lmask) { float d; s[S_LIGHT] += bce(a.lmask[i], a.gt_lmask[i], d); }
+  }
+  if (a.grad_theta)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * a.B; i += stride) {
+      const float x = a.grad_theta[i * 3], y = a.grad_theta[i * 3 + 1], z = a.grad_theta[i * 3 + 2];
+      const float d = sqrtf(x * x + y * y + z * z) - 1.0f;
+      s[S_EIK] += d * d;
+    }
+  if (a.surface)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_pc; i += stride) s[S_BUBBLE] += fabsf(a.surface[i]);
+  __shared__ float sm[4][S_N];
+#pragma unroll
+  for (int k = 0; k < S_N; ++k) {
+    float v = s[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < S_N) a.partial[blockIdx.x * S_N + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void loss_finalize_kernel(LossArgs a, int nblocks) {
+  __shared__ float tot[S_N];
+  if (threadIdx.x < S_N) {
+    float v = 0.f;
+    for (int b = 0; b < nblocks; ++b) v += a.partial[b * S_N + threadIdx.x];
+    tot[threadIdx.x] = v;
+    a.sums[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float B = (float)a.B;
+    const float rgb = tot[S_RGB] / (3.0f * B);
+    const float eik = a.grad_theta ? tot[S_EIK] / (2.0f * B) : 0.f;
+    const float smooth = (a.diff_norm && a.c.smooth_on && a.c.smooth_w > 0.f) ? tot[S_SMOOTH] / B : 0.f;
+    const float mask = (a.gt_mask && a.c.mask_w > 0.f) ? tot[S_MASK] / B : 0.f;
+    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / tot[S_DEPTH_CNT] : 0.f;
+    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / tot[S_NORMAL_CNT] : 0.f;
+    const float normal = a.c.normal_w > 0.f ? nl1 : 0.f, angular = a.c.angular_w > 0.f ? nl1 : 0.f;
+    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / (float)a.n_pc : 0.f;
+    const float light = (a.lmask && a.gt_lmask && a.c.light_w > 0.f) ? tot[S_LIGHT] / B : 0.f;
+    a.losses[0] = rgb + a.c.eikonal_w * eik + a.c.smooth_w * smooth + a.c.mask_w * mask + a.c.depth_w * depth + a.c.normal_w * normal +
+                  a.c.angular_w * angular + a.c.bubble_w * bubble + a.c.light_w * light;
+    a.losses[1] = rgb; a.losses[2] = eik; a.losses[3] = smooth; a.losses[4] = mask; a.losses[5] = depth;
+    a.losses[6] = normal; a.losses[7] = angular; a.losses[8] = bubble; a.losses[9] = light;
+  }
+}
+
+__global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float B = (float)a.B;
+  if (i < a.B) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float d = a.rgb[i * 3 + k] - a.gt_rgb[i * 3 + k];
+      a.g_rgb[i * 3 + k] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (3.0f * B);
+    }
+    float gd = 0.f;
+    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / a.sums[S_DEPTH_CNT];
+    a.g_depth[i] = gd;
+    float gw = 0.f;
+    if (a.gt_mask && a.c.mask_w > 0.f) { float d; (void)bce(a.wsum[i], a.gt_mask[i], d); gw = a.c.mask_w * d / B; }
+    a.g_wsum[i] = gw;
+    if (a.g_normal) {
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+      if (a.gt_normal && a.normal && a.normal_mask[i]) {
+        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / a.sums[S_NORMAL_CNT];
+        const float n0 = a.gt_normal[i * 3], n1 = a.gt_normal[i * 3 + 1], n2 = a.gt_normal[i * 3 + 2];
+        const float u = 1.0f - (a.normal[i * 3] * n0 + a.normal[i * 3 + 1] * n1 + a.normal[i * 3 + 2] * n2);
+        const float sg = u > 0.f ? -1.f : (u < 0.f ? 1.f : 0.f);          // d|1-dot| / d dot
+        g0 = w * sg * n0; g1 = w * sg * n1; g2 = w * sg * n2;
+      }
+      a.g_normal[i * 3] = g0; a.g_normal[i * 3 + 1] = g1; a.g_normal[i * 3 + 2] = g2;
+    }
+    if (a.g_diff_norm) a.g_diff_norm[i] = (a.c.smooth_on && a.c.smooth_w > 0.f) ? a.c.smooth_w / B : 0.f;
+    if (a.g_lmask) {
+      float gl = 0.f;
+      if (a.lmask && a.gt_lmask && a.c.light_w > 0.f) { float d; (void)bce(a.lmask[i], a.gt_lmask[i], d); gl = a.c.light_w * d / B; }
+      a.g_lmask[i] = gl;
+    }
+  }
+  if (a.g_grad_theta && i < 2 * a.B) {
+    const float x = a.grad_theta[i * 3], y = a.grad_theta[i * 3 + 1], z = a.grad_theta[i * 3 + 2];
+    const float nrm = sqrtf(x * x + y * y + z * z);
+    const float f = nrm > 0.f ? a.c.eikonal_w * 2.0f * (nrm - 1.0f) / (nrm * 2.0f * B) : 0.f;
+    a.g_grad_theta[i * 3] = f * x; a.g_grad_theta[i * 3 + 1] = f * y; a.g_grad_theta[i * 3 + 2] = f * z;
+  }
+  if (a.g_surface && i < a.n_pc) {
+    const float sv = a.surface[i];
+    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / (float)a.n_pc : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N; }
+
+extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_pc, const float* rgb, const float* depth,
+                                           const float* wsum, const float* normal, const float* grad_theta, const float* diff_norm,
+                                           const float* surface, const float* lmask, const float* gt_rgb, const float* gt_depth,
+                                           const uint8_t* depth_mask, const float* gt_normal, const uint8_t* normal_mask, const float* gt_mask,
+                                           const float* gt_lmask, float* scratch, float* losses, float* g_rgb, float* g_depth, float* g_wsum,
+                                           float* g_normal, float* g_grad_theta, float* g_diff_norm, float* g_surface, float* g_lmask,
+                                           void* stream) {
+  if (!cfg || B <= 0 || !rgb || !depth || !wsum || !gt_rgb || !scratch || !losses || !g_rgb || !g_depth || !g_wsum) return I2SDF_EINVAL;
+  if ((gt_depth && !depth_mask) || (gt_normal && !normal_mask) || (normal && !g_normal && gt_normal)) return I2SDF_EINVAL;
+  LossArgs a{};
+  a.c = *cfg; a.B = B; a.n_pc = surface ? n_pc : 0;
+  a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.normal = normal; a.grad_theta = grad_theta; a.diff_norm = diff_norm; a.surface = surface;
+  a.lmask = lmask; a.gt_rgb = gt_rgb; a.gt_depth = gt_depth; a.gt_normal = gt_normal; a.gt_mask = gt_mask; a.gt_lmask = gt_lmask;
+  a.depth_mask = depth_mask; a.normal_mask = normal_mask;
+  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.losses = losses;
+  a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_wsum = g_wsum; a.g_normal = g_normal; a.g_grad_theta = g_grad_theta; a.g_diff_norm = g_diff_norm;
+  a.g_surface = g_surface; a.g_lmask = g_lmask;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t work = std::max<int64_t>(2 * B, a.n_pc);
+  const int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (work + 255) / 256);
+  loss_partial_kernel<<<nb, 256, 0, st>>>(a);
+  loss_finalize_kernel<<<1, 64, 0, st>>>(a, nb);
+  loss_grad_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(a);
+  return i2sdf_hip_check(hipGetLastError(), "loss_forward_backward launch");
+}

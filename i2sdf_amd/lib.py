@@ -33,6 +33,11 @@ class SamplerCfg(C.Structure):
                 ("N_samples_extra", C.c_int32), ("beta_iters", C.c_int32), ("max_total_iters", C.c_int32)]
 
 
+class LossCfg(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("eikonal_w", "smooth_w", "mask_w", "depth_w", "normal_w", "angular_w", "bubble_w", "light_w")] + \
+               [("smooth_on", C.c_int32)]
+
+
 class I2SDFError(RuntimeError):
     pass
 
@@ -69,6 +74,8 @@ SIGNATURES = {
                                     _I64, _P, _P, _P]),
     "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "i2sdf_loss_scratch_floats": (_I64, []),
+    "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 26),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
     "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),

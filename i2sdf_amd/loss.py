@@ -8,6 +8,45 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _FusedLossFn(torch.autograd.Function):
+    """value + gradient of the whole loss in three HIP launches (include/i2sdf.h: i2sdf_loss_forward_backward)."""
+
+    @staticmethod
+    def forward(ctx, cfg, n_pc, gt, rgb, depth, wsum, normal, grad_theta, diff_norm, surface, lmask):
+        from . import lib as L
+        lib = L.load()
+        dev = rgb.device
+        B = rgb.shape[0]
+        c = lambda t: None if t is None else t.detach().contiguous()
+        f32 = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        ins = [c(rgb), c(depth), c(wsum), c(normal), c(grad_theta), c(diff_norm), c(surface), c(lmask)]
+        gts = [f32(gt.get("rgb")).reshape(-1, 3), f32(gt.get("depth")), c(gt.get("depth_mask")), f32(gt.get("normal")), c(gt.get("normal_mask")),
+               f32(gt.get("mask")), f32(gt.get("light_mask"))]
+        if gts[1] is None:
+            gts[2] = None
+        if gts[3] is None:
+            gts[4] = None
+        for m in (2, 4):
+            if gts[m] is not None:
+                assert gts[m].dtype == torch.bool or gts[m].dtype == torch.uint8
+        grads = [torch.empty_like(t) if t is not None else None for t in ins]
+        losses = torch.empty(10, dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(lib.i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(lib.i2sdf_loss_forward_backward(cfg, B, n_pc, *[L.ptr(t) for t in ins], L.ptr(gts[0]), L.ptr(gts[1]), L.ptr(gts[2]),
+                                                    L.ptr(gts[3]), L.ptr(gts[4]), L.ptr(gts[5]), L.ptr(gts[6]), L.ptr(scratch), L.ptr(losses),
+                                                    *[L.ptr(g) for g in grads], L.stream_ptr()), "i2sdf_loss_forward_backward")
+        ctx.grads = grads
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        scale = g[0]            # only `loss` (entry 0) is differentiable; the itemised entries are reported values
+        out = [None, None, None] + [(gr * scale if gr is not None else None) for gr in ctx.grads]
+        ctx.grads = None
+        return tuple(out)
+
+
 class I2SDFLoss(nn.Module):
     def __init__(self, eikonal_weight=0.1, smooth_weight=0.0, mask_weight=0.0, depth_weight=0.1, normal_weight=0.05, angular_weight=0.05,
                  bubble_weight=0.0, min_bubble_iter=0, max_bubble_iter=None, smooth_iter=None, light_mask_weight=0.0,
@@ -20,15 +59,52 @@ class I2SDFLoss(nn.Module):
         if self.bubble_weight > 0 and self.max_bubble_iter is not None and self.smooth_iter < self.max_bubble_iter:
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
+        self.fused = True          # CUDA inputs: one fused HIP forward+gradient call instead of ~100 element-wise torch kernels
 
+    # The reference indexes with boolean masks (`depth[depth_mask]`, `normal[normal_mask]`, :320-329), which costs a
+    # device->host synchronisation per call (the result size is data dependent).  The masked means below are the same
+    # numbers -- sum over selected rows / number of selected rows -- without the sync, and capturable in a hipGraph.
     @staticmethod
-    def _normal_l1(normal, normal_gt, mask):
-        m = mask.flatten()
-        return torch.abs(1 - torch.sum(normal[m] * normal_gt.reshape(-1, 3)[m], dim=-1)).mean()
+    def _masked_mean(values, mask):
+        m = mask.flatten().to(values.dtype)
+        return (values * m).sum() / m.sum()
+
+    @classmethod
+    def _normal_l1(cls, normal, normal_gt, mask):
+        return cls._masked_mean(torch.abs(1 - torch.sum(normal * normal_gt.reshape(-1, 3), dim=-1)), mask)
+
+    def _forward_fused(self, out, gt, current_step):
+        from . import lib as L
+        smooth_on = self.smooth_iter is None or current_step > self.smooth_iter
+        cfg = L.LossCfg(eikonal_w=self.eikonal_weight, smooth_w=self.smooth_weight, mask_w=self.mask_weight, depth_w=self.depth_weight,
+                        normal_w=self.normal_weight, angular_w=self.angular_weight, bubble_w=self.bubble_weight,
+                        light_w=self.light_mask_weight, smooth_on=1 if smooth_on else 0)
+        surf = out.get("surface_sdf")
+        gtc = dict(gt)
+        if not ("depth" in gt and self.depth_weight > 0):
+            gtc.pop("depth", None)
+        if not ("normal" in gt and (self.normal_weight > 0 or self.angular_weight > 0) and "normal_values" in out):
+            gtc.pop("normal", None)
+        if not ("mask" in gt and self.mask_weight > 0):
+            gtc.pop("mask", None)
+        if not ("light_mask" in out and self.light_mask_weight > 0 and "light_mask" in gt):
+            gtc.pop("light_mask", None)
+        import ctypes as C
+        vec = _FusedLossFn.apply(C.byref(cfg), 0 if surf is None else surf.shape[0], gtc, out["rgb_values"], out["depth_values"],
+                                 out["weight_sum"].reshape(-1), out.get("normal_values"), out.get("grad_theta"), out.get("diff_norm"),
+                                 None if surf is None else surf.reshape(-1),
+                                 out["light_mask"].reshape(-1) if "light_mask" in out else None)
+        names = ["loss", "rgb_loss", "eikonal_loss", "smooth_loss", "mask_loss", "depth_loss", "normal_loss", "angular_loss", "bubble_loss",
+                 "light_mask_loss"]
+        res = {n: vec[i].detach() for i, n in enumerate(names)}
+        res["loss"] = vec[0]
+        return res
 
     def forward(self, out, gt, current_step):
+        if self.fused and out["rgb_values"].is_cuda and out["rgb_values"].dtype == torch.float32:
+            return self._forward_fused(out, gt, current_step)
         dev = out["rgb_values"].device
-        zero = lambda: torch.tensor(0.0, device=dev).float()
+        zero = lambda: torch.zeros((), device=dev, dtype=torch.float32)       # no host->device copy (graph-capturable)
         rgb_loss = F.l1_loss(out["rgb_values"], gt["rgb"].reshape(-1, 3))
         eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean() if "grad_theta" in out else zero()
         smooth_on = self.smooth_iter is None or current_step > self.smooth_iter
@@ -38,8 +114,7 @@ class I2SDFLoss(nn.Module):
         else:
             mask = zero()
         if "depth" in gt and self.depth_weight > 0:
-            dm = gt["depth_mask"].flatten()
-            depth = F.mse_loss(out["depth_values"][dm], gt["depth"].flatten()[dm])
+            depth = self._masked_mean((out["depth_values"] - gt["depth"].flatten()) ** 2, gt["depth_mask"])
         else:
             depth = zero()
         normal = self._normal_l1(out["normal_values"], gt["normal"], gt["normal_mask"]) if ("normal" in gt and self.normal_weight > 0) else zero()

@@ -244,6 +244,30 @@ int i2sdf_light_forward(const i2sdf_plan* plan, const float* packed, const float
 int i2sdf_light_backward(const i2sdf_plan* plan, const float* packed, const float* lm, const float* lm_bar, const float* hl, int64_t M,
                          int64_t Mp, float* gal0, float* gal_last, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * I2SDFLoss -- model/network/__init__.py:289-406 -- value AND gradient w.r.t. every render output in one call
+ * (SURVEY.md "next" row N1).  Per-ray tensors as returned by the module: rgb (B,3), depth (B), wsum (B),
+ * normal (B,3)|NULL, grad_theta (2B,3)|NULL, diff_norm (B)|NULL, surface (n_pc)|NULL, lmask (B)|NULL; ground truth
+ * gt_rgb (B,3), gt_depth (B)+depth_mask (B bytes)|NULL, gt_normal (B,3)+normal_mask|NULL, gt_mask (B)|NULL,
+ * gt_lmask (B)|NULL.  `smooth_on` = the reference's `smooth_iter is None or step > smooth_iter` (:347).
+ *   -> losses[10] = {loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask} (device),
+ *      g_* = d loss / d (same-named input); scratch: i2sdf_loss_scratch_floats() floats.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_loss_cfg {
+  float eikonal_w, smooth_w, mask_w, depth_w, normal_w, angular_w, bubble_w, light_w;
+  int32_t smooth_on;
+} i2sdf_loss_cfg;
+
+int64_t i2sdf_loss_scratch_floats(void);
+int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_pc, const float* rgb, const float* depth,
+                                const float* wsum, const float* normal, const float* grad_theta, const float* diff_norm,
+                                const float* surface, const float* lmask, const float* gt_rgb, const float* gt_depth,
+                                const uint8_t* depth_mask, const float* gt_normal, const uint8_t* normal_mask, const float* gt_mask,
+                                const float* gt_lmask, float* scratch, float* losses, float* g_rgb, float* g_depth, float* g_wsum,
+                                float* g_normal, float* g_grad_theta, float* g_diff_norm, float* g_surface, float* g_lmask,
+                                void* stream);
+
 #ifdef __cplusplus
 }
 #endif
