@@ -29,6 +29,8 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU")
     ap.add_argument("--sampler-iters", type=int, default=2, help="fixed sampler iterations k (0 = data dependent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-rays", type=int, default=64)
     ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
@@ -60,12 +62,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev_index = 0 if (world == 1 or args.share_gpu) else local_rank
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(args.backend)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from i2sdf_amd import I2SDFNetwork, I2SDFLoss, NetConfig, synthetic_conf
@@ -170,7 +176,7 @@ def main():
                        "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce)"},
             "rays_per_s": round(B * world / (dt / args.steps), 1),
             "step_tflops": round(total_flops * world / (dt / args.steps) / 1e12, 2),
-            "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / args.steps) / 1e12 / PEAK, 4),
+            "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / args.steps) / 1e12 / PEAK, 4),   # per GPU (weak scaling)
             "final_loss": float(loss.item()),
             "roofline": roof, "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }
