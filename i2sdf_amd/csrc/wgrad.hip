@@ -24,20 +24,26 @@ struct WgTask {
 };
 struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t pad; int64_t chunk_stride; float* partials; };
 
+// AM = 0: A tile 128 wide (16 B per lane, rows 4i+ta)      AM = 1: A narrower than 32 columns (4 B per lane, row i)
+// BM = 0: B tile 128 wide (16 B per lane, cols 4j+tb)      BM = 1 / 2: B at most 32 / 64 columns wide (4 B per lane, col j + 32 tb)
+template <int AM, int BM>
 __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.y;
   const WgTask& t = L.t[tile];
   const int64_t chunk = blockIdx.x;
   const int i32 = lane & 31, hi = lane >> 5;
-  f32x16 acc[4][4];
+  f32x16 acc[TA][TB];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TA; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  float bsum[TA];
+#pragma unroll
+  for (int a = 0; a < TA; ++a) bsum[a] = 0.f;
   for (int jb = 0; jb < t.njobs; ++jb) {
     const WgJob job = t.j[jb];
     const int64_t m_lo = chunk * WG_CH;
@@ -45,41 +51,62 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
     if (m_hi <= m_lo) continue;
     const int npairs = (int)((m_hi - m_lo + 1) / 2);
     // Buffer loads with hardware range checking: rows >= m_hi and columns >= the operand width read as 0, so the
-    // loop body has no branches and the loads stay PFW pairs ahead of the MFMAs (a select around a load makes hipcc
-    // branch and drain vmcnt every iteration).
+    // loop body has no branches and the loads stay a whole group of pairs ahead of the MFMAs.
     const int rows = (int)(m_hi - m_lo);
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A + m_lo * job.lda), 0,
                                                                       rows * job.lda * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.B + m_lo * job.ldb), 0,
                                                                       rows * job.ldb * 4, 0x00020000);
     const unsigned OOB = 0x7fffffffu;
-    const unsigned a_off = (4 * i32 < job.a_w) ? (unsigned)((hi * job.lda + 4 * i32) * 4) : OOB;
-    const unsigned b_off = (4 * i32 < job.b_w) ? (unsigned)((hi * job.ldb + 4 * i32) * 4) : OOB;
+    const int a_col = AM ? i32 : 4 * i32;
+    const unsigned a_off = (a_col < job.a_w) ? (unsigned)((hi * job.lda + a_col) * 4) : OOB;
+    unsigned b_off[BM ? BM : 1];
+    if (BM) {
+#pragma unroll
+      for (int tb = 0; tb < (BM ? BM : 1); ++tb) b_off[tb] = (i32 + 32 * tb < job.b_w) ? (unsigned)((hi * job.ldb + i32 + 32 * tb) * 4) : OOB;
+    } else {
+      b_off[0] = (4 * i32 < job.b_w) ? (unsigned)((hi * job.ldb + 4 * i32) * 4) : OOB;
+    }
     const unsigned a_step = 2u * job.lda * 4u, b_step = 2u * job.ldb * 4u;
     const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;           // branch-free optional ReLU on the B operand
     const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;       // branch-free optional column sums of A
-    // Group double buffering: while the 16*PFW MFMAs of one group of point pairs run, the loads of the NEXT group are
-    // already in flight (issued at the top of the group, ~6k cycles ahead of their first use).
-    f32x4 a0[PFW], b0[PFW], a1[PFW], b1[PFW];
-    auto load_group = [&](f32x4 (&A)[PFW], f32x4 (&Bv)[PFW], unsigned pbase) {
+    // Group double buffering: while the MFMAs of one group of point pairs run, the loads of the NEXT group are in flight.
+    float a0[PFW][TA], b0[PFW][TB], a1[PFW][TA], b1[PFW][TB];
+    auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned add) -> float {
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off == OOB ? OOB : off + add, 0, 0));
+    };
+    auto load_group = [&](float (&A)[PFW][TA], float (&Bv)[PFW][TB], unsigned pbase) {
 #pragma unroll
       for (int u = 0; u < PFW; ++u) {
         const unsigned pn = pbase + u;
-        A[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off == OOB ? OOB : a_off + pn * a_step, 0, 0));
-        Bv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off == OOB ? OOB : b_off + pn * b_step, 0, 0));
+        if (AM) A[u][0] = ldw(ra, a_off, pn * a_step);
+        else {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off == OOB ? OOB : a_off + pn * a_step, 0, 0));
+#pragma unroll
+          for (int q = 0; q < TA; ++q) A[u][q] = x[q];
+        }
+        if (BM) {
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) Bv[u][tb] = ldw(rb, b_off[tb < (BM ? BM : 1) ? tb : 0], pn * b_step);
+        } else {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[0] == OOB ? OOB : b_off[0] + pn * b_step, 0, 0));
+#pragma unroll
+          for (int q = 0; q < TB; ++q) Bv[u][q] = x[q];
+        }
       }
     };
-    auto compute_group = [&](const f32x4 (&A)[PFW], const f32x4 (&Bv)[PFW]) {
+    auto compute_group = [&](const float (&A)[PFW][TA], const float (&Bv)[PFW][TB]) {
 #pragma unroll
       for (int u = 0; u < PFW; ++u) {
-        const f32x4 a = A[u];
-        f32x4 b = Bv[u];
-        b.x = fmaxf(b.x, relu_lo); b.y = fmaxf(b.y, relu_lo); b.z = fmaxf(b.z, relu_lo); b.w = fmaxf(b.w, relu_lo);
-        bsum.x = fmaf(a.x, bias_w, bsum.x); bsum.y = fmaf(a.y, bias_w, bsum.y); bsum.z = fmaf(a.z, bias_w, bsum.z); bsum.w = fmaf(a.w, bias_w, bsum.w);
+        float bq[TB];
 #pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
+        for (int tb = 0; tb < TB; ++tb) bq[tb] = fmaxf(Bv[u][tb], relu_lo);
 #pragma unroll
-          for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = mfma(a[ta], b[tb], acc[ta][tb]);
+        for (int ta = 0; ta < TA; ++ta) bsum[ta] = fmaf(A[u][ta], bias_w, bsum[ta]);
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) acc[ta][tb] = mfma(A[u][ta], bq[tb], acc[ta][tb]);
       }
     };
     load_group(a0, b0, 0);
@@ -96,20 +123,29 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
   }
   float* out = L.partials + chunk * L.chunk_stride;
 #pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
+  for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int n = 4 * ((r & 3) + 8 * (r >> 2) + 4 * hi) + ta;
-      if (n < t.rows_store && 4 * i32 < t.cols_store) {
-        const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
-        *reinterpret_cast<f32x4*>(out + t.out_off + (int64_t)n * t.ldo + 4 * i32) = v;
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * hi;
+      const int n = AM ? ri : 4 * ri + ta;
+      if (n < t.rows_store) {
+        if (BM) {
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb)
+            if (i32 + 32 * tb < t.cols_store) out[t.out_off + (int64_t)n * t.ldo + i32 + 32 * tb] = acc[ta][tb][r];
+        } else if (4 * i32 < t.cols_store) {
+          const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+          *reinterpret_cast<f32x4*>(out + t.out_off + (int64_t)n * t.ldo + 4 * i32) = v;
+        }
       }
     }
   if (t.has_bias) {
-    f32x4 tot;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) tot[q] = bsum[q] + __shfl_xor(bsum[q], 32);
-    if (hi == 0 && 4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = tot;
+    for (int ta = 0; ta < TA; ++ta) bsum[ta] += __shfl_xor(bsum[ta], 32);
+    if (hi == 0) {
+      if (AM) { if (i32 < t.rows_store) out[t.bias_off + i32] = bsum[0]; }
+      else if (4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = f32x4{bsum[0], bsum[TA > 1 ? 1 : 0], bsum[TA > 2 ? 2 : 0], bsum[TA > 3 ? 3 : 0]};
+    }
   }
 }
 
@@ -123,9 +159,11 @@ struct WnTab { WnLayer l[3 * I2SDF_MAX_LAYERS]; int32_t n; int32_t n_rows; };
 
 __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float* __restrict__ params, const float* __restrict__ partials,
                                                            int n_chunks, int64_t chunk_stride, float* __restrict__ grad) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (row >= tab.n_rows) return;
+  // one block per weight row; wave w sums chunks w, w+4, ... (4x the memory parallelism of one wave per row)
+  __shared__ float s_dw[4][5 * 64];
+  __shared__ float s_b[4];
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int e = 0;
   while (e + 1 < tab.n && row >= tab.l[e + 1].row0) ++e;
   const WnLayer& y = tab.l[e];
@@ -133,6 +171,25 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
   const int brow = r < y.rsplit ? r : r - y.rsplit + y.rbase;
   const float* v = params + y.off_v + (int64_t)r * y.cols;
   constexpr int MAXC = 5;      // cols <= 320
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) {
+    const int c = lane + 64 * q;
+    float sacc = 0.f;
+    if (c < y.cols) {
+      const int kp = c < y.valid0 ? c : y.split + (c - y.base1);
+      const float* src = partials + y.blk_off + (int64_t)brow * y.ldo + kp;
+      for (int ch = wv; ch < n_chunks; ch += 4) sacc += src[ch * chunk_stride];
+    }
+    s_dw[wv][lane + 64 * q] = sacc;
+  }
+  if (lane == 0) {
+    float b = 0.f;
+    const float* bs = partials + y.bias_blk_off + brow;
+    for (int ch = wv; ch < n_chunks; ch += 4) b += bs[ch * chunk_stride];
+    s_b[wv] = b;
+  }
+  __syncthreads();
+  if (wv != 0) return;
   float dw[MAXC], vv[MAXC];
   float dot = 0.f, nrm2 = 0.f;
 #pragma unroll
@@ -140,11 +197,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
     const int c = lane + 64 * q;
     dw[q] = 0.f; vv[q] = 0.f;
     if (c < y.cols) {
-      const int kp = c < y.valid0 ? c : y.split + (c - y.base1);
-      const float* src = partials + y.blk_off + (int64_t)brow * y.ldo + kp;
-      float s = 0.f;
-      for (int ch = 0; ch < n_chunks; ++ch) s += src[ch * chunk_stride];
-      dw[q] = s * y.mult;
+      dw[q] = (s_dw[0][c] + s_dw[1][c] + s_dw[2][c] + s_dw[3][c]) * y.mult;
       vv[q] = v[c];
       dot = fmaf(dw[q], vv[q], dot);
       nrm2 = fmaf(vv[q], vv[q], nrm2);
@@ -162,10 +215,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
   }
   if (lane == 0) {
     grad[y.off_g + r] = dot / nrm;
-    float b = 0.f;
-    const float* bs = partials + y.bias_blk_off + brow;
-    for (int ch = 0; ch < n_chunks; ++ch) b += bs[ch * chunk_stride];
-    grad[y.off_bias + r] = b;
+    grad[y.off_bias + r] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
   }
 }
 
@@ -293,18 +343,23 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
                  {Mm}, {{tb->hl, H, H}}, {}, 0, false);
   }
   (void)light_first;
-  // longest tiles first (2-job tiles, then wide ones): the tail of the launch is then made of short tiles
-  std::stable_sort(tl.tasks.begin(), tl.tasks.end(), [](const WgTask& x, const WgTask& y) {
-    const int64_t cx = (int64_t)x.njobs * 1000 + x.rows_store + x.cols_store, cy = (int64_t)y.njobs * 1000 + y.rows_store + y.cols_store;
-    return cx > cy;
-  });
-  for (size_t off = 0; off < tl.tasks.size(); off += MAX_TASKS) {
-    WgLaunch L{};
-    L.n = (int32_t)std::min<size_t>(MAX_TASKS, tl.tasks.size() - off);
-    for (int i = 0; i < L.n; ++i) L.t[i] = tl.tasks[off + i];
-    L.chunk_stride = p->wgrad_floats; L.partials = partials;
-    dim3 grid((unsigned)n_chunks, (unsigned)L.n);
-    wgrad_kernel<<<grid, 64, 0, st>>>(L);
+  // group the tiles by operand shape (narrow operands run 4x / 2x fewer MFMAs per point pair), longest first inside a group
+  auto variant = [](const WgTask& x) { return x.j[0].a_w <= 32 ? 1 : (x.j[0].b_w <= 32 ? 2 : (x.j[0].b_w <= 64 ? 3 : 0)); };
+  for (int var = 0; var < 4; ++var) {
+    std::vector<WgTask> sel;
+    for (const WgTask& x : tl.tasks) if (variant(x) == var) sel.push_back(x);
+    std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
+    for (size_t off = 0; off < sel.size(); off += MAX_TASKS) {
+      WgLaunch L{};
+      L.n = (int32_t)std::min<size_t>(MAX_TASKS, sel.size() - off);
+      for (int i = 0; i < L.n; ++i) L.t[i] = sel[off + i];
+      L.chunk_stride = p->wgrad_floats; L.partials = partials;
+      dim3 grid((unsigned)n_chunks, (unsigned)L.n);
+      if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
+      else if (var == 1) wgrad_kernel<1, 0><<<grid, 64, 0, st>>>(L);
+      else if (var == 2) wgrad_kernel<0, 1><<<grid, 64, 0, st>>>(L);
+      else wgrad_kernel<0, 2><<<grid, 64, 0, st>>>(L);
+    }
   }
   WnTab tab{};
   int row0 = 0;
@@ -312,6 +367,6 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   if (Mm > 0 && tb->gar) fill_wn(tab, p->rgb, 1, row0);
   if (has_light) fill_wn(tab, p->light, 2, row0);
   tab.n_rows = row0;
-  wn_backward_kernel<<<cdiv(row0, 4), 256, 0, st>>>(tab, params, partials, n_chunks, p->wgrad_floats, grad_flat);
+  wn_backward_kernel<<<row0, 256, 0, st>>>(tab, params, partials, n_chunks, p->wgrad_floats, grad_flat);
   return i2sdf_hip_check(hipGetLastError(), "weight_grads launch");
 }
