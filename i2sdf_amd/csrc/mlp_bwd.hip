@@ -238,8 +238,8 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
                                   const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M, int64_t Mp,
                                   const float* hs, const float* abars, const float* sbar, const float* fbar, int64_t m_fbar,
                                   const float* nbar, float* gus, float* gpbar, float* gas, float* ga_last4, float* ones4, void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !hs || !abars || !gus || !gpbar || !gas || !ga_last4 || !ones4 || M < 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   if (n_ray_pts < 0 || n_ray_pts > M || (n_ray_pts > 0 && (!cam || !dirs || !z || n_per_ray <= 0)) || (n_ray_pts < M && !points))
     return I2SDF_EINVAL;
@@ -270,8 +270,8 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
 
 extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, const float* rgb, const float* rgb_bar, const float* rs,
                                   int64_t M, int64_t Mp, float* gar, float* ga_last, float* fbar, void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !rgb || !rgb_bar || !rs || !gar || !ga_last || !fbar || M < 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   const i2sdf_mlp_desc& d = p->rgb.d;
   RgbBwdArgs a{};

@@ -78,8 +78,8 @@ int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, c
 
 extern "C" int i2sdf_sdf_forward(const i2sdf_plan* p, const float* packed, const float* points, int64_t M, float* sdf_out,
                                  float* feat_out, int64_t ld_feat, void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !points || M < 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (feat_out && (ld_feat < p->F || ld_feat % 4)) return I2SDF_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (p->sdf.d.multires != 6) return I2SDF_EINVAL;

@@ -192,8 +192,8 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
                                       const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M,
                                       int64_t Mp, float* sdf, float* feat, float* grad, float* hs, float* abars, float* pe_save,
                                       void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || M < 0 || !sdf) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   if (n_ray_pts < 0 || n_ray_pts > M) return I2SDF_EINVAL;
   if (n_ray_pts > 0 && (!cam || !dirs || !z || n_per_ray <= 0)) return I2SDF_EINVAL;
@@ -227,8 +227,8 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
 
 extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const float* dirs, int32_t n_per_ray, const float* feat,
                                  int64_t M, int64_t Mp, float* rgb, float* rs, float* pev_save, void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !dirs || !feat || !rgb || M < 0 || n_per_ray <= 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   const i2sdf_mlp_desc& d = p->rgb.d;
   if (d.multires != 4) return I2SDF_EINVAL;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void light_bwd_kernel(LightArgs a) {
 
 extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, const float* feat, int64_t M, int64_t Mp, float* lm, float* hl,
                                    void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !feat || !lm || M < 0 || p->light.d.n_lin == 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   LightArgs a{};
   const int HL = p->light.d.hidden, F = p->F;
@@ -331,8 +331,8 @@ extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, con
 
 extern "C" int i2sdf_light_backward(const i2sdf_plan* p, const float* packed, const float* lm, const float* lm_bar, const float* hl, int64_t M,
                                     int64_t Mp, float* gal0, float* gal_last, void* stream) {
+  if (M == 0) return I2SDF_OK;                 // empty batch: nothing to validate, nothing to launch
   if (!p || !packed || !lm || !lm_bar || !hl || !gal0 || !gal_last || M < 0 || p->light.d.n_lin == 0) return I2SDF_EINVAL;
-  if (M == 0) return I2SDF_OK;
   if (Mp < M || Mp % PTS_PER_WG) return I2SDF_EINVAL;
   LightArgs a{};
   const int HL = p->light.d.hidden;

@@ -256,9 +256,9 @@ __global__ __launch_bounds__(1024) void beta_reduce_kernel(const float* __restri
 
 extern "C" int i2sdf_ray_setup(const float* uv, const float* pose, const float* intrinsics, int64_t batch, int32_t pixels, float* cam_loc,
                                float* dirs, float* dnorm, void* stream) {
+  if (batch == 0) return I2SDF_OK;
   if (!uv || !pose || !intrinsics || !cam_loc || !dirs || !dnorm || batch < 0 || pixels <= 0) return I2SDF_EINVAL;
   const int64_t N = batch * pixels;
-  if (N == 0) return I2SDF_OK;
   raygen_kernel<<<(unsigned)((N + 255) / 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, N, pixels, cam_loc, dirs, dnorm);
   return i2sdf_hip_check(hipGetLastError(), "ray_setup launch");
 }
@@ -267,10 +267,10 @@ extern "C" int i2sdf_composite_forward(const float* beta_param, float beta_min, 
                                        const float* rgb, const float* grad, const float* lmask, const float* dnorm, int64_t B, int32_t n,
                                        float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* w_save,
                                        float* nsum_save, void* stream) {
+  if (B == 0) return I2SDF_OK;
   if (!beta_param || !z || !sdf || !rgb || !dnorm || !o_rgb || !o_depth || !o_wsum || B < 0 || n <= 0 || n > 64 * MAX_SEG) return I2SDF_EINVAL;
   if (o_normal && !grad) return I2SDF_EINVAL;
   if (o_lmask && !lmask) return I2SDF_EINVAL;
-  if (B == 0) return I2SDF_OK;
   CompArgs a{};
   a.beta_param = beta_param; a.beta_min = beta_min; a.z = z; a.ldz = ldz; a.sdf = sdf; a.rgb = rgb; a.grad = o_normal ? grad : nullptr;
   a.lmask = o_lmask ? lmask : nullptr; a.dnorm = dnorm; a.B = B; a.n = n;
@@ -284,10 +284,10 @@ extern "C" int i2sdf_composite_backward(const float* beta_param, float beta_min,
                                         const float* g_rgb, const float* g_depth, const float* g_wsum, const float* g_normal,
                                         const float* g_lmask, float* sdf_bar, float* rgb_bar, float* grad_bar, float* lmask_bar,
                                         float* beta_partial, float* beta_grad_accum, void* stream) {
+  if (B == 0) return I2SDF_OK;
   if (!beta_param || !z || !sdf || !rgb || !dnorm || !g_rgb || !sdf_bar || !rgb_bar || !beta_partial || B < 0 || n <= 0 || n > 64 * MAX_SEG)
     return I2SDF_EINVAL;
   if (grad_bar && (!grad || !nsum_save)) return I2SDF_EINVAL;
-  if (B == 0) return I2SDF_OK;
   CompArgs a{};
   a.beta_param = beta_param; a.beta_min = beta_min; a.z = z; a.ldz = ldz; a.sdf = sdf; a.rgb = rgb; a.grad = grad; a.dnorm = dnorm;
   a.nsum_save = const_cast<float*>(nsum_save); a.B = B; a.n = n;

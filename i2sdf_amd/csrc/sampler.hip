@@ -444,8 +444,8 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
                                  const float* u_final, int64_t ldu_final, const int32_t* extra_tab, const float* strat_u,
                                  const int32_t* extra_idx, const int32_t* eik_idx, int32_t force_iters, float* workspace, float* z_out,
                                  int64_t ldz, float* z_eik, int32_t* iters_out, void* stream) {
-  if (!p || !packed || !params || !sc || !cam || !dirs || !t_lin || !u_more || !u_final || !workspace || !z_out || B < 0) return I2SDF_EINVAL;
   if (B == 0) return I2SDF_OK;
+  if (!p || !packed || !params || !sc || !cam || !dirs || !t_lin || !u_more || !u_final || !workspace || !z_out || B < 0) return I2SDF_EINVAL;
   if (sc->N_samples_eval > NNEW || sc->N_samples > NNEW || sc->N_samples_eval * sc->max_total_iters > NMAX || sc->max_total_iters > 12)
     return I2SDF_EINVAL;
   if (sc->N_samples + 2 + sc->N_samples_extra > 256 || ldz < sc->N_samples + 2 + sc->N_samples_extra) return I2SDF_EINVAL;

@@ -326,6 +326,33 @@ class I2SDFNetwork(nn.Module):
             return out
 
     # ------------------------------------------------------------------------------------------
+    # "next" rows N3 / N4 of SURVEY.md section 8(f): the callers' chunk loops, kept on the device
+    @torch.no_grad()
+    def render_image(self, input: Dict[str, torch.Tensor], split_n_pixels: int = 12000) -> Dict[str, torch.Tensor]:
+        """Full-image inference: utils.split_input -> self(chunk) -> utils.merge_output (utils/__init__.py:35-84,
+        model/eval/recon.py:161-182) in one call; input['uv'] is (1, P, 2).  Outputs are (P, C) / (P,) in pixel order.
+        Chunks are rendered exactly as the reference renders them (the sampler's convergence test is per chunk)."""
+        uv = input["uv"]
+        assert uv.shape[0] == 1, "eval layout: uv is (1, P, 2)"
+        P = uv.shape[1]
+        outs = []
+        for lo in range(0, P, split_n_pixels):
+            d = dict(input)
+            d["uv"] = uv[:, lo:lo + split_n_pixels].contiguous()
+            outs.append(self(d))
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+
+    @torch.no_grad()
+    def sdf_grid(self, points: torch.Tensor, chunk: int = 1 << 20) -> torch.Tensor:
+        """SDF values of an arbitrary point set in chunks (marching-cubes grids: model/eval/recon.py:46-51,89-90,
+        utils/plots.py:440-489).  Returns (M,)."""
+        out = torch.empty(points.shape[0], dtype=torch.float32, device=points.device)
+        eng = self._engine_for(points.device)
+        for lo in range(0, points.shape[0], chunk):
+            out[lo:lo + chunk] = eng.sdf_forward(points[lo:lo + chunk])[:, 0]
+        return out
+
+    # ------------------------------------------------------------------------------------------
     def _extra_points(self, input, cam, dirs, z_eik, draws):
         """Eikonal / neighbour / bubble points (model/network/__init__.py:175-201)."""
         N, dev, R = cam.shape[0], cam.device, self.scene_bounding_sphere

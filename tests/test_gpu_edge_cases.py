@@ -1,0 +1,86 @@
+"""GPU: ragged / degenerate inputs through the module and the C ABI (sizes that are not multiples of any tile, a single
+ray, an empty point cloud, masked ground truth), plus the N3/N4 helpers (chunked image render, grid SDF evaluation)."""
+import pytest
+import torch
+
+from oracle import i2sdf_oracle as orc
+from helpers import assert_close, camera_inputs, make_gt
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(train, skip=True, light=False):
+    from i2sdf_amd import I2SDFNetwork, plumbing_conf
+    conf = plumbing_conf(skip=skip, light=light)
+    conf["use_normal"] = True
+    ocfg = orc.plumbing_cfg(skip=skip, light=light)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=51), 0.05, seed=52)
+    sd["density.beta"] = torch.tensor(0.05)
+    net = I2SDFNetwork(conf)
+    net.load_state_dict(sd)
+    return net.cuda().train(train), ocfg, sd
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 130])
+def test_tiny_and_ragged_batches_train(B):
+    from i2sdf_amd import I2SDFLoss
+    net, ocfg, sd = _net(True)
+    inp = camera_inputs(B, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=B)
+    gt = make_gt(B)
+    if B > 2:      # an all-false mask gives nan in the reference too (mean over an empty selection)
+        gt["depth_mask"][::2] = False
+        gt["normal_mask"][1::3] = False
+    out = net({k: v.cuda() for k, v in inp.items()})
+    assert out["rgb_values"].shape == (B, 3) and out["grad_theta"].shape == (2 * B, 3) and out["diff_norm"].shape == (B,)
+    loss = I2SDFLoss(eikonal_weight=0.1, depth_weight=0.1, normal_weight=0.05)(out, {k: v.cuda() for k, v in gt.items()}, 0)["loss"]
+    loss.backward()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert torch.isfinite(loss)
+
+
+def test_pointcloud_sizes():
+    net, ocfg, sd = _net(True)
+    B = 17
+    inp = {k: v.cuda() for k, v in camera_inputs(B, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=1).items()}
+    for n_pc in (1, 129):
+        inp["pointcloud"] = (torch.rand(n_pc, 3, device="cuda") * 2 - 1)
+        out = net(inp)
+        assert out["surface_sdf"].shape == (n_pc, 1)
+        ref = orc.sdf_forward(sd, ocfg.sdf, inp["pointcloud"].cpu())[:, :1]
+        assert_close(out["surface_sdf"].detach().cpu(), ref, 2e-5, "surface_sdf")
+        out["surface_sdf"].abs().mean().backward()
+
+
+def test_predict_only_and_no_grad_training_mode():
+    net, ocfg, sd = _net(True, light=True)
+    inp = {k: v.cuda() for k, v in camera_inputs(33, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=2).items()}
+    out = net(inp, predict_only=True)
+    assert set(out) == {"rgb_values", "depth_values", "weight_sum", "light_mask"}
+    with torch.no_grad():
+        out = net(inp)                                        # bubble-PDF initialisation style call (model/trainer/recon.py:194)
+    assert "grad_theta" in out and not out["rgb_values"].requires_grad
+
+
+def test_empty_point_set_is_a_noop():
+    net, _, _ = _net(False)
+    out = net.implicit_network(torch.zeros(0, 3, device="cuda"))
+    assert out.shape == (0, 65)
+
+
+def test_render_image_equals_manual_chunk_loop_and_grid_sdf():
+    net, ocfg, sd = _net(False)
+    P = 700
+    inp = {k: v.cuda() for k, v in camera_inputs(P, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=4, train_layout=False).items()}
+    full = net.render_image(inp, split_n_pixels=256)
+    parts = []
+    with torch.no_grad():
+        for lo in range(0, P, 256):
+            d = dict(inp); d["uv"] = inp["uv"][:, lo:lo + 256].contiguous()
+            parts.append(net(d))
+    for k in full:
+        assert full[k].shape[0] == P
+        assert torch.equal(full[k], torch.cat([p[k] for p in parts], 0)), k
+    pts = (torch.rand(5000, 3) * 2 - 1) * 1.5
+    got = net.sdf_grid(pts.cuda(), chunk=1024)
+    assert_close(got.cpu(), orc.sdf_forward(sd, ocfg.sdf, pts)[:, 0], 2e-5, "sdf_grid")
