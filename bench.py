@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
-    ap.add_argument("--cpu-rays", type=int, default=64)
+    ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
 

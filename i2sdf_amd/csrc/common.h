@@ -200,7 +200,7 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
   for (int s = 0; s < NS; ++s) {
     // tile nt is complete before stage s  <=>  NB + (nt+1)*KC <= s*SC
     // tiles that completed during the previous stage get their epilogue during this stage.  If it is exactly one tile,
-    // its 16 elements are dealt out between the stage's chunks (one element after every other chunk's MFMAs, where the
+    // its 16 elements are dealt out between the stage's first 16 chunks (one element after each chunk's MFMAs, where the
     // 64-cycle MFMA gaps absorb the VALU work); otherwise the epilogues run in front of the MFMAs.
     int pend = -1, npend = 0;
 #pragma unroll
@@ -270,7 +270,9 @@ __device__ __forceinline__ void dense_op_epi(WStream& ws, const float (&in)[KC *
               if (last > s * SC && last <= (s + 1) * SC) epi.prefetch(n2);
             }
           }
-          if ((jj & 1) == 0 && jj / 2 < 16) epi.elem(pend, acc[pend < 0 ? 0 : pend], jj / 2);
+          // one element per chunk during the FIRST half of the stage: its stores are then >= 16 chunks (4k cycles) old when
+          // the next stage's barrier drains vmcnt
+          if (jj < 16) epi.elem(pend, acc[pend < 0 ? 0 : pend], jj);
           // per-chunk scheduling region: {MFMA, ds_read, 3 MFMA} then this chunk's share of the epilogue
           I2SDF_SGB(I2SDF_MASK_MFMA, 1);
           if (j + PF < j1) I2SDF_SGB(I2SDF_MASK_DSREAD, 1);
