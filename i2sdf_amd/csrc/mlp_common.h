@@ -9,17 +9,28 @@ namespace i2sdf {
 
 // launch a 256-thread kernel with the double-buffered weight stage in dynamic LDS (> 64 KB needs the attribute once)
 template <class K, class... A>
-inline void launch_lds(K kern, unsigned grid, hipStream_t st, A... args) {
+inline void launch_lds_bytes(int lds_bytes, K kern, unsigned grid, hipStream_t st, A... args) {
   static std::mutex mu;
   static std::unordered_set<const void*> done;
   {
     std::lock_guard<std::mutex> lk(mu);
     if (!done.count((const void*)kern)) {
-      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
       done.insert((const void*)kern);
     }
   }
-  kern<<<grid, 256, LDS_BYTES, st>>>(args...);
+  kern<<<grid, 256, lds_bytes, st>>>(args...);
+}
+template <class K, class... A>
+inline void launch_lds(K kern, unsigned grid, hipStream_t st, A... args) { launch_lds_bytes(LDS_BYTES, kern, grid, st, args...); }
+
+// Split of a launch over M points into full rounds of 128-point workgroups (one per CU) and a short tail that is run by
+// the split-K kernels (ksplit.h): returns the number of points of the bulk part (0 = no split).
+inline int64_t split_bulk_points(int64_t M, int n_cu = 256) {
+  const int64_t n_wg = (M + PTS_PER_WG - 1) / PTS_PER_WG;
+  const int64_t full = (n_wg / n_cu) * n_cu, rem = n_wg - full;
+  if (full == 0 || rem == 0 || rem * 4 > n_cu) return 0;      // nothing to gain, or the tail would not fit one round
+  return full * PTS_PER_WG;
 }
 
 constexpr float RS2 = 0.70710678118654752440f;

@@ -4,7 +4,7 @@
 //                    is evaluated explicitly in the same kernel, in registers.
 //                   Saves h_l = softplus(a_{l-1}) and abar_l = d sdf / d a_l for the backward kernels.
 //   rgb_fwd       : RenderingNetwork.forward, 'nerf' mode (mlp.py:208-229), saves the post-ReLU activations.
-#include "epi.h"
+#include "ksplit.h"
 
 using namespace i2sdf;
 
@@ -185,6 +185,61 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
   }
 }
 
+// Split-K variant for the last partial round (ksplit.h): one 32-point tile per workgroup, points m0 + 32*blockIdx.x ...
+template <int H, int F, int LFV>
+__global__ __launch_bounds__(256) void rgb_fwd_split_kernel(RgbFwdArgs a, int64_t m0) {
+  constexpr int NT = H / 32, KC = H / 8, PECV = PE<LFV>::PEC, FC = F / 8;
+  static_assert(NT == 8 && KC == SC && FC == SC, "split-K kernels are built for 256-wide layers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xlds = lds + 2 * STAGE_FLOATS;
+  float* slds = xlds + KS_X_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5;
+  const int64_t m = m0 + (int64_t)blockIdx.x * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t ray = mc / a.n_per_ray;
+  float in0[(PECV + FC) * 4];
+  {
+    float full[PECV * 8], pv[PECV * 4];
+    pe_full<LFV>(a.dirs[ray * 3 + 0], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2], full);
+    to_b_layout<PECV>(full, pv, hi);
+    if (a.pev_save && w == 0) store_regs<PECV>(a.pev_save + m * (PECV * 8), hi, valid, pv);
+    float ft[FC * 4];
+    load_regs<FC>(a.feat + mc * F, hi, ft);
+#pragma unroll
+    for (int i = 0; i < PECV * 4; ++i) in0[i] = pv[i];
+#pragma unroll
+    for (int i = 0; i < FC * 4; ++i) in0[PECV * 4 + i] = ft[i];
+  }
+  const int64_t lstride = a.Mp * H;
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  float rq[32];
+  {
+    // layer 0 (reduction length 36 chunks: not stage aligned) is computed by every wave; each keeps its quarter
+    f32x16 acc[NT];
+    float r[NT * 16];
+    ReluEpi re{a.rs ? a.rs + m * H : nullptr, hi, valid};
+    re.own = w;
+    dense_op_epi<NT, PECV + FC, NT * 4, 0, 0, ReluEpi>(ws, in0, acc, re, tid);
+    commit_tiles<NT>(acc, r);
+    take_quarter(r, rq, w);
+  }
+  for (int l = 1; l < a.L - 1; ++l) {
+    ReluEpi re{a.rs ? a.rs + l * lstride + m * H : nullptr, hi, valid};
+    float nq[32];
+    dense_op_ksplit<NT, NT * 4, 0, ReluEpi>(ws, rq, nq, nullptr, re, xlds, tid);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) rq[i] = nq[i];
+  }
+  float o[3];
+  rowvec_ksplit<3>(ws, rq, o, slds, tid);
+  if (valid && hi == 0 && w == 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) a.rgb[m * 3 + i] = 1.0f / (1.0f + expf(-o[i]));
+  }
+}
+
 }  // namespace
 
 // =============================================================================================================
@@ -239,7 +294,15 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
-    launch_lds(rgb_fwd_kernel<256, 256, 4>, grid, st, a);
+    const int64_t bulk = split_bulk_points(M);
+    if (bulk > 0) {          // full rounds with one 32-point tile per wave, the partial last round as split-K workgroups
+      RgbFwdArgs b = a;
+      b.M = bulk;
+      launch_lds(rgb_fwd_kernel<256, 256, 4>, (unsigned)(bulk / PTS_PER_WG), st, b);
+      launch_lds_bytes(KS_LDS_BYTES, rgb_fwd_split_kernel<256, 256, 4>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
+    } else {
+      launch_lds(rgb_fwd_kernel<256, 256, 4>, grid, st, a);
+    }
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_fwd = rgb_fwd_stages(64, 64, PE<4>::PEC, d.n_lin);
     launch_lds(rgb_fwd_kernel<64, 64, 4>, grid, st, a);

@@ -103,3 +103,30 @@ def test_rgb_forward_golden(golden):
     featp[:M] = t(z["feat"])
     rgb, _, _ = eng.rgb_forward(t(z["dirs"]).cuda(), 1, featp.cuda(), M)
     assert_close(rgb.cpu(), z["rgb"], 2e-5, "RenderingNetwork.forward")
+
+
+def test_rgb_forward_split_k_tail():
+    """M = 256 full workgroups + a short tail: the tail runs through the split-K kernel (ksplit.h); both parts vs the oracle."""
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=7), 0.05, seed=8)
+    eng = make_engine(synthetic_conf(False), sd)
+    g = torch.Generator().manual_seed(9)
+    n = 7
+    B = (256 * 128 + 777 + n - 1) // n
+    M = B * n
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1)
+    feat = torch.randn(M, 256, generator=g)
+    Mp = eng.pad_rows(M)
+    featp = torch.zeros(Mp, 256)
+    featp[:M] = feat
+    rgb, rs, pev = eng.rgb_forward(dirs.cuda(), n, featp.cuda(), M)
+    idx = torch.cat([torch.arange(0, 300), torch.arange(256 * 128 - 200, M)])          # some bulk points + the whole tail
+    ref = orc.rgb_forward(dbl(sd), ocfg.rgb, dirs.double()[idx // n], feat.double()[idx])
+    assert_close(rgb.cpu()[idx], ref, TOL, "rgb (bulk sample + split-K tail)")
+    # saved activations of the tail (consumed by the backward / weight-gradient kernels)
+    x = torch.cat([orc.positional_encode(dirs.double()[idx // n], 4), feat.double()[idx]], -1)
+    W0 = orc.effective_weight(dbl(sd), "rendering_network.lin0")
+    r1 = torch.relu(x @ W0.t() + sd["rendering_network.lin0.bias"].double())
+    assert_close(rs[0].cpu()[idx], r1, TOL, "r_1")
+    assert_close(pev.cpu()[idx][:, :27], orc.positional_encode(dirs.double()[idx // n], 4), 1e-6, "PE(view)")
