@@ -49,10 +49,11 @@ __device__ __forceinline__ void store_quad(float* __restrict__ row, int nt, int 
 // h = softplus100(a) [+ store h]                      (forward, SDF net / light head)
 struct SoftplusEpi {
   float* row; int hi; bool valid;
+  int own = -1;             // >= 0: store only the tiles this wave owns (nt/2 == own); split-K tail kernels
   __device__ __forceinline__ void prefetch(int) {}
   __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
     acc[r] = softplus100(acc[r]);
-    if (row && (r & 3) == 3) store_quad(row, nt, r >> 2, hi, valid, acc);
+    if (row && (r & 3) == 3) store_quad(row, nt, r >> 2, hi, valid && (own < 0 || (nt >> 1) == own), acc);
   }
   I2SDF_APPLY_FROM_ELEM
 };

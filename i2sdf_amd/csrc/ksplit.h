@@ -15,7 +15,9 @@ namespace i2sdf {
 
 constexpr int KS_TILE_FLOATS = 16 * 64;                         // one D-layout tile of one wave
 constexpr int KS_X_FLOATS = 2 * 4 * KS_TILE_FLOATS;             // exchange area: 2 buffers x 4 waves
-constexpr int KS_LDS_BYTES = LDS_BYTES + KS_X_FLOATS * 4 + 4096;
+constexpr int KS_G_FLOATS = 8 * KS_TILE_FLOATS;                 // all-gather area: one full 8-tile vector
+constexpr int KS_S_FLOATS = 1024;                               // small scratch (row-vector sums)
+constexpr int KS_LDS_BYTES = LDS_BYTES + (KS_X_FLOATS + KS_S_FLOATS + KS_G_FLOATS) * 4;
 
 // NT output tiles (tiles >= 8 belong to wave 0 and are returned through `extra`), reduction over exactly SC chunks.
 //   NB = NT*4 (bias stage first, MODE 0 adds it, MODE 1 ignores it) or 0
@@ -85,11 +87,8 @@ __device__ __forceinline__ void dense_op_ksplit(WStream& ws, const float (&inq)[
 #pragma unroll
         for (int r = 0; r < 16; ++r) outq[(nt & 1) * 16 + r] = tot[r];
       } else {
-        if (MODE == 2) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) extra[nt - 8][r] += tot[r];
-        } else {
-          epi.apply(nt, tot);
+        epi.apply(nt, tot);                       // tiles beyond the 8 hidden ones (PE part of the skip layer): wave 0, handled by the epilogue
+        if (extra != nullptr) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) extra[nt - 8][r] = tot[r];
         }
@@ -105,6 +104,61 @@ __device__ __forceinline__ void take_quarter(const float (&full)[128], float (&q
     const float a = (w & 1) ? full[32 + i] : full[i];
     const float b = (w & 1) ? full[96 + i] : full[64 + i];
     q[i] = (w & 2) ? b : a;
+  }
+}
+
+// every wave contributes its quarter (tiles 2w, 2w+1), every wave receives the full 8-tile vector
+__device__ __forceinline__ void gather_full(const float (&q)[32], float (&full)[128], float* glds, int tid) {
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f32x4* dst = reinterpret_cast<f32x4*>(glds + (2 * w + t) * KS_TILE_FLOATS) + lane;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) dst[qq * 64] = f32x4{q[t * 16 + 4 * qq], q[t * 16 + 4 * qq + 1], q[t * 16 + 4 * qq + 2], q[t * 16 + 4 * qq + 3]};
+  }
+  __syncthreads();
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(glds + nt * KS_TILE_FLOATS) + lane;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const f32x4 v = src[qq * 64];
+      full[nt * 16 + 4 * qq] = v.x; full[nt * 16 + 4 * qq + 1] = v.y; full[nt * 16 + 4 * qq + 2] = v.z; full[nt * 16 + 4 * qq + 3] = v.w;
+    }
+  }
+  __syncthreads();
+}
+
+// this wave's quarter of a row vector stored as a rowvec op: regs[i*4+t] = w[8*(8w+i) + 4hi + t]; also the scalar chunk
+__device__ __forceinline__ void rowvec_load_quarter(WStream& ws, float (&wq)[32], f32x4& scalars, int tid) {
+  constexpr int KC = 32, TOT = rowvec_chunks(KC, 1), NS = TOT / SC;
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+    if (s == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 v = cur[(8 * w + i) * 64];
+        wq[i * 4] = v.x; wq[i * 4 + 1] = v.y; wq[i * 4 + 2] = v.z; wq[i * 4 + 3] = v.w;
+      }
+    } else if (s == 1) {
+      scalars = cur[0];
+    }
+  }
+}
+
+// store / load this wave's quarter of a point-major [m][256] row (columns 64w .. 64w+63)
+__device__ __forceinline__ void store_quarter(float* __restrict__ row, int w, int hi, bool valid, const float (&q)[32]) {
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(row + 64 * w + 8 * i + 4 * hi) = f32x4{q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
+}
+__device__ __forceinline__ void load_quarter(const float* __restrict__ row, int w, int hi, float (&q)[32]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + 64 * w + 8 * i + 4 * hi);
+    q[4 * i] = v.x; q[4 * i + 1] = v.y; q[4 * i + 2] = v.z; q[4 * i + 3] = v.w;
   }
 }
 

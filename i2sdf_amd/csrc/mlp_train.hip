@@ -120,6 +120,131 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
   }
 }
 
+// Split-K variant of sdf_train_fwd_kernel for the last partial round (ksplit.h): one 32-point tile per workgroup.
+template <int H, int F, int LF, bool GRAD>
+__global__ __launch_bounds__(256) void sdf_train_fwd_split_kernel(SdfTrainFwdArgs a, int64_t m0) {
+  constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FT = F / 32;
+  static_assert(NT == 8 && KC == SC && FT == 8, "split-K kernels are built for 256-wide layers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xlds = lds + 2 * STAGE_FLOATS;
+  float* slds = xlds + KS_X_FLOATS;
+  float* glds = slds + KS_S_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5;
+  const int64_t m = m0 + (int64_t)blockIdx.x * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  float px, py, pz;
+  fetch_point(a.pts, mc, px, py, pz);
+  float pe[PEC * 4];
+  {
+    float full[PEC * 8];
+    pe_full<LF>(px, py, pz, full);
+    to_b_layout<PEC>(full, pe, hi);
+  }
+  if (a.pe_save && w == 0) store_regs<PEC>(a.pe_save + m * (PEC * 8), hi, valid, pe);
+  const int64_t lstride = a.Mp * H;
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  float hq[32];
+  {
+    f32x16 acc[NT];
+    float h[NT * 16];
+    SoftplusEpi fe{a.hs ? a.hs + m * H : nullptr, hi, valid};
+    fe.own = w;
+    dense_op_epi<NT, PEC, NT * 4, 0, 0, SoftplusEpi>(ws, pe, acc, fe, tid);         // tiny: every wave computes all of layer 0
+    commit_tiles<NT>(acc, h);
+    take_quarter(h, hq, w);
+  }
+  for (int l = 1; l < a.L - 1; ++l) {
+    float* hrow = a.hs ? a.hs + l * lstride + m * H : nullptr;
+    if (l == a.skip) {
+      // 37 chunks per tile: not stage aligned -> gather the full input, every wave computes the layer, keeps its quarter
+      float u[(KC + PEC) * 4];
+      {
+        float h[NT * 16];
+        gather_full(hq, h, glds, tid);
+#pragma unroll
+        for (int i = 0; i < KC * 4; ++i) u[i] = h[i] * RS2;
+      }
+#pragma unroll
+      for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = pe[i] * RS2;
+      f32x16 acc[NT];
+      SoftplusEpi fe{hrow, hi, valid};
+      fe.own = w;
+      dense_op_epi<NT, KC + PEC, NT * 4, 0, 0, SoftplusEpi>(ws, u, acc, fe, tid);
+      float h2[NT * 16];
+      commit_tiles<NT>(acc, h2);
+      take_quarter(h2, hq, w);
+    } else {
+      SoftplusEpi fe{hrow, hi, valid};
+      float nq[32];
+      dense_op_ksplit<NT, NT * 4, 0, SoftplusEpi>(ws, hq, nq, nullptr, fe, xlds, tid);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) hq[i] = nq[i];
+    }
+  }
+  {
+    float s[1];
+    rowvec_ksplit<1>(ws, hq, s, slds, tid);
+    if (valid && hi == 0 && w == 0) a.sdf[m] = s[0];
+  }
+  if (a.feat != nullptr) {
+    StoreEpi se{a.feat + m * F, hi, valid};
+    float dq[32];
+    dense_op_ksplit<FT, FT * 4, 0, StoreEpi>(ws, hq, dq, nullptr, se, xlds, tid);
+  }
+  if (!GRAD) return;
+  // ---------------- reverse chain ----------------
+  __syncthreads();
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float abq[32];
+  {
+    float wq[32];
+    f32x4 sc;
+    rowvec_load_quarter(ws, wq, sc, tid);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) abq[i] = wq[i] * sp_sigma_from_h(hq[i]);
+  }
+  if (a.abars) store_quarter(a.abars + (a.L - 2) * lstride + m * H, w, hi, valid, abq);
+  f32x16 pt[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[i][r] = 0.f;
+  for (int l = a.L - 2; l >= 1; --l) {
+    const float* hrow = a.hs + (l - 1) * lstride + mc * H;
+    float* abrow = a.abars ? a.abars + (l - 1) * lstride + m * H : nullptr;
+    float nq[32];
+    if (l == a.skip) {
+      RevEpi<NT, PT, true> re{hrow, abrow, hi, valid, RS2, pt};
+      dense_op_ksplit<NT + PT, 0, 1, RevEpi<NT, PT, true>>(ws, abq, nq, nullptr, re, xlds, tid);
+    } else {
+      RevEpi<NT, PT, true> re{hrow, abrow, hi, valid, 1.0f, pt};
+      dense_op_ksplit<NT, 0, 1, RevEpi<NT, PT, true>>(ws, abq, nq, nullptr, re, xlds, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) abq[i] = nq[i];
+  }
+  {
+    NoEpi ne;
+    float oq[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) oq[i] = 0.f;
+    dense_op_ksplit<PT, 0, 1, NoEpi>(ws, abq, oq, nullptr, ne, xlds, tid);        // W_0^T abar_0: both tiles land in wave 0
+    if (w == 0) {
+#pragma unroll
+      for (int i = 0; i < PT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pt[i][r] += oq[i * 16 + r];
+      float full[PEC * 8], coef[PEC * 8], n[3];
+      pe_full<LF>(px, py, pz, full);
+      pe_coef<LF>(full, coef);
+      pe_jt_apply<LF, PT>(coef, pt, hi, n);
+      if (valid && hi == 0) { a.grad[m * 3 + 0] = n[0]; a.grad[m * 3 + 1] = n[1]; a.grad[m * 3 + 2] = n[2]; }
+    }
+  }
+}
+
 }  // namespace
 
 // ---- radiance network ---------------------------------------------------------------------------------------
@@ -266,15 +391,27 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   const bool has_skip = d.skip_layer > 0;
-#define LAUNCH(HH, FF)                                                                               \
+#define LAUNCH(HH, FF, G_)                                                                           \
   do {                                                                                               \
     a.n_fwd = sdf_fwd_stages(HH, FF, PE<6>::PEC, d.n_lin, has_skip, feat != nullptr);                \
     a.n_rev = sdf_rev_stages(HH, PE<6>::PEC, d.n_lin, has_skip);                                     \
-    if (grad) launch_lds(sdf_train_fwd_kernel<HH, FF, 6, true>, grid, st, a);                \
-    else launch_lds(sdf_train_fwd_kernel<HH, FF, 6, false>, grid, st, a);                    \
+    if (grad) launch_lds(sdf_train_fwd_kernel<HH, FF, 6, true>, G_, st, a);                          \
+    else launch_lds(sdf_train_fwd_kernel<HH, FF, 6, false>, G_, st, a);                              \
   } while (0)
-  if (p->H == 256 && p->F == 256) LAUNCH(256, 256);
-  else if (p->H == 64 && p->F == 64) LAUNCH(64, 64);
+  if (p->H == 256 && p->F == 256) {
+    const int64_t bulk = split_bulk_points(M);
+    if (bulk > 0 && feat != nullptr) {      // full rounds + the partial last round as split-K workgroups (ksplit.h)
+      const int64_t M_all = a.M;
+      a.M = bulk;
+      LAUNCH(256, 256, (unsigned)(bulk / PTS_PER_WG));
+      a.M = M_all;
+      const unsigned tg = (unsigned)((M_all - bulk + 31) / 32);
+      if (grad) launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, true>, tg, st, a, bulk);
+      else launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, false>, tg, st, a, bulk);
+    } else {
+      LAUNCH(256, 256, grid);
+    }
+  } else if (p->H == 64 && p->F == 64) LAUNCH(64, 64, grid);
   else return I2SDF_EINVAL;
 #undef LAUNCH
   return i2sdf_hip_check(hipGetLastError(), "sdf_forward_grad launch");

@@ -130,3 +130,28 @@ def test_rgb_forward_split_k_tail():
     r1 = torch.relu(x @ W0.t() + sd["rendering_network.lin0.bias"].double())
     assert_close(rs[0].cpu()[idx], r1, TOL, "r_1")
     assert_close(pev.cpu()[idx][:, :27], orc.positional_encode(dirs.double()[idx // n], 4), 1e-6, "PE(view)")
+
+
+@pytest.mark.parametrize("light", [False, True])
+def test_sdf_forward_grad_split_k_tail(light):
+    """256 full workgroups + a short tail (split-K workgroups): sdf, feature, d sdf/dx and every saved tensor of the tail."""
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(light)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=5), 0.05, seed=6)
+    eng = make_engine(synthetic_conf(light), sd)
+    g = torch.Generator().manual_seed(11)
+    M = 256 * 128 + 601
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.0
+    out = eng.sdf_forward_grad(points=x.cuda())
+    idx = torch.cat([torch.arange(0, 200), torch.arange(256 * 128 - 100, M)])
+    fw = orc.sdf_analytic_forward(dbl(sd), ocfg.sdf, x.double()[idx])
+    L = ocfg.sdf.n_lin
+    assert_close(out["sdf"].cpu()[idx], fw["sdf"], TOL, "sdf")
+    assert_close(out["feat"].cpu()[idx], fw["feat"], TOL, "feature")
+    assert_close(out["grad"].cpu()[idx], fw["n"], TOL, "d sdf/dx")
+    assert_close(out["pe"].cpu()[idx][:, :39], fw["p"], 1e-6, "PE")
+    for l in range(L - 1):
+        ref_h = orc.softplus100(fw["a"][l])
+        wd = ref_h.shape[1]
+        assert_close(out["hs"][l].cpu()[idx][:, :wd], ref_h, TOL, f"h_{l+1}")
+        assert_close(out["abars"][l].cpu()[idx][:, :wd], fw["abar"][l], TOL, f"abar_{l}")
