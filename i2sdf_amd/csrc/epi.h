@@ -103,6 +103,7 @@ struct RevEpi {
 template <bool PRE>
 struct Sweep1Epi {
   const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
+  int own = -1;             // >= 0: store only the tiles this wave owns (split-K tail kernels, redundantly computed ops)
   float hb[2][16], ab[2][16];
   float g2[16];
   __device__ __forceinline__ void prefetch(int nt) {
@@ -114,7 +115,10 @@ struct Sweep1Epi {
     const float sg = sp_sigma_from_h(hb[nt & 1][r]);
     acc[r] = ga * sg;
     g2[r] = ga * ab[nt & 1][r] * (100.f * (1.0f - sg));
-    if ((r & 3) == 3) { store_quad(g2row, nt, r >> 2, hi, valid, g2); store_quad(gurow, nt, r >> 2, hi, valid, acc); }
+    if ((r & 3) == 3) {
+      const bool v = valid && (own < 0 || (nt >> 1) == own);
+      store_quad(g2row, nt, r >> 2, hi, v, g2); store_quad(gurow, nt, r >> 2, hi, v, acc);
+    }
   }
   I2SDF_APPLY_FROM_ELEM
 };
@@ -148,6 +152,23 @@ struct Sweep2TopEpi {
   __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
     if (!PRE && r == 0) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
     acc[r] = fmaf(fmaf(sb, wv[nt * 16 + r], acc[r]), sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
+    if ((r & 3) == 3) store_quad(grow, nt, r >> 2, hi, valid, acc);
+  }
+  I2SDF_APPLY_FROM_ELEM
+};
+
+// the same for the split-K kernels: the owner wave holds only its quarter of w_sdf (local index (nt&1)*16 + r)
+template <bool PRE>
+struct Sweep2TopEpiQ {
+  const float* hrow; const float* g2row; float* grow; int hi; bool valid; float sb;
+  const float (&wq)[32];
+  float hb[2][16], gb[2][16];
+  __device__ __forceinline__ void prefetch(int nt) {
+    if (PRE) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
+  }
+  __device__ __forceinline__ void elem(int nt, f32x16& acc, int r) {
+    if (!PRE && r == 0) { load_tile16(hrow, nt, hi, hb[nt & 1]); load_tile16(g2row, nt, hi, gb[nt & 1]); }
+    acc[r] = fmaf(fmaf(sb, wq[(nt & 1) * 16 + r], acc[r]), sp_sigma_from_h(hb[nt & 1][r]), gb[nt & 1][r]);
     if ((r & 3) == 3) store_quad(grow, nt, r >> 2, hi, valid, acc);
   }
   I2SDF_APPLY_FROM_ELEM

@@ -5,7 +5,7 @@
 //             sweep 2 (ordinary backward, top-down, transposed weights).  Emits per layer the operands of the
 //             weight-gradient GEMMs (G(ubar_l), G(a_l)); the GEMMs themselves run in wgrad.hip.
 //   rgb_bwd : first-order backward of the radiance net; emits G(a_l) and the feature gradient fbar.
-#include "epi.h"
+#include "ksplit.h"
 
 using namespace i2sdf;
 
@@ -139,6 +139,111 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
   }
 }
 
+// Split-K variant of sdf_bwd_kernel for the last partial round (ksplit.h): one 32-point tile per workgroup.
+template <int H, int F, int LF>
+__global__ __launch_bounds__(256) void sdf_bwd_split_kernel(SdfBwdArgs a, int64_t m0) {
+  constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FC = F / 8;
+  static_assert(NT == 8 && KC == SC && FC == SC, "split-K kernels are built for 256-wide layers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xlds = lds + 2 * STAGE_FLOATS;
+  float* slds = xlds + KS_X_FLOATS;
+  float* glds = slds + KS_S_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5;
+  const int64_t m = m0 + (int64_t)blockIdx.x * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float gp[PEC * 4];
+  {
+    float px, py, pz, full[PEC * 8], coef[PEC * 8], nb[3] = {0.f, 0.f, 0.f};
+    fetch_point(a.pts, mc, px, py, pz);
+    pe_full<LF>(px, py, pz, full);
+    pe_coef<LF>(full, coef);
+    if (a.nbar) { nb[0] = a.nbar[mc * 3 + 0]; nb[1] = a.nbar[mc * 3 + 1]; nb[2] = a.nbar[mc * 3 + 2]; }
+    pe_j_apply<LF>(coef, nb, hi, gp);
+    if (w == 0) store_regs<PEC>(a.gpbar + m * (PEC * 8), hi, valid, gp);
+  }
+  WStream ws;
+  // ------------------------------ sweep 1 ------------------------------
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  float ghq[32];
+  for (int l = 0; l < a.L - 1; ++l) {
+    const float* hrow = a.hs + l * lstride + mc * H;
+    const float* arow = a.abars + l * lstride + mc * H;
+    float* g2row = a.gas + l * lstride + m * H;
+    float* gurow = a.gus + (l + 1) * lstride + m * H;
+    if (l == 0 || l == a.skip) {
+      // reduction length 5 / 37 chunks: not stage aligned -> every wave computes the layer (stores masked to its own tiles)
+      f32x16 acc[NT];
+      Sweep1Epi<false> e{hrow, arow, g2row, gurow, hi, valid};
+      e.own = w;
+      if (l == 0) {
+        dense_op_epi<NT, PEC, NT * 4, 1, 0, Sweep1Epi<false>>(ws, gp, acc, e, tid);
+      } else {
+        float u[(KC + PEC) * 4];
+        {
+          float gh[NT * 16];
+          gather_full(ghq, gh, glds, tid);
+#pragma unroll
+          for (int i = 0; i < KC * 4; ++i) u[i] = gh[i] * RS2;
+        }
+#pragma unroll
+        for (int i = 0; i < PEC * 4; ++i) u[KC * 4 + i] = gp[i] * RS2;
+        dense_op_epi<NT, KC + PEC, NT * 4, 1, 0, Sweep1Epi<false>>(ws, u, acc, e, tid);
+      }
+      float gh2[NT * 16];
+      commit_tiles<NT>(acc, gh2);
+      take_quarter(gh2, ghq, w);
+    } else {
+      Sweep1Epi<true> e{hrow, arow, g2row, gurow, hi, valid};
+      float nq[32];
+      dense_op_ksplit<NT, NT * 4, 1, Sweep1Epi<true>>(ws, ghq, nq, nullptr, e, xlds, tid);
+#pragma unroll
+      for (int i = 0; i < 32; ++i) ghq[i] = nq[i];
+    }
+  }
+  // ------------------------------ sweep 2 ------------------------------
+  __syncthreads();
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float gaq[32];
+  {
+    float wq[32];
+    f32x4 sc;
+    rowvec_load_quarter(ws, wq, sc, tid);
+    float fbq[32];
+    const bool hasf = a.fbar != nullptr && mc < a.m_fbar;
+    if (hasf) load_quarter(a.fbar + mc * F, w, hi, fbq);
+    else {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) fbq[i] = 0.f;
+    }
+    const float sb = a.sbar ? a.sbar[mc] : 0.f;
+    if (valid && hi == 0 && w == 0) {
+      *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(a.ones4 + m * 4) = f32x4{1.f, 0.f, 0.f, 0.f};
+    }
+    const int lt = a.L - 2;
+    Sweep2TopEpiQ<true> te{a.hs + lt * lstride + mc * H, a.gas + lt * lstride + mc * H, a.gas + lt * lstride + m * H, hi, valid, sb, wq};
+    dense_op_ksplit<NT, 0, 1, Sweep2TopEpiQ<true>>(ws, fbq, gaq, nullptr, te, xlds, tid);
+    ws.skip(rowvec_chunks(KC, 1) / SC, tid);
+  }
+  for (int l = a.L - 2; l >= 1; --l) {
+    const float* hrow = a.hs + (l - 1) * lstride + mc * H;
+    const float* g2row = a.gas + (l - 1) * lstride + mc * H;
+    float* grow = a.gas + (l - 1) * lstride + m * H;
+    float nq[32];
+    if (l == a.skip) {
+      Sweep2Epi<NT, true> e{hrow, g2row, grow, hi, valid, RS2};
+      dense_op_ksplit<NT + PT, 0, 1, Sweep2Epi<NT, true>>(ws, gaq, nq, nullptr, e, xlds, tid);
+    } else {
+      Sweep2Epi<NT, true> e{hrow, g2row, grow, hi, valid, 1.0f};
+      dense_op_ksplit<NT, 0, 1, Sweep2Epi<NT, true>>(ws, gaq, nq, nullptr, e, xlds, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gaq[i] = nq[i];
+  }
+}
+
 }  // namespace
 
 // ---- radiance net backward ---------------------------------------------------------------------------------
@@ -232,6 +337,68 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(RgbBwdArgs a) {
   }
 }
 
+template <int H, int F>
+__global__ __launch_bounds__(256) void rgb_bwd_split_kernel(RgbBwdArgs a, int64_t m0) {
+  constexpr int NT = H / 32, KC = H / 8, FT = F / 32;
+  static_assert(NT == 8 && KC == SC && FT == 8, "split-K kernels are built for 256-wide layers");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xlds = lds + 2 * STAGE_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, hi = lane >> 5;
+  const int64_t m = m0 + (int64_t)blockIdx.x * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float g3[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float c = a.rgb[mc * 3 + j];
+    g3[j] = a.rgb_bar[mc * 3 + j] * c * (1.0f - c);
+  }
+  if (valid && hi == 0 && w == 0) *reinterpret_cast<f32x4*>(a.ga_last + m * 4) = f32x4{g3[0], g3[1], g3[2], 0.f};
+  WStream ws;
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  float gaq[32];
+  {
+    // this wave's quarter of G(r_{L-1}) = W_last^T G(a_last): row j of the last layer fills stage j
+    float grq[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) grq[i] = 0.f;
+    constexpr int NS = rowvec_chunks(KC, 3) / SC;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+      if (s < 3) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const f32x4 wv = cur[(8 * w + i) * 64];
+          grq[i * 4 + 0] = fmaf(wv.x, g3[s < 3 ? s : 0], grq[i * 4 + 0]);
+          grq[i * 4 + 1] = fmaf(wv.y, g3[s < 3 ? s : 0], grq[i * 4 + 1]);
+          grq[i * 4 + 2] = fmaf(wv.z, g3[s < 3 ? s : 0], grq[i * 4 + 2]);
+          grq[i * 4 + 3] = fmaf(wv.w, g3[s < 3 ? s : 0], grq[i * 4 + 3]);
+        }
+      }
+    }
+    const int l = a.L - 2;
+    float rq[32];
+    load_quarter(a.rs + l * lstride + mc * H, w, hi, rq);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gaq[i] = rq[i] > 0.f ? grq[i] : 0.f;
+    store_quarter(a.gar + l * lstride + m * H, w, hi, valid, gaq);
+  }
+  for (int l = a.L - 2; l >= 1; --l) {
+    MaskEpi<true> e{a.rs + (l - 1) * lstride + mc * H, a.gar + (l - 1) * lstride + m * H, hi, valid};
+    float nq[32];
+    dense_op_ksplit<NT, 0, 1, MaskEpi<true>>(ws, gaq, nq, nullptr, e, xlds, tid);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) gaq[i] = nq[i];
+  }
+  {
+    StoreEpi se{a.fbar + m * F, hi, valid};
+    float dq[32];
+    dense_op_ksplit<FT, 0, 1, StoreEpi>(ws, gaq, dq, nullptr, se, xlds, tid);
+  }
+}
+
 }  // namespace
 
 extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, const float* points, const float* cam, const float* dirs,
@@ -259,7 +426,15 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
   if (p->H == 256 && p->F == 256) {
     a.n_fwd = sdf_fwd_hidden_stages(256, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
-    launch_lds(sdf_bwd_kernel<256, 256, 6>, grid, st, a);
+    const int64_t bulk = split_bulk_points(M);
+    if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
+      a.M = bulk;
+      launch_lds(sdf_bwd_kernel<256, 256, 6>, (unsigned)(bulk / PTS_PER_WG), st, a);
+      a.M = M;
+      launch_lds_bytes(KS_LDS_BYTES, sdf_bwd_split_kernel<256, 256, 6>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
+    } else {
+      launch_lds(sdf_bwd_kernel<256, 256, 6>, grid, st, a);
+    }
   } else if (p->H == 64 && p->F == 64) {
     a.n_fwd = sdf_fwd_hidden_stages(64, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(64, 64, PE<6>::PEC, d.n_lin, has_skip);
@@ -281,7 +456,15 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
-    launch_lds(rgb_bwd_kernel<256, 256>, grid, st, a);
+    const int64_t bulk = split_bulk_points(M);
+    if (bulk > 0) {
+      a.M = bulk;
+      launch_lds(rgb_bwd_kernel<256, 256>, (unsigned)(bulk / PTS_PER_WG), st, a);
+      a.M = M;
+      launch_lds_bytes(KS_LDS_BYTES, rgb_bwd_split_kernel<256, 256>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
+    } else {
+      launch_lds(rgb_bwd_kernel<256, 256>, grid, st, a);
+    }
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_rev = rgb_rev_stages(64, 64, d.n_lin);
     launch_lds(rgb_bwd_kernel<64, 64>, grid, st, a);

@@ -113,3 +113,49 @@ def test_rgb_backward_param_and_feature_grads(which):
     for k in names:
         r = ref[k] if ref[k] is not None else torch.zeros_like(params[k])
         assert_close(got[k], r, 1e-4, k)
+
+
+@pytest.mark.parametrize("which", ["synthetic", "light"])
+def test_backward_split_k_tail(which):
+    """256 full workgroups + a short tail: the tail of both backward kernels runs as split-K workgroups (ksplit.h).
+    The probe loss only weights the tail and a few bulk points, so the oracle differentiates just those."""
+    ocfg, conf = _cfgs(which)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=21), 0.05, seed=22)
+    eng = make_engine(conf, sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    g = torch.Generator().manual_seed(23)
+    n = 7
+    B = (256 * 128 + 500 + n - 1) // n
+    M, F = B * n, ocfg.rgb.feature_size
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 1.5
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1)
+    idx = torch.cat([torch.arange(0, 150), torch.arange(256 * 128 - 90, M)])
+    sel = torch.zeros(M, 1)
+    sel[idx] = 1
+    cw = torch.randn(M, 3, generator=g) * sel
+    sw = torch.randn(M, 1, generator=g) * sel
+    m_f = M - 29
+    # oracle on the selected points only
+    params = {k: v.double().requires_grad_(True) for k, v in sd.items() if not k.startswith("light") and k != "density.beta"}
+    sdf, feat, grad = orc.sdf_outputs(params, ocfg.sdf, x.double()[idx], create_graph=True)
+    with_rgb = (idx < m_f).double().unsqueeze(1)
+    rgb = orc.rgb_forward(params, ocfg.rgb, dirs.double()[idx // n], feat)
+    loss = (rgb * cw.double()[idx] * with_rgb).sum() + (sdf * sw.double()[idx]).sum() + ((grad.norm(2, dim=1) - 1) ** 2).sum()
+    names = list(params)
+    ref = dict(zip(names, torch.autograd.grad(loss, [params[k] for k in names], allow_unused=True)))
+    # HIP
+    fwd = eng.sdf_forward_grad(points=x.cuda())
+    rgb_h, rs, pev = eng.rgb_forward(dirs.cuda(), n, fwd["feat"], M)
+    cw_d = cw.clone()
+    cw_d[m_f:] = 0
+    gar, ga_last, fbar = eng.rgb_backward(rgb_h, cw_d.cuda(), rs, M)
+    nvec = fwd["grad"]
+    nn = nvec.norm(dim=1, keepdim=True)
+    nbar = 2 * (nn - 1) * nvec / nn * sel.cuda()
+    bw = eng.sdf_backward(fwd, sbar=sw.reshape(-1).cuda(), fbar=fbar, m_fbar=m_f, nbar=nbar)
+    gflat = torch.zeros_like(flat)
+    eng.weight_grads(flat, gflat, fwd, bw, M_main=m_f, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
+    got = eng.layout.state_dict_from_flat(gflat.cpu())
+    for k in names:
+        r = ref[k] if ref[k] is not None else torch.zeros_like(params[k])
+        assert_close(got[k], r, 1e-4, k)
