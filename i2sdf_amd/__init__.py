@@ -11,6 +11,9 @@ def __getattr__(name):
     if name == "I2SDFLoss":
         from .loss import I2SDFLoss
         return I2SDFLoss
+    if name in ("RayBatcher", "RaySample"):
+        from . import batcher
+        return getattr(batcher, name)
     if name == "RenderEngine":
         from .engine import RenderEngine
         return RenderEngine

@@ -29,31 +29,102 @@ __device__ __forceinline__ float wave_sum(float v) {
 // R1/R2: utils/rend_util.py:92-147 (get_camera_params + lift, pose-matrix branch) and
 // model/network/__init__.py:88-93 (repeat cam_loc, norm, F.normalize eps 1e-12).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void raygen_kernel(const float* __restrict__ uv, const float* __restrict__ pose,
-                                                      const float* __restrict__ K, int64_t N, int P, float* __restrict__ cam,
-                                                      float* __restrict__ dirs, float* __restrict__ dnorm) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const int64_t b = i / P;
-  const float* k = K + b * 16;
-  const float* p = pose + b * 16;
+// un-normalised world direction of pixel (x, y) -> unit dir, norm.  p = pose rows (3x4), k = intrinsics (4x4 row-major)
+__device__ __forceinline__ void pixel_ray(float x, float y, const float* k, const float (&p)[12], float (&d)[3], float& nrm) {
   const float fx = k[0], sk = k[1], cx = k[2], fy = k[5], cy = k[6];
-  const float x = uv[i * 2 + 0], y = uv[i * 2 + 1];
   // x_lift = (x - cx + cy*sk/fy - sk*y/fy) / fx * z ; z = 1   (rend_util.py:143-144), same association order
   const float xl = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(x, cx), __fdiv_rn(__fmul_rn(cy, sk), fy)), __fdiv_rn(__fmul_rn(sk, y), fy)), fx);
   const float yl = __fdiv_rn(__fsub_rn(y, cy), fy);
-  float d[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     // world = pose @ [xl, yl, 1, 1]; dir = world - pose[:3,3]
     const float w = fmaf(p[r * 4 + 0], xl, fmaf(p[r * 4 + 1], yl, p[r * 4 + 2] + p[r * 4 + 3]));
     d[r] = w - p[r * 4 + 3];
-    cam[i * 3 + r] = p[r * 4 + 3];
   }
-  const float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+  d[0] *= inv; d[1] *= inv; d[2] *= inv;
+}
+
+// pose rows from either a 4x4 cam->world matrix or [qr qi qj qk tx ty tz] (rend_util.py:93-98, quat_to_rot :150-167)
+__device__ __forceinline__ void load_pose(const float* pose, int64_t b, bool quat, float (&p)[12]) {
+  if (!quat) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) p[i] = pose[b * 16 + i];
+    return;
+  }
+  const float* q = pose + b * 7;
+  const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+  const float qr = q[0] / n, qi = q[1] / n, qj = q[2] / n, qk = q[3] / n;
+  p[0] = 1.f - 2.f * (qj * qj + qk * qk); p[1] = 2.f * (qj * qi - qk * qr);       p[2] = 2.f * (qi * qk + qr * qj);        p[3] = q[4];
+  p[4] = 2.f * (qj * qi + qk * qr);       p[5] = 1.f - 2.f * (qi * qi + qk * qk); p[6] = 2.f * (qj * qk - qi * qr);        p[7] = q[5];
+  p[8] = 2.f * (qk * qi - qj * qr);       p[9] = 2.f * (qj * qk + qi * qr);       p[10] = 1.f - 2.f * (qi * qi + qj * qj); p[11] = q[6];
+}
+
+__global__ __launch_bounds__(256) void raygen_kernel(const float* __restrict__ uv, const float* __restrict__ pose, bool quat,
+                                                      const float* __restrict__ K, int64_t N, int P, float* __restrict__ cam,
+                                                      float* __restrict__ dirs, float* __restrict__ dnorm) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int64_t b = i / P;
+  float p[12], d[3], nrm;
+  load_pose(pose, b, quat, p);
+  pixel_ray(uv[i * 2 + 0], uv[i * 2 + 1], K + b * 16, p, d, nrm);
   dnorm[i] = nrm;
-  dirs[i * 3 + 0] = d[0] * inv; dirs[i * 3 + 1] = d[1] * inv; dirs[i * 3 + 2] = d[2] * inv;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { cam[i * 3 + r] = p[r * 4 + 3]; dirs[i * 3 + r] = d[r]; }
+}
+
+// N2: ray batch straight from HBM-resident camera / image tables.  One thread per ray: the global pixel index selects
+// the image (K, pose: 128 B shared by all rays of an image, cache resident) and the pixel; ground truth is gathered in the same pass.
+__global__ __launch_bounds__(256) void ray_batch_kernel(i2sdf_ray_tables t, const int64_t* __restrict__ tidx, int64_t B,
+                                                         i2sdf_ray_batch_out o) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  const int64_t hw = (int64_t)t.height * t.width;
+  const int64_t g = tidx[i];
+  const int64_t img = g / hw, pix = g - img * hw;
+  const float x = (float)(pix % t.width), y = (float)(pix / t.width);     // dataset/train_dataset.py:67-70 (flipped mgrid: uv = (col, row))
+  float p[12], d[3], nrm;
+  load_pose(t.pose, img, t.pose_is_quat != 0, p);
+  pixel_ray(x, y, t.intrinsics + img * 16, p, d, nrm);
+  if (o.image_idx) o.image_idx[i] = img;
+  if (o.uv) { o.uv[i * 2 + 0] = x; o.uv[i * 2 + 1] = y; }
+  o.dnorm[i] = nrm;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { o.cam_loc[i * 3 + r] = p[r * 4 + 3]; o.dirs[i * 3 + r] = d[r]; }
+  if (t.rgb && o.rgb) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.rgb[i * 3 + r] = t.rgb[g * 3 + r];
+  }
+  if (t.depth && o.depth) o.depth[i] = t.depth[g];
+  if (t.normal && o.normal) {
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.normal[i * 3 + r] = t.normal[g * 3 + r];
+  }
+  if (t.mask && o.mask) o.mask[i] = t.mask[g];
+  if (t.light_mask && o.light_mask) o.light_mask[i] = t.light_mask[g];
+  if (t.depth_mask && o.depth_mask) o.depth_mask[i] = t.depth_mask[g];
+  if (t.normal_mask && o.normal_mask) o.normal_mask[i] = t.normal_mask[g];
+}
+
+// R3: utils/rend_util.py:211-227.  Rays that miss the sphere are counted instead of exit()
+__global__ __launch_bounds__(256) void sphere_isect_kernel(const float* __restrict__ cam, const float* __restrict__ dirs, int64_t N,
+                                                            float r, float* __restrict__ out, int32_t* __restrict__ n_miss) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float ox = cam[i * 3], oy = cam[i * 3 + 1], oz = cam[i * 3 + 2];
+  const float dot = dirs[i * 3] * ox + dirs[i * 3 + 1] * oy + dirs[i * 3 + 2] * oz;
+  const float nn = sqrtf(ox * ox + oy * oy + oz * oz);
+  const float under = dot * dot - (nn * nn - r * r);
+  if (under <= 0.f) {
+    atomicAdd(n_miss, 1);
+    out[i * 2] = 0.f; out[i * 2 + 1] = 0.f;
+    return;
+  }
+  const float sq = sqrtf(under);
+  out[i * 2 + 0] = fmaxf(-sq - dot, 0.f);
+  out[i * 2 + 1] = fmaxf(sq - dot, 0.f);
 }
 
 // Laplace density (model/network/density.py:21-26): (1/beta)(0.5 + 0.5 sign(s) expm1(-|s|/beta))
@@ -256,11 +327,36 @@ __global__ __launch_bounds__(1024) void beta_reduce_kernel(const float* __restri
 
 extern "C" int i2sdf_ray_setup(const float* uv, const float* pose, const float* intrinsics, int64_t batch, int32_t pixels, float* cam_loc,
                                float* dirs, float* dnorm, void* stream) {
-  if (batch == 0) return I2SDF_OK;
-  if (!uv || !pose || !intrinsics || !cam_loc || !dirs || !dnorm || batch < 0 || pixels <= 0) return I2SDF_EINVAL;
+  return i2sdf_ray_setup_ex(uv, pose, 0, intrinsics, batch, pixels, cam_loc, dirs, dnorm, stream);
+}
+
+extern "C" int i2sdf_ray_setup_ex(const float* uv, const float* pose, int32_t pose_is_quat, const float* intrinsics, int64_t batch,
+                                  int32_t pixels, float* cam_loc, float* dirs, float* dnorm, void* stream) {
+  if (batch < 0 || pixels < 0) return I2SDF_EINVAL;
   const int64_t N = batch * pixels;
-  raygen_kernel<<<(unsigned)((N + 255) / 256), 256, 0, (hipStream_t)stream>>>(uv, pose, intrinsics, N, pixels, cam_loc, dirs, dnorm);
+  if (N == 0) return I2SDF_OK;
+  if (!uv || !pose || !intrinsics || !cam_loc || !dirs || !dnorm) return I2SDF_EINVAL;
+  raygen_kernel<<<(unsigned)((N + 255) / 256), 256, 0, (hipStream_t)stream>>>(uv, pose, pose_is_quat != 0, intrinsics, N, pixels, cam_loc,
+                                                                              dirs, dnorm);
   return i2sdf_hip_check(hipGetLastError(), "ray_setup launch");
+}
+
+extern "C" int i2sdf_ray_batch(const i2sdf_ray_tables* t, const int64_t* tidx, int64_t n_rays, const i2sdf_ray_batch_out* out, void* stream) {
+  if (!t || !out || n_rays < 0) return I2SDF_EINVAL;
+  if (n_rays == 0) return I2SDF_OK;
+  if (!tidx || !t->intrinsics || !t->pose || t->n_images <= 0 || t->height <= 0 || t->width <= 0) return I2SDF_EINVAL;
+  if (!out->cam_loc || !out->dirs || !out->dnorm) return I2SDF_EINVAL;
+  ray_batch_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(*t, tidx, n_rays, *out);
+  return i2sdf_hip_check(hipGetLastError(), "ray_batch launch");
+}
+
+extern "C" int i2sdf_sphere_intersections(const float* cam_loc, const float* dirs, int64_t n_rays, float radius, float* t_near_far,
+                                          int32_t* n_miss, void* stream) {
+  if (n_rays < 0) return I2SDF_EINVAL;
+  if (n_rays == 0) return I2SDF_OK;
+  if (!cam_loc || !dirs || !t_near_far || !n_miss) return I2SDF_EINVAL;
+  sphere_isect_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(cam_loc, dirs, n_rays, radius, t_near_far, n_miss);
+  return i2sdf_hip_check(hipGetLastError(), "sphere_intersections launch");
 }
 
 extern "C" int i2sdf_composite_forward(const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf,

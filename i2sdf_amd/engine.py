@@ -200,15 +200,31 @@ class RenderEngine:
 
     # -- per-ray kernels -------------------------------------------------------------------------
     def ray_setup(self, uv, pose, intrinsics):
+        """pose: (batch,4,4) cam->world or (batch,7) [quaternion, translation] (utils/rend_util.py:93-101)."""
         uv, pose, intrinsics = (t.detach().to(torch.float32).contiguous() for t in (uv, pose, intrinsics))
+        quat = pose.dim() == 2 and pose.shape[1] == 7
+        if not quat and tuple(pose.shape[1:]) != (4, 4):
+            raise ValueError(f"pose must be (batch,4,4) or (batch,7), got {tuple(pose.shape)}")
         batch, pixels = uv.shape[0], uv.shape[1]
         N = batch * pixels
         cam = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
         dirs = torch.empty_like(cam)
         dnorm = torch.empty(N, dtype=torch.float32, device=uv.device)
-        L_.check(self._lib.i2sdf_ray_setup(L_.ptr(uv), L_.ptr(pose), L_.ptr(intrinsics), batch, pixels, L_.ptr(cam), L_.ptr(dirs),
-                                           L_.ptr(dnorm), L_.stream_ptr()), "i2sdf_ray_setup")
+        L_.check(self._lib.i2sdf_ray_setup_ex(L_.ptr(uv), L_.ptr(pose), int(quat), L_.ptr(intrinsics), batch, pixels, L_.ptr(cam),
+                                              L_.ptr(dirs), L_.ptr(dnorm), L_.stream_ptr()), "i2sdf_ray_setup_ex")
         return cam, dirs, dnorm
+
+    def sphere_intersections(self, cam_loc, dirs, radius):
+        """utils/rend_util.py:211-227; raises where the reference prints 'BOUNDING SPHERE PROBLEM!' and exit()s."""
+        cam_loc, dirs = cam_loc.detach().float().contiguous(), dirs.detach().float().contiguous()
+        N = cam_loc.shape[0]
+        out = torch.empty(N, 2, dtype=torch.float32, device=cam_loc.device)
+        miss = torch.zeros(1, dtype=torch.int32, device=cam_loc.device)
+        L_.check(self._lib.i2sdf_sphere_intersections(L_.ptr(cam_loc), L_.ptr(dirs), N, float(radius), L_.ptr(out), L_.ptr(miss),
+                                                      L_.stream_ptr()), "i2sdf_sphere_intersections")
+        if int(miss.item()) > 0:
+            raise ValueError(f"BOUNDING SPHERE PROBLEM: {int(miss.item())} rays do not intersect the sphere of radius {radius}")
+        return out
 
     def composite_forward(self, beta_param, z_all, sdf, rgb, grad, lmask, dnorm, want_normal, save=True):
         B, n = z_all.shape[0], z_all.shape[1] - 1

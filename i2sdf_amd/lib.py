@@ -38,6 +38,17 @@ class LossCfg(C.Structure):
                [("smooth_on", C.c_int32)]
 
 
+class RayTables(C.Structure):
+    _fields_ = [("intrinsics", C.c_void_p), ("pose", C.c_void_p), ("pose_is_quat", C.c_int32), ("n_images", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("rgb", "depth", "normal", "mask", "light_mask", "depth_mask", "normal_mask")]
+
+
+class RayBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("image_idx", "uv", "cam_loc", "dirs", "dnorm", "rgb", "depth", "normal", "mask", "light_mask",
+                                          "depth_mask", "normal_mask")]
+
+
 class I2SDFError(RuntimeError):
     pass
 
@@ -77,6 +88,9 @@ SIGNATURES = {
     "i2sdf_loss_scratch_floats": (_I64, []),
     "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 26),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
+    "i2sdf_ray_setup_ex": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P]),
+    "i2sdf_ray_batch": (C.c_int, [C.POINTER(RayTables), _P, _I64, C.POINTER(RayBatch), _P]),
+    "i2sdf_sphere_intersections": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P]),
     "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
     "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),
 }

@@ -236,7 +236,9 @@ class I2SDFNetwork(nn.Module):
             with torch.cuda.device(device):
                 eng = RenderEngine(self.cfg, device)
             self._engines[key] = eng
-        ver = (flat.data_ptr(), flat._version)
+        # the parameters are views of `flat` made through `.data`, so they keep their OWN version counters: an optimizer
+        # step bumps p._version, never flat._version.  Both are part of the key, or the kernels would run on stale weights.
+        ver = (flat.data_ptr(), flat._version, sum(p._version for p in self._param_list()))
         if self._packed_version.get(key) != ver:
             with torch.cuda.device(device):
                 eng.pack(flat)
@@ -245,12 +247,16 @@ class I2SDFNetwork(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward(self, input: Dict[str, torch.Tensor], predict_only: bool = False, draws: Optional[dict] = None):
-        uv, pose, K = input["uv"], input["pose"], input["intrinsics"]
+        uv = input["uv"]
         eng = self._engine_for(uv.device)
         flat = self._flat
         sc = self.cfg.sampler
-        with torch.cuda.device(uv.device), torch.no_grad():
-            cam, dirs, dnorm = eng.ray_setup(uv, pose, K)
+        rays = input.get("rays")
+        if rays is not None:                # batch from i2sdf_amd.batcher.RayBatcher: rays were made together with the ground truth
+            cam, dirs, dnorm = rays["cam_loc"], rays["dirs"], rays["dnorm"]
+        else:
+            with torch.cuda.device(uv.device), torch.no_grad():
+                cam, dirs, dnorm = eng.ray_setup(uv, input["pose"], input["intrinsics"])
         N = cam.shape[0]
         dev = cam.device
         training = self.training

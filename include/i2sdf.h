@@ -158,6 +158,57 @@ int i2sdf_sdf_backward(const i2sdf_plan* plan, const float* packed, const float*
  * ---------------------------------------------------------------------------------------------- */
 int i2sdf_ray_setup(const float* uv, const float* pose, const float* intrinsics, int64_t batch, int32_t pixels,
                     float* cam_loc, float* dirs, float* dnorm, void* stream);
+/* Same with the pose given as (batch,7) = [qr qi qj qk tx ty tz] when pose_is_quat != 0 (rend_util.py:93-98, quat_to_rot :150-167). */
+int i2sdf_ray_setup_ex(const float* uv, const float* pose, int32_t pose_is_quat, const float* intrinsics, int64_t batch,
+                       int32_t pixels, float* cam_loc, float* dirs, float* dnorm, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray batcher -- replaces ReconDataset.__getitem__ + collate_fn (dataset/train_dataset.py:169-209),
+ * which stack one 4x4 K and one 4x4 pose PER RAY on the host, and the get_camera_params call that consumes them.
+ * The camera tables and (optionally) the ground-truth images stay resident in HBM; a batch is a list of global pixel
+ * indices tidx = image * (H*W) + pixel (what the DataLoader's sampler yields).  One pass writes the rays and gathers
+ * the ground truth.  uv follows dataset/train_dataset.py:67-70: uv = (column, row) as floats.
+ * Any table / output pointer except intrinsics, pose, cam_loc, dirs, dnorm may be NULL (skipped).
+ * Dtypes follow the dataset: mask / light_mask are float images (:82,:96), depth_mask / normal_mask are bool bytes (:123,:163).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_ray_tables {
+  const float* intrinsics;         /* (n_images,4,4) */
+  const float* pose;               /* (n_images,4,4) cam->world, or (n_images,7) when pose_is_quat */
+  int32_t pose_is_quat;
+  int32_t n_images, height, width;
+  const float* rgb;                /* (n_images, H*W, 3) */
+  const float* depth;              /* (n_images, H*W)    */
+  const float* normal;             /* (n_images, H*W, 3) */
+  const float* mask;               /* (n_images, H*W, 1) */
+  const float* light_mask;         /* (n_images, H*W, 1) */
+  const uint8_t* depth_mask;       /* (n_images, H*W)    */
+  const uint8_t* normal_mask;      /* (n_images, H*W)    */
+} i2sdf_ray_tables;
+
+typedef struct i2sdf_ray_batch_out {
+  int64_t* image_idx;              /* (n_rays)   tidx / (H*W) */
+  float* uv;                       /* (n_rays,2) */
+  float* cam_loc;                  /* (n_rays,3) */
+  float* dirs;                     /* (n_rays,3) unit */
+  float* dnorm;                    /* (n_rays)   */
+  float* rgb;                      /* (n_rays,3) */
+  float* depth;                    /* (n_rays)   */
+  float* normal;                   /* (n_rays,3) */
+  float* mask;                     /* (n_rays,1) */
+  float* light_mask;               /* (n_rays,1) */
+  uint8_t* depth_mask;             /* (n_rays)   */
+  uint8_t* normal_mask;            /* (n_rays)   */
+} i2sdf_ray_batch_out;
+
+int i2sdf_ray_batch(const i2sdf_ray_tables* tables, const int64_t* tidx, int64_t n_rays, const i2sdf_ray_batch_out* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ray / bounding-sphere intersection -- utils/rend_util.py:211-227 (reached only with a background network).
+ *   -> t_near_far (n_rays,2) = clamp(+-sqrt((d.o)^2 - (|o|^2 - r^2)) - d.o, min 0).  Where the reference prints and exit()s
+ *   (non-positive discriminant) this entry writes (0,0) for the ray and increments *n_miss (device int32, caller-zeroed).
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_sphere_intersections(const float* cam_loc, const float* dirs, int64_t n_rays, float radius, float* t_near_far,
+                               int32_t* n_miss, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Laplace density + log-space alpha compositing -- LaplaceDensity (density.py:21-30),

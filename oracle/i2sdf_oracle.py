@@ -328,9 +328,25 @@ def laplace_density(sdf: Tensor, beta) -> Tensor:
 # --------------------------------------------------------------------------------------
 # R1/R2  rays -- utils/rend_util.py:92-147 ; model/network/__init__.py:88-93
 # --------------------------------------------------------------------------------------
+def quat_to_rot(q: Tensor) -> Tensor:
+    """utils/rend_util.py:150-167; q = (qr, qi, qj, qk), normalised first."""
+    q = torch.nn.functional.normalize(q, dim=1)
+    qr, qi, qj, qk = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([
+        1 - 2 * (qj ** 2 + qk ** 2), 2 * (qj * qi - qk * qr), 2 * (qi * qk + qr * qj),
+        2 * (qj * qi + qk * qr), 1 - 2 * (qi ** 2 + qk ** 2), 2 * (qj * qk - qi * qr),
+        2 * (qk * qi - qj * qr), 2 * (qj * qk + qi * qr), 1 - 2 * (qi ** 2 + qj ** 2)], dim=1)
+    return R.reshape(-1, 3, 3)
+
+
 def get_camera_params(uv: Tensor, pose: Tensor, intrinsics: Tensor) -> Tuple[Tensor, Tensor]:
-    """uv (B,P,2), pose (B,4,4) cam->world, K (B,4,4) -> un-normalised ray dirs (B,P,3), cam_loc (B,3).
-    Pose-matrix branch only (rend_util.py:99-101); the quaternion branch is unused by the datasets."""
+    """uv (B,P,2), pose (B,4,4) cam->world or (B,7) [quaternion, translation], K (B,4,4)
+    -> un-normalised ray dirs (B,P,3), cam_loc (B,3).  utils/rend_util.py:92-120."""
+    if pose.dim() == 2 and pose.shape[1] == 7:                 # rend_util.py:93-98
+        p = torch.eye(4, dtype=pose.dtype).repeat(pose.shape[0], 1, 1)
+        p[:, :3, :3] = quat_to_rot(pose[:, :4])
+        p[:, :3, 3] = pose[:, 4:]
+        pose = p
     fx, fy = intrinsics[:, 0, 0:1], intrinsics[:, 1, 1:2]
     cx, cy = intrinsics[:, 0, 2:3], intrinsics[:, 1, 2:3]
     sk = intrinsics[:, 0, 1:2]
@@ -342,6 +358,33 @@ def get_camera_params(uv: Tensor, pose: Tensor, intrinsics: Tensor) -> Tuple[Ten
     world = torch.bmm(pose, pts.permute(0, 2, 1)).permute(0, 2, 1)[:, :, :3]  # rend_util.py:116
     cam_loc = pose[:, :3, 3]
     return world - cam_loc[:, None, :], cam_loc
+
+
+def pixel_uv(height: int, width: int) -> Tensor:
+    """dataset/train_dataset.py:67-70: flipped mgrid -> (H*W, 2) with uv = (column, row)."""
+    rows, cols = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    return torch.stack([cols.reshape(-1), rows.reshape(-1)], dim=1).float()
+
+
+def ray_batch(tables: Dict[str, Tensor], img_res, tidx: Tensor):
+    """ReconDataset.__getitem__ + collate_fn (dataset/train_dataset.py:169-209) for a list of global pixel indices.
+    tables: intrinsics_all, pose_all, rgb_images and optionally mask_images, lightmask_images, depth_images, depth_masks,
+    normal_images, normal_masks (the dataset's attribute names / layouts).
+    -> (tidx, image_idx, sample{uv (B,1,2), intrinsics (B,4,4), pose}, ground_truth{...})."""
+    hw = img_res[0] * img_res[1]
+    uv = pixel_uv(img_res[0], img_res[1])
+    pidx, idx = tidx % hw, tidx // hw
+    sample = {"uv": uv[pidx].unsqueeze(1), "intrinsics": tables["intrinsics_all"][idx], "pose": tables["pose_all"][idx]}
+    gt = {"rgb": tables["rgb_images"][idx, pidx]}
+    if "mask_images" in tables:
+        gt["mask"] = tables["mask_images"][idx, pidx]
+    if "lightmask_images" in tables:
+        gt["light_mask"] = tables["lightmask_images"][idx, pidx]
+    if "depth_images" in tables:
+        gt["depth"], gt["depth_mask"] = tables["depth_images"][idx, pidx], tables["depth_masks"][idx, pidx]
+    if "normal_images" in tables:
+        gt["normal"], gt["normal_mask"] = tables["normal_images"][idx, pidx], tables["normal_masks"][idx, pidx]
+    return tidx, idx, sample, gt
 
 
 def prepare_rays(uv, pose, intrinsics):

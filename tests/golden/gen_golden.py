@@ -291,5 +291,48 @@ def main():
     save("g11_loss", **arrs)
 
 
+    # ---- G10b quaternion poses, G12 sphere intersections -----------------------------------
+    g = torch.Generator().manual_seed(77)            # fresh stream: fixtures above stay byte-identical
+    inp = camera_batch(64, (0.3, -0.1, 0.7), W=640, H=480, f=600.0, seed=5, skew=2.5)
+    q = torch.randn(6, 4, generator=g)
+    pose7 = torch.cat([q, torch.randn(6, 3, generator=g)], dim=1)
+    uvq = torch.rand(6, 5, 2, generator=g) * 32
+    dirs_q, cam_q = ref_utils.get_camera_params(uvq, pose7, inp["intrinsics"][:6])
+    save("g10b_camera_quat", uv=uvq, pose=pose7, intrinsics=inp["intrinsics"][:6], ray_dirs=dirs_q, cam_loc=cam_q)
+    o = torch.randn(200, 3, generator=g) * 0.8                                   # inside the r=3 sphere
+    d = torch.nn.functional.normalize(torch.randn(200, 3, generator=g), dim=1)
+    save("g12_sphere", cam_loc=o, dirs=d, r=np.float32(3.0), t=ref_utils.get_sphere_intersections(o, d, r=3.0))
+
+    # ---- G13 ReconDataset batching (N2): __getitem__ + collate_fn on hand-filled tables ------
+    import importlib
+    ReconDataset = importlib.import_module("dataset.train_dataset").ReconDataset
+    ds = object.__new__(ReconDataset)                  # the constructor only reads image files; the batching code reads attributes
+    n_img, H, W = 3, 6, 8
+    ds.n_images, ds.img_res, ds.total_pixels = n_img, [H, W], H * W
+    uv_np = np.mgrid[0:H, 0:W].astype(np.int32)        # same three lines as the constructor (train_dataset.py:67-70)
+    uv_np = np.flip(uv_np, axis=0).copy()
+    ds.uv = torch.from_numpy(uv_np).float().reshape(2, -1).transpose(1, 0)
+    cb = camera_batch(n_img, (0.2, -0.1, -2.0), W=W, H=H, f=9.0, seed=3, skew=0.3)
+    ds.intrinsics_all, ds.pose_all = cb["intrinsics"].clone(), cb["pose"].clone()
+    ds.intrinsics_all[:, 0, 0] += torch.arange(n_img).float()          # distinct cameras
+    ds.pose_all[:, :3, 3] += torch.randn(n_img, 3, generator=g) * 0.1
+    ds.rgb_images = torch.rand(n_img, H * W, 3, generator=g)
+    ds.use_mask, ds.mask_images = True, (torch.rand(n_img, H * W, 1, generator=g) > 0.2).float()
+    ds.use_lightmask, ds.lightmask_images = True, (torch.rand(n_img, H * W, 1, generator=g) > 0.7).float()
+    ds.use_depth, ds.use_bubble = True, False
+    ds.depth_images, ds.depth_masks = torch.rand(n_img, H * W, generator=g) * 4, torch.rand(n_img, H * W, generator=g) > 0.3
+    ds.use_normal = True
+    ds.normal_images = torch.nn.functional.normalize(torch.randn(n_img, H * W, 3, generator=g), dim=-1)
+    ds.normal_masks = torch.rand(n_img, H * W, generator=g) > 0.3
+    tidx = torch.randperm(n_img * H * W, generator=g)[:40]
+    t_out, i_out, sample, gtb = ds.collate_fn([ds[int(i)] for i in tidx])
+    dirs_b, cam_b = ref_utils.get_camera_params(sample["uv"], sample["pose"], sample["intrinsics"])
+    arrs = {"tab." + k: getattr(ds, k) for k in ("intrinsics_all", "pose_all", "rgb_images", "mask_images", "lightmask_images",
+                                                  "depth_images", "depth_masks", "normal_images", "normal_masks")}
+    arrs.update({"sample." + k: v for k, v in sample.items()})
+    arrs.update({"gt." + k: v for k, v in gtb.items()})
+    save("g13_batcher", img_res=np.array([H, W]), tidx=t_out, image_idx=i_out, ray_dirs=dirs_b, cam_loc=cam_b, **arrs)
+
+
 if __name__ == "__main__":
     main()

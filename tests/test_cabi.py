@@ -101,7 +101,14 @@ def test_entry_points_validate_arguments_without_a_gpu(lib):
     assert h.i2sdf_composite_forward(P, 1e-4, P, 10, P, P, None, None, P, 4, 300, P, P, P, None, None, None, None, None) == -1  # n > 256
     assert h.i2sdf_composite_forward(P, 1e-4, P, 10, P, P, None, None, P, 4, 9, P, P, P, P, None, None, None, None) == -1     # normal without grad
     assert h.i2sdf_light_forward(plan, P, P, 10, 128, P, P, None) == -1                       # this net has no light head
-    assert h.i2sdf_ray_setup(P, P, P, 4, 0, P, P, P, None) == -1
+    assert h.i2sdf_ray_setup(P, P, P, 4, -1, P, P, P, None) == -1
+    assert h.i2sdf_ray_setup(P, None, P, 4, 2, P, P, P, None) == -1                           # no pose
+    assert h.i2sdf_ray_setup_ex(P, P, 1, P, 0, 2, P, P, P, None) == 0                         # empty batch is a no-op
+    tab, out = lib.RayTables(), lib.RayBatch()
+    assert h.i2sdf_ray_batch(C.byref(tab), P, 0, C.byref(out), None) == 0                     # empty batch
+    assert h.i2sdf_ray_batch(C.byref(tab), P, 8, C.byref(out), None) == -1                    # no camera tables
+    assert h.i2sdf_ray_batch(None, P, 8, C.byref(out), None) == -1
+    assert h.i2sdf_sphere_intersections(P, P, 8, 3.0, P, None, None) == -1                    # no miss counter
     h.i2sdf_plan_destroy(plan)
 
 

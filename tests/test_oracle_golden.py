@@ -175,6 +175,36 @@ def test_g10_camera(golden):
     assert torch.equal(c, t(z["cam_loc"]))
 
 
+def test_g10b_camera_quaternion(golden):
+    z = golden("g10b_camera_quat")
+    d, c = orc.get_camera_params(t(z["uv"]), t(z["pose"]), t(z["intrinsics"]))
+    assert_close(d, z["ray_dirs"], 1e-6, "ray dirs (quaternion pose)")
+    assert torch.equal(c, t(z["cam_loc"]))
+
+
+def test_g12_sphere_intersections(golden):
+    z = golden("g12_sphere")
+    assert_close(orc.get_sphere_intersections(t(z["cam_loc"]), t(z["dirs"]), float(z["r"])), z["t"], 1e-6, "sphere intersections")
+    with pytest.raises(ValueError):
+        orc.get_sphere_intersections(torch.tensor([[5.0, 0, 0]]), torch.tensor([[0.0, 1, 0]]), 3.0)
+
+
+def test_g13_batcher(golden):
+    """ReconDataset.__getitem__ + collate_fn for 40 global pixel indices over 3 images."""
+    z = golden("g13_batcher")
+    tables = {k[4:]: t(z[k]) for k in z.files if k.startswith("tab.")}
+    tidx, idx, sample, gt = orc.ray_batch(tables, [int(v) for v in z["img_res"]], t(z["tidx"]))
+    assert torch.equal(idx, t(z["image_idx"]))
+    for k in ("uv", "intrinsics", "pose"):
+        assert torch.equal(sample[k], t(z["sample." + k])), k
+    names = [k[3:] for k in z.files if k.startswith("gt.")]
+    assert sorted(names) == sorted(gt)
+    for k in names:
+        assert torch.equal(gt[k], t(z["gt." + k])), k
+    d, c = orc.get_camera_params(sample["uv"], sample["pose"], sample["intrinsics"])
+    assert_close(d, z["ray_dirs"], 1e-6, "ray dirs")
+
+
 def test_g11_loss(golden):
     z = golden("g11_loss")
     out = {k[4:]: t(z[k]) for k in z.files if k.startswith("out.")}
