@@ -222,7 +222,7 @@ class I2SDFNetwork(nn.Module):
             self._packed_version.clear()
         return self._flat
 
-    def _engine_for(self, device) -> RenderEngine:
+    def _engine_for(self, device, fresh: bool = True) -> RenderEngine:
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("i2sdf_amd.I2SDFNetwork runs on MI355X only (tensors must be on a cuda/HIP device); "
@@ -236,10 +236,12 @@ class I2SDFNetwork(nn.Module):
             with torch.cuda.device(device):
                 eng = RenderEngine(self.cfg, device)
             self._engines[key] = eng
-        # the parameters are views of `flat` made through `.data`, so they keep their OWN version counters: an optimizer
-        # step bumps p._version, never flat._version.  Both are part of the key, or the kernels would run on stale weights.
+        # The parameters are views of `flat` made through `.data`, so they keep their OWN version counters: an optimizer
+        # step bumps p._version, never flat._version -- and fused / foreach optimizers or raw-pointer writers need not
+        # bump anything.  Packing costs ~17 us, so every public entry point (fresh=True) simply repacks; only the
+        # internal second look-up of the same call (render() after forward()) reuses it.
         ver = (flat.data_ptr(), flat._version, sum(p._version for p in self._param_list()))
-        if self._packed_version.get(key) != ver:
+        if fresh or self._packed_version.get(key) != ver:
             with torch.cuda.device(device):
                 eng.pack(flat)
             self._packed_version[key] = ver
@@ -286,7 +288,7 @@ class I2SDFNetwork(nn.Module):
             else:
                 z_all, z_eik, iters = eng.sample_rays(flat, cam, dirs, training=False, force_iters=self.force_iters)
         self.last_sampler_iters = iters
-        return self.render(input, cam, dirs, dnorm, z_all, z_eik, predict_only, draws)
+        return self.render(input, cam, dirs, dnorm, z_all, z_eik, predict_only, draws, _fresh=False)
 
     def _extra_mask(self, dev):
         m = getattr(self, "_extra_mask_t", None)
@@ -298,9 +300,9 @@ class I2SDFNetwork(nn.Module):
             object.__setattr__(self, "_extra_mask_t", m)
         return m
 
-    def render(self, input, cam, dirs, dnorm, z_all, z_eik, predict_only=False, draws=None):
+    def render(self, input, cam, dirs, dnorm, z_all, z_eik, predict_only=False, draws=None, _fresh=True):
         """Everything after the sampler (model/network/__init__.py:99-221) for given depths z_all (N, n+1)."""
-        eng = self._engine_for(cam.device)
+        eng = self._engine_for(cam.device, fresh=_fresh)
         flat = self._flat
         dev = cam.device
         N, n = z_all.shape[0], z_all.shape[1] - 1
