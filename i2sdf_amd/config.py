@@ -66,6 +66,10 @@ class NetConfig:
     use_normal: bool = False
     detach_light_feature: bool = True
     rgb_mode: str = "nerf"
+    # arithmetic of the MFMA kernels that have a bf16x3 twin (csrc/x3.h): fp32 operands split into three bf16 terms, six
+    # partial products accumulated in fp32 -- fp32-level accuracy (same parity bar) on the 16x faster bf16 matrix pipe.
+    # `bf16x3: false` in the model conf selects the plain fp32-MFMA kernels everywhere.
+    bf16x3: bool = True
 
     @staticmethod
     def from_conf(conf) -> "NetConfig":
@@ -117,7 +121,8 @@ class NetConfig:
                          scene_bounding_sphere=float(_get(conf, "scene_bounding_sphere", 1.0)),
                          beta_init=float(_get(_get(dens, "params_init"), "beta")), beta_min=float(_get(dens, "beta_min", 1e-4)),
                          sdf_bias=float(_get(inet, "bias", 1.0)), use_normal=bool(_get(conf, "use_normal", False)),
-                         detach_light_feature=bool(_get(conf, "detach_light_feature", True)))
+                         detach_light_feature=bool(_get(conf, "detach_light_feature", True)),
+                         bf16x3=bool(_get(conf, "bf16x3", True)))
 
 
 def synthetic_conf(light: bool = False) -> dict:

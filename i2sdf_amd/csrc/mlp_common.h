@@ -52,6 +52,14 @@ __host__ __device__ constexpr int sdf_fwd_stages(int H, int F, int PEC, int L, b
   if (full) c += op_chunks(F / 32, H / 8);
   return c / SC;
 }
+__host__ __device__ constexpr int sdf_fwd3_stages(int H, int PED, int L, bool has_skip) {
+  const int PE16 = cdiv(PED, 16);
+  int c = x3_op_chunks(H / 32, PE16);
+  for (int l = 1; l < L - 1; ++l) c += x3_op_chunks(H / 32, H / 16);
+  if (has_skip) c += x3_op_chunks(H / 32, H / 16 + PE16) - x3_op_chunks(H / 32, H / 16);
+  c += rowvec_chunks(H / 8, 1);
+  return c / SC;
+}
 __host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
 // reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space
 __host__ __device__ constexpr int sdf_rev_stages(int H, int PEC, int L, bool has_skip) {

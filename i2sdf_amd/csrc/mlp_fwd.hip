@@ -59,12 +59,66 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// bf16x3 variant of the sdf-only forward (x3.h): same result to fp32 rounding level at 3/8 of the matrix-pipe cycles.
+template <int H, int LF>
+__global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
+                                                        const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out) {
+  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NPE = PE16 * 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (skip_flag != nullptr && skip_flag[0] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
+  float px, py, pz;
+  fetch_point(ps, mc, px, py, pz);
+  float pe[NPE];
+  {
+    float full[PE<LF>::PEC * 8], pad[PE16 * 16];
+    pe_full<LF>(px, py, pz, full);
+#pragma unroll
+    for (int i = 0; i < PE16 * 16; ++i) pad[i] = (i < PED) ? full[i] : 0.f;
+    x3_select_pe<PE16>(pad, pe, hi);
+  }
+  WStream ws;
+  ws.begin(stream, lds, n_stages, tid);
+  f32x16 accP[NT], accN[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[nt][r] = 0.f;
+  dense_x3<NT, PE16, 0, NPE>(ws, accP, pe, accN, hi, tid);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
+  for (int l = 1; l < L - 1; ++l) {
+    if (l == skip) dense_x3<NT, KH16 + PE16, KH16, NPE>(ws, accP, pe, accN, hi, tid);
+    else dense_x3<NT, KH16, KH16, NPE>(ws, accP, pe, accN, hi, tid);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
+  }
+  float h[NT * 16];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accP[nt][r]);
+  float s[1];
+  rowvec_op<1, KC>(ws, h, s, tid);
+  if (valid && hi == 0) sdf_out[m] = s[0];
+}
+
 template <int H, int F, int LF>
 int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, const int* skip_flag, int64_t M, float* sdf_out,
                    float* feat_out, int64_t ld_feat, hipStream_t st) {
   const i2sdf_mlp_desc& d = p->sdf.d;
   const float* stream = packed + p->scale_floats + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
   const bool full = feat_out != nullptr;
+  if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && p->sdf.fwd3_chunks > 0) {
+    const float* s3 = packed + p->scale_floats + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;
+    const int ns3 = sdf_fwd3_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
+    launch_lds(sdf_fwd3_kernel<H, LF>, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st, s3, ns3, d.n_lin, d.skip_layer, points,
+               skip_flag, M, sdf_out);
+    return i2sdf_hip_check(hipGetLastError(), "sdf_forward (bf16x3) launch");
+  }
   const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (full)

@@ -73,6 +73,15 @@ void emit_dense_bwd(Builder& b, const NetPlan& np, int l, int KT, int NC, ColMap
   sw.row_off = row_off; sw.nrows = nrows;
   b.add(sw);
 }
+// bf16x3 forward op (x3.h): [NT*4 bias chunks][KC16 * NT * 3 split-plane chunks] padded to stages
+void emit_dense_fwd3(Builder& b, const NetPlan& np, int l, int NT, int KC16, ColMap cm, float mult) {
+  Seg sb = base_seg(np, l, SEG_BIAS);
+  sb.NT = NT; sb.KC = 4; sb.nchunks = NT * 4; sb.used = NT * 4;
+  b.add(sb);
+  Seg sw = base_seg(np, l, SEG_WFWD3);
+  sw.NT = NT; sw.KC = KC16; sw.used = KC16 * NT * 3; sw.nchunks = x3_op_chunks(NT, KC16) - NT * 4; sw.cm = cm; sw.mult = mult;
+  b.add(sw);
+}
 void emit_rowvec(Builder& b, const NetPlan& np, int l, int nrows, int KC, ColMap cm) {
   Seg sw = base_seg(np, l, SEG_ROWVEC);
   sw.NT = nrows; sw.KC = KC; sw.used = nrows * KC; sw.nchunks = nrows * KC; sw.cm = cm; sw.nrows = nrows;
@@ -131,6 +140,21 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
     emit_dense_bwd(b, np, l, KT, H / 8, cm, 0, d.out_dim[l]);
   }
   np.rev_chunks = b.chunk - np.rev_chunk0;
+  // bf16x3 forward stream (sampler / grid queries without features): hidden layers K-outer, then the fp32 sdf row.
+  // The 1/sqrt(2) of the skip concatenation is folded into that layer's weights.
+  np.fwd3_chunk0 = b.chunk;
+  if ((H / 32) % 2 == 0) {
+    const int PE16 = cdiv(PED, 16);
+    for (int l = 0; l < L - 1; ++l) {
+      ColMap cm{HUGE_SPLIT, 0, d.in_dim[l], 0, 0};
+      int KC16 = (l == 0) ? PE16 : H / 16;
+      float mult = 1.0f;
+      if (l == d.skip_layer) { cm = ColMap{H, 0, d.in_dim[l] - PED, d.in_dim[l] - PED, PED}; KC16 += PE16; mult = 0.70710678118654752440f; }
+      emit_dense_fwd3(b, np, l, H / 32, KC16, cm, mult);
+    }
+    emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  }
+  np.fwd3_chunks = b.chunk - np.fwd3_chunk0;
   return I2SDF_OK;
 }
 
@@ -238,6 +262,16 @@ extern "C" void i2sdf_plan_destroy(i2sdf_plan* p) {
   if (!p) return;
   if (p->d_segs) (void)hipFree(p->d_segs);
   delete p;
+}
+
+extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t value) {
+  if (!p) return I2SDF_EINVAL;
+  if (option == I2SDF_OPT_SDF_FWD_BF16X3) {
+    if (value && p->sdf.fwd3_chunks == 0) return I2SDF_EINVAL;      // no bf16x3 stream for this shape
+    p->sdf_fwd_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  return I2SDF_EINVAL;
 }
 
 extern "C" int64_t i2sdf_plan_pack_floats(const i2sdf_plan* p) {

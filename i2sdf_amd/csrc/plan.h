@@ -5,11 +5,12 @@
 #include <stdint.h>
 #include <vector>
 #include "../../include/i2sdf.h"
-#include "common.h"
+#include "x3.h"
 
 namespace i2sdf {
 
-enum SegType : int32_t { SEG_ZERO = 0, SEG_BIAS = 1, SEG_WFWD = 2, SEG_WBWD = 3, SEG_ROWVEC = 4, SEG_SCALAR = 5 };
+enum SegType : int32_t { SEG_ZERO = 0, SEG_BIAS = 1, SEG_WFWD = 2, SEG_WBWD = 3, SEG_ROWVEC = 4, SEG_SCALAR = 5,
+                         SEG_WFWD3 = 6 /* bf16x3 split planes, K-outer order (x3.h) */ };
 
 // Column map from a padded register-space index to a source column of weight_v:
 //   kp <  split : kp < valid0 ? base0 + kp : none
@@ -42,6 +43,7 @@ struct NetPlan {
   int64_t fwd_chunk0 = 0, fwd_chunks = 0;      // forward stream
   int64_t rev_chunk0 = 0, rev_chunks = 0;      // transposed / reverse stream
   int64_t rev_wsdf_chunk = 0;                  // where the igrad chain starts inside rev (sdf net)
+  int64_t fwd3_chunk0 = 0, fwd3_chunks = 0;    // bf16x3 forward stream of the hidden layers + sdf row (sdf net, x3.h)
   int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
   int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
 };
@@ -59,4 +61,5 @@ struct i2sdf_plan {
   int64_t total_chunks = 0;          // chunks after the scale region (+1 stage of slack for the DMA look-ahead)
   int64_t wgrad_floats = 0;
   int32_t H = 0, F = 0;              // sdf hidden width / feature size
+  int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
 };

@@ -1,0 +1,147 @@
+// bf16x3 split arithmetic for the no-gradient SDF forward (the sampler's inner loop).
+//
+// fp32 products at bf16 MFMA speed: every fp32 operand is split into three bf16 terms x = x0 + x1 + x2 (round-to-nearest
+// residuals, |x - x0 - x1 - x2| <= 2^-25 |x|), and W*h is accumulated in fp32 from the six partial products whose combined
+// order is <= 2:  W0h0, W0h1, W1h0, W0h2, W2h0, W1h1  (the dropped ones are <= 2^-24 |W||h|, i.e. at fp32 rounding level).
+// Six v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 32x32x16 block:
+// 192 instead of 512 matrix-pipe cycles.
+//
+// Loop structure (differs from the fp32 kernels, see common.h): K-outer.  All NT output tiles of a layer accumulate
+// concurrently (NT x 16 accumulator registers); the previous layer's PRE-activation accumulators stay live next to them, and
+// the B operand of k-chunk kc (16 reduction indices) is made on the fly -- read 8 accumulator registers, softplus100, split --
+// one k-chunk ahead of its use, dealt into the MFMA shadows.  Weights are split at pack time (SEG_WFWD3).
+//
+// Index maps (kg = lane>>5, element j = 0..7 of the 8 bf16 a lane holds):
+//   k-chunk kc, element j   <->  reduction index 16*kc + (j&3) + 8*(j>>2) + 4*kg
+//                           ==   D-layout tile kc/2, register 8*(kc&1) + j           (so accumulators feed straight back)
+// Stream of one op: [NT*4 bias chunks, fp32, D layout][for kc: for g < NT/2: for split s < 3: for e < 2: chunk of tile 2g+e]
+// padded to whole stages; a chunk = 64 lanes x 16 B = the A operand (32 rows x 16 k, one split plane) of one MFMA.
+#pragma once
+#include "common.h"
+
+namespace i2sdf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: low half = a, high half = b (RNE)
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+// two values -> their three split planes, packed pairwise
+__device__ __forceinline__ void split3_pair(float xa, float xb, unsigned& p0, unsigned& p1, unsigned& p2) {
+  p0 = pk_bf16(xa, xb);
+  float ra = xa - bf16_lo(p0), rb = xb - bf16_hi(p0);      // exact
+  p1 = pk_bf16(ra, rb);
+  ra -= bf16_lo(p1); rb -= bf16_hi(p1);                     // exact
+  p2 = pk_bf16(ra, rb);
+}
+
+// this lane's B-operand values of an input vector given in reduction-index order (NC16 k-chunks)
+template <int NC16>
+__device__ __forceinline__ void x3_select_pe(const float (&full)[NC16 * 16], float (&sel)[NC16 * 8], int hi) {
+#pragma unroll
+  for (int kc = 0; kc < NC16; ++kc)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int base = 16 * kc + (j & 3) + 8 * (j >> 2);
+      sel[8 * kc + j] = hi ? full[base + 4] : full[base];
+    }
+}
+
+// One K-outer bf16x3 layer:  acc[NT] = bias + W * src, src(kc) = 8 fp32 values per lane for k-chunk kc.
+//   KACC  k-chunks [0, KACC) come from softplus100(accP) (the previous layer's pre-activations, D layout),
+//         k-chunks [KACC, KC16) from pe[] (this lane's 8 values per k-chunk, already selected by lane half: x3_select_pe).
+template <int NT, int KC16, int KACC, int NPE>
+__device__ __forceinline__ void dense_x3(WStream& ws, const f32x16 (&accP)[NT], const float (&pe)[NPE], f32x16 (&acc)[NT], int hi,
+                                         int tid) {
+  static_assert(NT % 2 == 0, "tiles are processed in pairs");
+  static_assert((KC16 - KACC) * 8 <= NPE, "pe[] too short");
+  constexpr int NB = NT * 4, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
+  constexpr int TOT = round_up(NB + NW, SC), NS = TOT / SC, PFP = 2;
+  const int lane = tid & 63;
+  float v[8];
+  u32x4 bq[2][3];                       // split B operands of the current / next k-chunk
+  // unit u of the preparation of k-chunk kc: u < 8 -> value u ; u >= 8 -> split of the value pair u-8
+  auto prep = [&](int kc, int u, u32x4 (&b)[3]) {
+    if (kc >= KC16) return;
+    if (u < 8) {
+      if (kc < KACC) v[u] = softplus100(accP[kc >> 1][8 * (kc & 1) + u]);
+      else v[u] = pe[8 * (kc - KACC) + u];
+    } else {
+      const int i = u - 8;
+      unsigned p0, p1, p2;
+      split3_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
+      b[0][i] = p0; b[1][i] = p1; b[2][i] = p2;
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+    // ---- bias chunks of this stage (fp32, D layout)
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < NB) {
+        const int nt = c / 4, q = c % 4;
+        const f32x4 b = __builtin_bit_cast(f32x4, cur[j * 64]);
+        acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+      }
+    }
+    // ---- weight chunk pairs of this stage: pair slots [p0, p1) of 16
+    const int p0 = (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0;
+    const int p1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2;
+    u32x4 ring[PFP][2];
+#pragma unroll
+    for (int i = 0; i < PFP; ++i)
+      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+    bool issued = false;
+#pragma unroll
+    for (int jp = 0; jp < SC / 2; ++jp) {
+      if (jp >= p0 && jp < p1) {
+        const int w = (s * SC + 2 * jp - NB) / 2;          // pair index inside the op
+        const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
+        const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
+        if (jp + PFP < p1) {
+          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
+          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
+        }
+        const u32x4 (&b)[3] = bq[kc & 1];
+        acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
+        acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
+        if (sp < 2) {
+          acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
+          acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
+        }
+        if (sp == 0) {
+          acc[nt] = mfma_bf16(a0, b[2], acc[nt]);
+          acc[nt + 1] = mfma_bf16(a1, b[2], acc[nt + 1]);
+        }
+        if (!issued) { ws.advance_issue(tid); issued = true; }       // next stage's DMA in the shadow of the first MFMAs
+        // this pair's share of the preparation of k-chunk kc+1: 12 units over the PPK pairs of a k-chunk
+        {
+          const int pi = w % PPK;
+#pragma unroll
+          for (int u = 0; u < 12; ++u)
+            if (u * PPK / 12 == pi) prep(kc + 1, u, bq[(kc + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!issued) ws.advance_issue(tid);
+  }
+}
+
+}  // namespace i2sdf

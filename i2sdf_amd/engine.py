@@ -27,6 +27,9 @@ class RenderEngine:
         self.wgrad_floats = int(self._lib.i2sdf_plan_wgrad_floats(plan))
         self.packed = torch.zeros(self.pack_floats, dtype=torch.float32, device=self.device)
         self.F = cfg.feature_size
+        self.sdf_forward_bf16x3 = False
+        if cfg.bf16x3 and cfg.sdf.hidden % 64 == 0:
+            self.set_sdf_forward_bf16x3(True)
         sc = cfg.sampler
         self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
                                   N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
@@ -93,6 +96,12 @@ class RenderEngine:
         """weight-norm reparametrisation + stream packing; call after every parameter update."""
         assert flat_params.is_cuda and flat_params.dtype == torch.float32 and flat_params.numel() == self.layout.n_params
         L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
+
+    def set_sdf_forward_bf16x3(self, on: bool):
+        """Evaluate the sdf-only forward (sampler passes, grid queries) in bf16x3 split arithmetic (include/i2sdf.h,
+        I2SDF_OPT_SDF_FWD_BF16X3): fp32-level accuracy on the bf16 matrix pipe."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SDF_FWD_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
+        self.sdf_forward_bf16x3 = bool(on)
 
     # -- SDF queries ---------------------------------------------------------------------------
     def sdf_forward(self, points: torch.Tensor, want_features: bool = False):

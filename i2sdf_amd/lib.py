@@ -49,6 +49,9 @@ class RayBatch(C.Structure):
                                           "depth_mask", "normal_mask")]
 
 
+OPT_SDF_FWD_BF16X3 = 1
+
+
 class I2SDFError(RuntimeError):
     pass
 
@@ -63,6 +66,7 @@ SIGNATURES = {
     "i2sdf_last_hip_error": (C.c_char_p, []),
     "i2sdf_plan_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(_P)]),
     "i2sdf_plan_destroy": (None, [_P]),
+    "i2sdf_plan_set_option": (C.c_int, [_P, _I32, _I32]),
     "i2sdf_plan_pack_floats": (_I64, [_P]),
     "i2sdf_plan_wgrad_floats": (_I64, [_P]),
     "i2sdf_pack_weights": (C.c_int, [_P, _P, _P, _P]),

@@ -76,6 +76,13 @@ const char* i2sdf_last_hip_error(void);    /* thread-local text of the last HIP 
 
 int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out);
 void i2sdf_plan_destroy(i2sdf_plan* plan);
+/* Plan options (host side, takes effect on the next launch).
+ *   I2SDF_OPT_SDF_FWD_BF16X3: evaluate the sdf-only forward (i2sdf_sdf_forward without features, and the SDF passes inside
+ *   i2sdf_sample_rays) in bf16x3 split arithmetic: every fp32 operand is split into three bf16 terms and the six leading
+ *   partial products are accumulated in fp32 on the bf16 matrix pipe -- results agree with the fp32 path to fp32 rounding
+ *   level (same 1e-4 parity bar) at 3/8 of the matrix-pipe cycles.  Default 0 (plain fp32 MFMA). */
+#define I2SDF_OPT_SDF_FWD_BF16X3 1
+int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
 /* floats of the effective-weight gradient buffer i2sdf_weightnorm_backward consumes */

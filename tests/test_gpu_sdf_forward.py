@@ -48,3 +48,29 @@ def test_sdf_forward_golden(golden, name, skip):
     sdf, feat = eng.sdf_forward(t(z["x"]).cuda(), want_features=True)
     out = torch.cat([sdf, feat], 1).cpu()
     assert_close(out, z["out"], 2e-5, "ImplicitNetwork.forward")
+
+
+@pytest.mark.parametrize("which", ["synthetic", "light", "plumbing", "plumbing_skip"])
+def test_sdf_forward_bf16x3(which):
+    """The bf16x3 split-arithmetic forward (x3.h) against the fp64 oracle at the SAME bar as the fp32 MFMA kernel, and
+    against the fp32 kernel itself."""
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    if which in ("synthetic", "light"):
+        ocfg, conf = orc.synthetic_cfg(which == "light"), synthetic_conf(which == "light")
+    else:
+        ocfg, conf = orc.plumbing_cfg(skip=which.endswith("skip")), plumbing_conf(skip=which.endswith("skip"))
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=3), 0.05, seed=4)
+    eng = _engine(conf, sd)
+    M = 256 * 128 + 333
+    g = torch.Generator().manual_seed(17)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.5
+    eng.set_sdf_forward_bf16x3(False)
+    f32 = eng.sdf_forward(x.cuda()).cpu()
+    eng.set_sdf_forward_bf16x3(True)
+    x3 = eng.sdf_forward(x.cuda()).cpu()
+    idx = torch.cat([torch.arange(0, 3000), torch.arange(M - 500, M)])
+    ref = orc.sdf_forward({k: v.double() for k, v in sd.items()}, ocfg.sdf, x.double()[idx])[:, :1]
+    e32 = assert_close(f32[idx], ref, 1e-5, "sdf (fp32 MFMA)")
+    e3 = assert_close(x3[idx], ref, 1e-5, "sdf (bf16x3)")
+    print(f"max-norm relative error vs fp64: fp32 MFMA {e32:.2e}, bf16x3 {e3:.2e}")
+    assert_close(x3, f32, 1e-5, "bf16x3 vs fp32 kernel, all points")
