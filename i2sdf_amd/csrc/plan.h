@@ -61,5 +61,6 @@ struct i2sdf_plan {
   int64_t total_chunks = 0;          // chunks after the scale region (+1 stage of slack for the DMA look-ahead)
   int64_t wgrad_floats = 0;
   int32_t H = 0, F = 0;              // sdf hidden width / feature size
+  int32_t wgrad_bf16x3 = 0;          // I2SDF_OPT_WGRAD_BF16X3: full 256x256 weight-gradient blocks in bf16x3 split arithmetic
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
 };

@@ -4,7 +4,7 @@
 // the _weight_norm backward.  X, Y are point-major ([Mp][ld]); a wave owns a 128x128 output tile and streams
 // point pairs straight from HBM into MFMA operands (fp32 32x32x2: the reduction index of the MFMA is the point).
 #include <algorithm>
-#include "plan.h"
+#include "mlp_common.h"
 
 using namespace i2sdf;
 
@@ -149,6 +149,146 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2) per block and chunk.
+// 16 points (one MFMA k-group of v_mfma_f32_32x32x16_bf16) form a stage: the four waves DMA the 16 x 256 slices of both
+// operands into LDS (ring of three stages, each slice is consumed by two waves), read their halves back in MFMA operand
+// layout (lane = column quad 4i..4i+3 x 8 consecutive points), split every fp32 value into three bf16 terms and run the six
+// leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
+// The splits of stage s+1 are dealt into the MFMA shadows of stage s.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W3_PTS = 16;
+constexpr int W3_STAGE_FLOATS = 2 * W3_PTS * 256;        // A and B slices: 32 KB
+constexpr int W3_LDS_BYTES = 3 * W3_STAGE_FLOATS * 4;
+
+__global__ __launch_bounds__(256) void wgrad3_kernel(WgLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
+  const WgTask& t = L.t[blockIdx.y];
+  const int64_t chunk = blockIdx.x;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = t.has_bias != 0 && wb == 0;
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const WgJob job = t.j[jb];
+    const int64_t m_lo = chunk * WG_CH;
+    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
+    if (m_hi <= m_lo) continue;
+    const int rows = (int)(m_hi - m_lo);
+    const int nst = (rows + W3_PTS - 1) / W3_PTS;
+    // DMA: wave w fetches operand (w>>1), column half (w&1); lane (i32, kg) addresses row 8*kg + j, columns 128*half + 4*i32
+    const float* dbase = ((w >> 1) ? job.B : job.A) + m_lo * ((w >> 1) ? job.ldb : job.lda) + 128 * (w & 1) + 4 * i32;
+    const int dld = (w >> 1) ? job.ldb : job.lda;
+    auto issue = [&](int s) {
+      if (s >= nst) return;
+      float* dst = lds + (s % 3) * W3_STAGE_FLOATS + (w * 8) * 256;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int row = s * W3_PTS + 8 * kg + j;
+        row = row < rows ? row : rows - 1;                       // clamp: rows beyond the chunk are masked after the read
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dbase + (int64_t)row * dld),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+      }
+    };
+    auto rd = [&](int s, int op, int half, int j) -> f32x4 {
+      return *reinterpret_cast<const f32x4*>(lds + (s % 3) * W3_STAGE_FLOATS + (op * 16 + half * 8 + j) * 256 + lane * 4);
+    };
+    // rows of stage s that lie beyond the chunk read as zero (B) / do not count (bias sums of A)
+    auto rdB = [&](int s, int j) -> f32x4 {
+      f32x4 x = rd(s, 1, wb, j);
+      if ((s + 1) * W3_PTS > rows && s * W3_PTS + 8 * kg + j >= rows) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (t.relu_b) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      return x;
+    };
+    auto rdA = [&](int s, int j) -> f32x4 {
+      const f32x4 x = rd(s, 0, wa, j);
+      if (do_bias && jb == 0) {
+        const bool ok = !((s + 1) * W3_PTS > rows && s * W3_PTS + 8 * kg + j >= rows);
+        if (ok) { bsum[0] += x.x; bsum[1] += x.y; bsum[2] += x.z; bsum[3] += x.w; }
+      }
+      return x;
+    };
+    unsigned Apl[2][4][3][4];    // [buffer][tile ta][plane][point pair]: 8 bf16 = the lane's 8 points
+    unsigned Bpl[2][3][4];       // [tb & 1][plane][point pair]
+    auto q4 = [](const unsigned (&d)[4]) { return u32x4{d[0], d[1], d[2], d[3]}; };
+    f32x4 Braw[2][8];            // [buffer][point j]: 4 tb values
+    __syncthreads();             // the previous job's LDS reads are done
+    issue(0); issue(1);
+    __syncthreads();             // stage 0 (and 1) landed
+    // ---- prologue (exposed once per job): planes of stage 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 lo = rdA(0, 2 * i), hi_ = rdA(0, 2 * i + 1);
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta) split3_pair(lo[ta], hi_[ta], Apl[0][ta][0][i], Apl[0][ta][1][i], Apl[0][ta][2][i]);
+      Braw[0][2 * i] = rdB(0, 2 * i); Braw[0][2 * i + 1] = rdB(0, 2 * i + 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3_pair(Braw[0][2 * i][0], Braw[0][2 * i + 1][0], Bpl[0][0][i], Bpl[0][1][i], Bpl[0][2][i]);
+    // ---- one stage: P = buffer holding this stage's planes
+    auto stage = [&](int s, auto Pc) {
+      constexpr int P = decltype(Pc)::value;
+      if (s > 0) __syncthreads();          // stage s+1 landed (issued one stage ago); everyone is done with stage s-1
+      issue(s + 2);
+      const bool more = s + 1 < nst;
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        // six leading partial products, tiles interleaved so that consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const int sa = (p == 2 || p == 5) ? 1 : (p == 4 ? 2 : 0);
+          const int sb = (p == 1 || p == 5) ? 1 : (p == 3 ? 2 : 0);
+#pragma unroll
+          for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(q4(Apl[P][ta][sa]), q4(Bpl[tb & 1][sb]), acc[ta][tb]);
+        }
+        if (more) {                        // planes of stage s+1: point pair tb of every A tile, and two rows of B
+          const f32x4 lo = rdA(s + 1, 2 * tb), hi_ = rdA(s + 1, 2 * tb + 1);
+#pragma unroll
+          for (int ta = 0; ta < 4; ++ta)
+            split3_pair(lo[ta], hi_[ta], Apl[P ^ 1][ta][0][tb], Apl[P ^ 1][ta][1][tb], Apl[P ^ 1][ta][2][tb]);
+          Braw[P ^ 1][2 * tb] = rdB(s + 1, 2 * tb); Braw[P ^ 1][2 * tb + 1] = rdB(s + 1, 2 * tb + 1);
+        }
+        if (tb < 3) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            split3_pair(Braw[P][2 * i][tb + 1], Braw[P][2 * i + 1][tb + 1], Bpl[(tb + 1) & 1][0][i], Bpl[(tb + 1) & 1][1][i],
+                        Bpl[(tb + 1) & 1][2][i]);
+        } else if (more) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            split3_pair(Braw[P ^ 1][2 * i][0], Braw[P ^ 1][2 * i + 1][0], Bpl[0][0][i], Bpl[0][1][i], Bpl[0][2][i]);
+        }
+      }
+    };
+    for (int s = 0; s < nst; s += 2) {
+      stage(s, std::integral_constant<int, 0>{});
+      if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{});
+    }
+  }
+  float* out = L.partials + chunk * L.chunk_stride;
+  const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+      *reinterpret_cast<f32x4*>(out + toff + (int64_t)(4 * ri + ta) * t.ldo + 4 * i32) = v;
+    }
+  if (do_bias) {
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) bsum[ta] += __shfl_xor(bsum[ta], 32);
+    if (kg == 0) *reinterpret_cast<f32x4*>(out + t.bias_off + wa * 128 + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
+  }
+}
+
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
 struct WnLayer {
   int64_t off_v, off_g, off_bias, blk_off, bias_blk_off;
@@ -224,6 +364,7 @@ struct Src { const float* p; int ld; int w; };     // a [Mp][ld] matrix and the 
 
 struct TaskList {
   std::vector<WgTask> tasks;
+  bool quads = false;        // emit one 256x256 task (bf16x3 kernel) where both operands are 256 wide
   // Emit the tiles of one weight block.  rows: segments of A (one per source, stacked in block rows at row0[i]);
   // cols: segments of B.  job 0 = (A0[i], B0[k]) over m0 points, job 1 = (A1[i], B1[k]) over m1 points (optional).
   void add_block(int64_t blk_off, int ldo, int64_t bias_off, const std::vector<Src>& A0, const std::vector<Src>& A1,
@@ -231,8 +372,27 @@ struct TaskList {
                  int64_t m1, bool relu_b) {
     int col0 = 0;
     for (size_t k = 0; k < B0.size(); ++k) {
+      if (quads && B0[k].w == 256) {
+        for (size_t i = 0; i < A0.size(); ++i) {
+          if (A0[i].w != 256) continue;
+          WgTask t{};
+          t.j[0] = WgJob{A0[i].p, B0[k].p, A0[i].ld, B0[k].ld, 256, 256, mA0[i]};
+          t.njobs = 1;
+          if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
+            t.j[1] = WgJob{A1[i].p, B1[k].p, A1[i].ld, B1[k].ld, 256, 256, m1};
+            t.njobs = 2;
+          }
+          t.relu_b = relu_b ? 1 : 0;
+          t.has_bias = (k == 0) ? 1 : 0;
+          t.rows_store = 256; t.cols_store = 256; t.ldo = ldo;
+          t.out_off = blk_off + (int64_t)row0[i] * ldo + col0;
+          t.bias_off = bias_off + row0[i];
+          tasks.push_back(t);
+        }
+      }
       for (int ct = 0; ct * 128 < B0[k].w; ++ct) {
         for (size_t i = 0; i < A0.size(); ++i) {
+          if (quads && B0[k].w == 256 && A0[i].w == 256) continue;      // covered by the quad task above
           for (int rt = 0; rt * 128 < A0[i].w; ++rt) {
             WgTask t{};
             const int aw = std::min(128, A0[i].w - rt * 128), bw = std::min(128, B0[k].w - ct * 128);
@@ -291,6 +451,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   if (n_chunks > n_chunks_cap) return I2SDF_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   TaskList tl;
+  tl.quads = p->wgrad_bf16x3 != 0;
   {  // ---- SDF net
     const NetPlan& np = p->sdf;
     const i2sdf_mlp_desc& d = np.d;
@@ -344,8 +505,10 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   }
   (void)light_first;
   // group the tiles by operand shape (narrow operands run 4x / 2x fewer MFMAs per point pair), longest first inside a group
-  auto variant = [](const WgTask& x) { return x.j[0].a_w <= 32 ? 1 : (x.j[0].b_w <= 32 ? 2 : (x.j[0].b_w <= 64 ? 3 : 0)); };
-  for (int var = 0; var < 4; ++var) {
+  auto variant = [](const WgTask& x) {
+    return x.j[0].a_w == 256 ? 4 : (x.j[0].a_w <= 32 ? 1 : (x.j[0].b_w <= 32 ? 2 : (x.j[0].b_w <= 64 ? 3 : 0)));
+  };
+  for (int var = 4; var >= 0; --var) {
     std::vector<WgTask> sel;
     for (const WgTask& x : tl.tasks) if (variant(x) == var) sel.push_back(x);
     std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
@@ -355,7 +518,11 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       for (int i = 0; i < L.n; ++i) L.t[i] = sel[off + i];
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
       dim3 grid((unsigned)n_chunks, (unsigned)L.n);
-      if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
+      if (var == 4) {
+        (void)hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
+        wgrad3_kernel<<<grid, 256, W3_LDS_BYTES, st>>>(L);
+      }
+      else if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       else if (var == 1) wgrad_kernel<1, 0><<<grid, 64, 0, st>>>(L);
       else if (var == 2) wgrad_kernel<0, 1><<<grid, 64, 0, st>>>(L);
       else wgrad_kernel<0, 2><<<grid, 64, 0, st>>>(L);

@@ -50,6 +50,7 @@ class RayBatch(C.Structure):
 
 
 OPT_SDF_FWD_BF16X3 = 1
+OPT_WGRAD_BF16X3 = 2
 
 
 class I2SDFError(RuntimeError):

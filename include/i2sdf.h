@@ -82,6 +82,9 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   partial products are accumulated in fp32 on the bf16 matrix pipe -- results agree with the fp32 path to fp32 rounding
  *   level (same 1e-4 parity bar) at 3/8 of the matrix-pipe cycles.  Default 0 (plain fp32 MFMA). */
 #define I2SDF_OPT_SDF_FWD_BF16X3 1
+/*   I2SDF_OPT_WGRAD_BF16X3: the 256x256 blocks of i2sdf_weight_grads in the same split arithmetic (both operands are split
+ *   on the fly); narrower blocks stay on the fp32 MFMA kernel.  Default 0. */
+#define I2SDF_OPT_WGRAD_BF16X3 2
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
