@@ -32,6 +32,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--bf16x3", type=int, default=-1,
+                    help="bit mask of the kernels that run in bf16x3 split arithmetic (1 sampler forward, 2 weight gradients, "
+                         "4 training forward); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
     ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
 
@@ -115,9 +118,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step(0)                                   # builds the engine (and the flat parameter buffer) the way a trainer would
+    eng = net._engine_for(dev)
+    if args.bf16x3 >= 0:
+        eng.set_sdf_forward_bf16x3(bool(args.bf16x3 & 1))
+        eng.set_wgrad_bf16x3(bool(args.bf16x3 & 2))
+        eng.set_train_forward_bf16x3(bool(args.bf16x3 & 4))
     for i in range(args.warmup):
         step(i)
-    eng = net._engine_for(dev)
     fence()
     eng.start_timing()
     t0 = time.perf_counter()

@@ -3,12 +3,18 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p ../lib ../lib/obj
+# the K-outer bf16x3 ops (x3.h) are fully unrolled stage loops of several thousand instructions: lift the pragma-unroll cap,
+# otherwise the loop stays rolled, its register arrays are indexed dynamically and land in scratch
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result"
+X3FLAGS="-mllvm -pragma-unroll-threshold=1000000"     # only where the bf16x3 training kernels live
 pids=()
 for f in plan.cpp pack.hip mlp_fwd.hip mlp_train.hip render.hip mlp_bwd.hip wgrad.hip sampler.hip loss.hip "$@"; do
   o=../lib/obj/$(basename ${f%.*}).o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ plan.h -nt "$o" ] || [ mlp_common.h -nt "$o" ] || [ ../../include/i2sdf.h -nt "$o" ]; then
-    ( hipcc $FLAGS -x hip -c "$f" -o "$o" ) &
+  stale=0
+  for h in "$f" *.h ../../include/i2sdf.h build.sh; do [ "$h" -nt "$o" ] && stale=1; done
+  if [ ! -f "$o" ] || [ $stale = 1 ]; then
+    extra=""; [ "$f" = mlp_train.hip ] && extra="$X3FLAGS"
+    ( hipcc $FLAGS $extra -x hip -c "$f" -o "$o" ) &
     pids+=($!)
   fi
 done

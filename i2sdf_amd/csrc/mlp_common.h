@@ -60,6 +60,18 @@ __host__ __device__ constexpr int sdf_fwd3_stages(int H, int PED, int L, bool ha
   c += rowvec_chunks(H / 8, 1);
   return c / SC;
 }
+__host__ __device__ constexpr int sdf_fwd3_train_stages(int H, int F, int PED, int L, bool has_skip, bool full) {
+  return sdf_fwd3_stages(H, PED, L, has_skip) + (full ? x3_op_chunks(F / 32, H / 16) / SC : 0);
+}
+__host__ __device__ constexpr int x3_bwd_chunks(int KT, int KC16) { return round_up(KC16 * KT * 3, SC); }
+__host__ __device__ constexpr int sdf_rev3_stages(int H, int PEC, int L, bool has_skip) {
+  const int PT = cdiv(PEC * 8, 32);
+  int c = rowvec_chunks(H / 8, 1);
+  for (int l = L - 2; l >= 1; --l) c += x3_bwd_chunks(H / 32, H / 16);
+  if (has_skip) c += x3_bwd_chunks(PT, H / 16);
+  c += x3_bwd_chunks(PT, H / 16);
+  return c / SC;
+}
 __host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
 // reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space
 __host__ __device__ constexpr int sdf_rev_stages(int H, int PEC, int L, bool has_skip) {

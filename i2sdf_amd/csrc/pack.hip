@@ -103,6 +103,32 @@ __global__ __launch_bounds__(256) void pack_kernel(const Seg* __restrict__ segs,
         }
       }
       out = __builtin_bit_cast(f32x4, u32x4{q[0], q[1], q[2], q[3]});
+    } else if (s.type == SEG_WBWD3) {
+      // transposed: A-operand row = input column 32*kt + i32 of the layer, reduction index = output row (x3.h k-order)
+      const int G = s.NT / 2, w = c >> 1, e = c & 1;
+      const int kc = w / (3 * G), g = (w / 3) % G, sp = w % 3;
+      const int col = map_col(s.cm, 32 * (2 * g + e) + i32);
+      unsigned q[4] = {0u, 0u, 0u, 0u};
+      if (col >= 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int j = 2 * i + h2;
+            const int r = 16 * kc + (j & 3) + 8 * (j >> 2) + 4 * hi;
+            x[h2] = 0.f;
+            if (r < s.nrows) {
+              const int row = s.row_off + r;
+              x[h2] = params[s.off_v + (int64_t)row * s.cols + col] * scale[s.scale_off + row] * s.mult;
+            }
+          }
+          unsigned p0, p1, p2;
+          split3_pair(x[0], x[1], p0, p1, p2);
+          q[i] = sp == 0 ? p0 : (sp == 1 ? p1 : p2);
+        }
+      }
+      out = __builtin_bit_cast(f32x4, u32x4{q[0], q[1], q[2], q[3]});
     } else if (s.type == SEG_WBWD) {
       const int kt = c / s.KC, nc = c % s.KC;
       const int col = map_col(s.cm, 32 * kt + i32);

@@ -82,6 +82,13 @@ void emit_dense_fwd3(Builder& b, const NetPlan& np, int l, int NT, int KC16, Col
   sw.NT = NT; sw.KC = KC16; sw.used = KC16 * NT * 3; sw.nchunks = x3_op_chunks(NT, KC16) - NT * 4; sw.cm = cm; sw.mult = mult;
   b.add(sw);
 }
+// transposed bf16x3 op (no bias): KT tiles over the layer's input space, reduction over its output rows in 16-chunks
+void emit_dense_bwd3(Builder& b, const NetPlan& np, int l, int KT, int KC16, ColMap cm, int row_off, int nrows, float mult) {
+  Seg sw = base_seg(np, l, SEG_WBWD3);
+  sw.NT = KT; sw.KC = KC16; sw.used = KC16 * KT * 3; sw.nchunks = round_up(KC16 * KT * 3, SC); sw.cm = cm; sw.mult = mult;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
 void emit_rowvec(Builder& b, const NetPlan& np, int l, int nrows, int KC, ColMap cm) {
   Seg sw = base_seg(np, l, SEG_ROWVEC);
   sw.NT = nrows; sw.KC = KC; sw.used = nrows * KC; sw.nchunks = nrows * KC; sw.cm = cm; sw.nrows = nrows;
@@ -153,8 +160,34 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
       emit_dense_fwd3(b, np, l, H / 32, KC16, cm, mult);
     }
     emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    if (F > 0 && (F / 32) % 2 == 0) {          // feature rows (training forward)
+      Seg sb = base_seg(np, L - 1, SEG_BIAS);
+      sb.NT = F / 32; sb.KC = 4; sb.nchunks = F / 32 * 4; sb.used = sb.nchunks; sb.row_off = 1; sb.nrows = F;
+      b.add(sb);
+      Seg sw = base_seg(np, L - 1, SEG_WFWD3);
+      sw.NT = F / 32; sw.KC = H / 16; sw.used = (H / 16) * (F / 32) * 3; sw.nchunks = x3_op_chunks(F / 32, H / 16) - F / 32 * 4;
+      sw.cm = ColMap{HUGE_SPLIT, 0, H, 0, 0}; sw.row_off = 1; sw.nrows = F;
+      b.add(sw);
+    }
   }
   np.fwd3_chunks = b.chunk - np.fwd3_chunk0;
+  // bf16x3 reverse stream (d sdf/dx chain): [w_sdf row][W_{L-2}^T] ... [W_0^T]; skip factor folded into the weights
+  np.rev3_chunk0 = b.chunk;
+  if ((H / 32) % 2 == 0) {
+    const int PT = cdiv(PEC * 8, 32);
+    emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    for (int l = L - 2; l >= 0; --l) {
+      // the skip layer's transposed op is emitted as two ops over the same reduction: hidden part, then PE part
+      if (l == d.skip_layer) {
+        const float rs2 = 0.70710678118654752440f;
+        emit_dense_bwd3(b, np, l, H / 32, H / 16, ColMap{HUGE_SPLIT, 0, d.in_dim[l] - PED, 0, 0}, 0, d.out_dim[l], rs2);
+        emit_dense_bwd3(b, np, l, PT, H / 16, ColMap{HUGE_SPLIT, d.in_dim[l] - PED, PED, 0, 0}, 0, d.out_dim[l], rs2);
+      } else {
+        emit_dense_bwd3(b, np, l, (l == 0) ? PT : H / 32, H / 16, ColMap{HUGE_SPLIT, 0, d.in_dim[l], 0, 0}, 0, d.out_dim[l], 1.0f);
+      }
+    }
+  }
+  np.rev3_chunks = b.chunk - np.rev3_chunk0;
   return I2SDF_OK;
 }
 
@@ -269,6 +302,11 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
   if (option == I2SDF_OPT_SDF_FWD_BF16X3) {
     if (value && p->sdf.fwd3_chunks == 0) return I2SDF_EINVAL;      // no bf16x3 stream for this shape
     p->sdf_fwd_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  if (option == I2SDF_OPT_TRAIN_FWD_BF16X3) {
+    if (value && (p->sdf.rev3_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
+    p->train_fwd_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_WGRAD_BF16X3) {

@@ -144,4 +144,145 @@ __device__ __forceinline__ void dense_x3(WStream& ws, const f32x16 (&accP)[NT], 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Generalised K-outer bf16x3 op for the training kernels:  acc[NT] (+)= W * src.
+//   BIAS  : the stream starts with NT*4 fp32 bias chunks that initialise acc; otherwise acc is used as the caller left it
+//           (zeroed, or holding a running sum such as pbar) and the stream holds weight chunks only.
+//   Src   : where the B operand comes from.  `float value(kc, u)` returns value u (0..7) of k-chunk kc for this lane --
+//           reduction index 16*kc + (u&3) + 8*(u>>2) + 4*hi -- and `void done(kc, v)` is called once all eight are known
+//           (global stores of the saved tensors).  Both are dealt into the MFMA shadows one k-chunk ahead of their use;
+//           `void ahead(kc)` is called two k-chunks ahead (issue global loads there).
+// ---------------------------------------------------------------------------------------------
+template <int NT, int KC16, bool BIAS, class Src>
+__device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io)[NT], int tid) {
+  f32x16 acc[NT];
+  if (!BIAS) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_io[nt];
+  }
+  static_assert(NT % 2 == 0, "tiles are processed in pairs");
+  constexpr int NB = BIAS ? NT * 4 : 0, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
+  constexpr int TOT = round_up(NB + NW, SC), NS = TOT / SC, PFP = 2;
+  const int lane = tid & 63;
+  float v[8];
+  u32x4 bq[2][3];
+  auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
+    if (kc >= KC16) return;
+    if (u == 0 && kc + 1 < KC16) src.ahead(kc + 1);
+    if (u < 8) v[u] = src.value(kc, u);
+    else {
+      if (u == 8) src.done(kc, v);
+      const int i = u - 8;
+      unsigned p0, p1, p2;
+      split3_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
+      b[0][i] = p0; b[1][i] = p1; b[2][i] = p2;
+    }
+  };
+  src.ahead(0);
+#pragma unroll
+  for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+#pragma unroll
+    for (int j = 0; j < SC; ++j) {
+      const int c = s * SC + j;
+      if (c < NB) {
+        const int nt = c / 4, q = c % 4;
+        const f32x4 b = __builtin_bit_cast(f32x4, cur[j * 64]);
+        acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
+      }
+    }
+    const int p0 = (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0;
+    const int p1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2;
+    u32x4 ring[PFP][2];
+#pragma unroll
+    for (int i = 0; i < PFP; ++i)
+      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+    bool issued = false;
+#pragma unroll
+    for (int jp = 0; jp < SC / 2; ++jp) {
+      if (jp >= p0 && jp < p1) {
+        const int w = (s * SC + 2 * jp - NB) / 2;
+        const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
+        const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
+        if (jp + PFP < p1) {
+          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
+          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
+        }
+        const u32x4 (&b)[3] = bq[kc & 1];
+        acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
+        acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
+        if (sp < 2) {
+          acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
+          acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
+        }
+        if (sp == 0) {
+          acc[nt] = mfma_bf16(a0, b[2], acc[nt]);
+          acc[nt + 1] = mfma_bf16(a1, b[2], acc[nt + 1]);
+        }
+        if (!issued) { ws.advance_issue(tid); issued = true; }
+        {
+          const int pi = w % PPK;
+#pragma unroll
+          for (int u = 0; u < 12; ++u)
+            if (u * PPK / 12 == pi) prep(kc + 1, u, bq[(kc + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (!issued) ws.advance_issue(tid);
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc_io[nt] = acc[nt];
+}
+
+// B-operand sources -------------------------------------------------------------------------------------------------
+// softplus100 of the previous layer's pre-activations (D layout) for k-chunks < KACC, this lane's PE values beyond;
+// stores the activations (h row of the saved tensor) as they are produced
+template <int NT, int KACC, int NPE>
+struct X3FwdSrc {
+  const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid;
+  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ float value(int kc, int u) {
+    if (kc < KACC) return softplus100(accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u]);
+    return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+    if (kc < KACC && hrow != nullptr && valid) {
+      *reinterpret_cast<f32x4*>(hrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(hrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+};
+// values held in registers in the fp32 kernels' B layout (register 4*c + t <-> index 8*c + 4*hi + t)
+template <int NREG>
+struct X3RegSrc {
+  const float (&r)[NREG];
+  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ float value(int kc, int u) { return r[8 * kc + u]; }
+  __device__ __forceinline__ void done(int, const float (&)[8]) {}
+};
+// reverse chain: abar = (previous op's accumulators) * sigma(h) with h re-read from the saved tensor; stores abar
+template <int NT>
+struct X3RevSrc {
+  const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid;
+  f32x4 hq[3][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    hq[kc % 3][0] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 4 * hi);
+    hq[kc % 3][1] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 8 + 4 * hi);
+  }
+  __device__ __forceinline__ float value(int kc, int u) {
+    return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % 3][u >> 2][u & 3]);
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+    if (abrow != nullptr && valid) {
+      *reinterpret_cast<f32x4*>(abrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(abrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+  }
+};
+
 }  // namespace i2sdf

@@ -85,6 +85,8 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
 /*   I2SDF_OPT_WGRAD_BF16X3: the 256x256 blocks of i2sdf_weight_grads in the same split arithmetic (both operands are split
  *   on the fly); narrower blocks stay on the fp32 MFMA kernel.  Default 0. */
 #define I2SDF_OPT_WGRAD_BF16X3 2
+/*   I2SDF_OPT_TRAIN_FWD_BF16X3: the full workgroups of i2sdf_sdf_forward_grad (256-wide nets) in the same arithmetic. */
+#define I2SDF_OPT_TRAIN_FWD_BF16X3 4
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
