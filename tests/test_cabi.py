@@ -64,8 +64,9 @@ def test_plan_layout_sizes(lib):
         if n_params:
             assert lay.n_params == n_params          # SURVEY.md appendix B [probed on the reference]
         pack = h.i2sdf_plan_pack_floats(plan)
-        # forward + transposed streams (+ padding) hold every weight about twice
-        assert 2 * lay.n_params * 0.9 < pack < 2 * lay.n_params * 1.6 + 64 * 8192
+        # fp32 forward + transposed streams hold every weight about twice; the bf16x3 forward / reverse streams of the SDF net
+        # add 1.5x each; plus stage padding
+        assert 2 * lay.n_params * 0.9 < pack < 5 * lay.n_params * 1.2 + 128 * 8192
         assert h.i2sdf_plan_wgrad_floats(plan) >= lay.n_params - 1
         h.i2sdf_plan_destroy(plan)
 
