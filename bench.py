@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--bf16x3", type=int, default=-1,
                     help="bit mask of the kernels that run in bf16x3 split arithmetic (1 sampler forward, 2 weight gradients, "
-                         "4 training forward); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
+                         "4 training forward, 8 SDF backward); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
     ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
 
@@ -124,6 +124,7 @@ def main():
         eng.set_sdf_forward_bf16x3(bool(args.bf16x3 & 1))
         eng.set_wgrad_bf16x3(bool(args.bf16x3 & 2))
         eng.set_train_forward_bf16x3(bool(args.bf16x3 & 4))
+        eng.set_sdf_backward_bf16x3(bool(args.bf16x3 & 8))
     for i in range(args.warmup):
         step(i)
     fence()

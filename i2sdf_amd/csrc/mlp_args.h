@@ -1,0 +1,38 @@
+// Argument blocks of the SDF training kernels (shared by the fp32 MFMA kernels and their bf16x3 twins in mlp_x3.hip).
+#pragma once
+#include "mlp_common.h"
+
+struct SdfTrainFwdArgs {
+  const float* fwd; int n_fwd;
+  const float* rev; int n_rev;          // starts at the w_sdf row vector
+  int L, skip;
+  i2sdf::PointSpec pts;
+  int64_t M, Mp;
+  float* sdf;                           // (M)
+  float* feat;                          // (Mp, F)
+  float* grad;                          // (M,3) or nullptr
+  float* hs;                            // (L-1, Mp, H)  h_1..h_{L-1}   or nullptr (no saves: eval)
+  float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
+  float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
+};
+
+struct SdfBwdArgs {
+  const float* fwd; int n_fwd;          // forward stream up to (excluding) the last layer
+  const float* rev; int n_rev;          // reverse stream from W_feat^T down to W_1^T
+  int L, skip;
+  i2sdf::PointSpec pts;
+  int64_t M, Mp;
+  const float* hs; const float* abars;  // from sdf_train_fwd
+  const float* sbar;                    // (M) d loss / d sdf            (nullptr = 0)
+  const float* fbar; int64_t m_fbar;    // (Mp,F) d loss / d feature, rows >= m_fbar are zero (nullptr = 0)
+  const float* nbar;                    // (M,3) d loss / d grad         (nullptr = 0)
+  float* gus;                           // (L, Mp, H)  G(hbar_l): slot l = h-part of G(ubar_l), l = 1..L-1 (slot 0 unused)
+  float* gpbar;                         // (Mp, PEC*8) G(pbar)
+  float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (holds G2(a_l) between the sweeps)
+  float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
+  float* ones4;                         // (Mp,4) {1,0,0,0}
+};
+
+// bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st);
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);

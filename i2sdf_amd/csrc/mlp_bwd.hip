@@ -6,27 +6,12 @@
 //             weight-gradient GEMMs (G(ubar_l), G(a_l)); the GEMMs themselves run in wgrad.hip.
 //   rgb_bwd : first-order backward of the radiance net; emits G(a_l) and the feature gradient fbar.
 #include "ksplit.h"
+#include "mlp_args.h"
 
 using namespace i2sdf;
 
 int i2sdf_hip_check(hipError_t e, const char* what);
 
-struct SdfBwdArgs {
-  const float* fwd; int n_fwd;          // forward stream up to (excluding) the last layer
-  const float* rev; int n_rev;          // reverse stream from W_feat^T down to W_1^T
-  int L, skip;
-  PointSpec pts;
-  int64_t M, Mp;
-  const float* hs; const float* abars;  // from sdf_train_fwd
-  const float* sbar;                    // (M) d loss / d sdf            (nullptr = 0)
-  const float* fbar; int64_t m_fbar;    // (Mp,F) d loss / d feature, rows >= m_fbar are zero (nullptr = 0)
-  const float* nbar;                    // (M,3) d loss / d grad         (nullptr = 0)
-  float* gus;                           // (L, Mp, H)  G(hbar_l): slot l = h-part of G(ubar_l), l = 1..L-1 (slot 0 unused)
-  float* gpbar;                         // (Mp, PEC*8) G(pbar)
-  float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (holds G2(a_l) between the sweeps)
-  float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
-  float* ones4;                         // (Mp,4) {1,0,0,0}
-};
 
 namespace {
 
@@ -427,11 +412,24 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
     a.n_fwd = sdf_fwd_hidden_stages(256, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
     const int64_t bulk = split_bulk_points(M);
+    // full workgroups in bf16x3 split arithmetic (two launches); needs at least one plain hidden layer above the skip layer
+    const bool x3 = p->sdf_bwd_bf16x3 != 0 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
+    auto launch3 = [&](unsigned g) {
+      SdfBwdArgs a3 = a;
+      a3.fwd = base + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;
+      a3.rev = base + p->sdf.rev3_chunk0 * CHUNK_FLOATS;
+      a3.n_fwd = sdf_fwd3_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
+      a3.n_rev = sdf_rev3_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
+      i2sdf_launch_sdf_bwd3(a3, g, st);
+    };
     if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
       a.M = bulk;
-      launch_lds(sdf_bwd_kernel<256, 256, 6>, (unsigned)(bulk / PTS_PER_WG), st, a);
+      if (x3) launch3((unsigned)(bulk / PTS_PER_WG));
+      else launch_lds(sdf_bwd_kernel<256, 256, 6>, (unsigned)(bulk / PTS_PER_WG), st, a);
       a.M = M;
       launch_lds_bytes(KS_LDS_BYTES, sdf_bwd_split_kernel<256, 256, 6>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
+    } else if (x3) {
+      launch3(grid);
     } else {
       launch_lds(sdf_bwd_kernel<256, 256, 6>, grid, st, a);
     }

@@ -72,6 +72,17 @@ __host__ __device__ constexpr int sdf_rev3_stages(int H, int PEC, int L, bool ha
   c += x3_bwd_chunks(PT, H / 16);
   return c / SC;
 }
+// backward sweep 1 walks the hidden layers of the bf16x3 forward stream; sweep 2 the reverse stream from its start down to W_1^T
+__host__ __device__ constexpr int sdf_fwd3_hidden_stages(int H, int PED, int L, bool has_skip) {
+  return sdf_fwd3_stages(H, PED, L, has_skip) - rowvec_chunks(H / 8, 1) / SC;
+}
+__host__ __device__ constexpr int sdf_rev3_bwd_stages(int H, int F, int PEC, int L, bool has_skip) {
+  const int PT = cdiv(PEC * 8, 32);
+  int c = 2 * rowvec_chunks(H / 8, 1) + x3_bwd_chunks(H / 32, F / 16);
+  for (int l = L - 2; l >= 1; --l) c += x3_bwd_chunks(H / 32, H / 16);
+  if (has_skip) c += x3_bwd_chunks(PT, H / 16);
+  return c / SC;
+}
 __host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
 // reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space
 __host__ __device__ constexpr int sdf_rev_stages(int H, int PEC, int L, bool has_skip) {

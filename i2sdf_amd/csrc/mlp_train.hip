@@ -5,24 +5,12 @@
 //                   Saves h_l = softplus(a_{l-1}) and abar_l = d sdf / d a_l for the backward kernels.
 //   rgb_fwd       : RenderingNetwork.forward, 'nerf' mode (mlp.py:208-229), saves the post-ReLU activations.
 #include "ksplit.h"
+#include "mlp_args.h"
 
 using namespace i2sdf;
 
 int i2sdf_hip_check(hipError_t e, const char* what);
 
-struct SdfTrainFwdArgs {
-  const float* fwd; int n_fwd;
-  const float* rev; int n_rev;          // starts at the w_sdf row vector
-  int L, skip;
-  PointSpec pts;
-  int64_t M, Mp;
-  float* sdf;                           // (M)
-  float* feat;                          // (Mp, F)
-  float* grad;                          // (M,3) or nullptr
-  float* hs;                            // (L-1, Mp, H)  h_1..h_{L-1}   or nullptr (no saves: eval)
-  float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
-  float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
-};
 
 namespace {
 
@@ -111,139 +99,6 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
     }
   }
   dense_op_nobias<PT, KC, 2>(ws, ab, pt, tid);       // pbar += W_0^T abar_0
-  {
-    float full[PEC * 8], coef[PEC * 8], n[3];
-    pe_full<LF>(px, py, pz, full);
-    pe_coef<LF>(full, coef);
-    pe_jt_apply<LF, PT>(coef, pt, hi, n);
-    if (valid && hi == 0) { a.grad[m * 3 + 0] = n[0]; a.grad[m * 3 + 1] = n[1]; a.grad[m * 3 + 2] = n[2]; }
-  }
-}
-
-// bf16x3 variant (x3.h): same outputs and saved tensors, K-outer loops on the bf16 matrix pipe.  The activations of a layer
-// are produced (softplus, store, split) as the B operand of the NEXT op, one k-chunk ahead of their use; two accumulator
-// sets alternate between "previous layer" and "this layer".
-template <int H, int F, int LF, bool GRAD>
-__global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) {
-  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PT = cdiv(PEC * 8, 32), FT = F / 32;
-  constexpr int PE16 = cdiv(PED, 16), NPE = PE16 * 8;
-  static_assert(NT == FT, "feature tiles reuse the hidden accumulator set");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
-  const bool valid = m < a.M;
-  const int64_t mc = valid ? m : a.M - 1;
-  float px, py, pz;
-  fetch_point(a.pts, mc, px, py, pz);
-  float pe[NPE];
-  {
-    float full[PEC * 8], pad[PE16 * 16], reg[PEC * 4];
-    pe_full<LF>(px, py, pz, full);
-    if (a.pe_save) { to_b_layout<PEC>(full, reg, hi); store_regs<PEC>(a.pe_save + m * (PEC * 8), hi, valid, reg); }
-#pragma unroll
-    for (int i = 0; i < PE16 * 16; ++i) pad[i] = (i < PED) ? full[i] : 0.f;
-    x3_select_pe<PE16>(pad, pe, hi);
-  }
-  const int64_t lstride = a.Mp * H;
-  WStream ws;
-  ws.begin(a.fwd, lds, a.n_fwd, tid);
-  f32x16 accA[NT], accB[NT];
-  {
-    X3FwdSrc<NT, 0, NPE> src{accB, pe, nullptr, hi, valid};
-    dense_x3g<NT, PE16, true>(ws, src, accA, tid);
-  }
-  // hidden layers: layer l reads accA (pre-activations of layer l-1, whose softplus is h_l -> hs[l-1]) and writes accB
-  for (int l = 1; l < a.L - 1; ++l) {
-    float* hrow = a.hs ? a.hs + (l - 1) * lstride + m * H : nullptr;
-    if (l == a.skip) {
-      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
-      dense_x3g<NT, KH16 + PE16, true>(ws, src, accB, tid);
-    } else {
-      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
-      dense_x3g<NT, KH16, true>(ws, src, accB, tid);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  float h[KC * 4];                     // h_{L-1} in the fp32 kernels' B layout: sdf row, feature op, top of the reverse chain
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accA[nt][r]);
-  if (a.hs) store_regs<KC>(a.hs + (a.L - 2) * lstride + m * H, hi, valid, h);
-  {
-    float s[1];
-    rowvec_op<1, KC>(ws, h, s, tid);
-    if (valid && hi == 0) a.sdf[m] = s[0];
-  }
-  if (a.feat != nullptr) {
-    X3RegSrc<KC * 4> src{h};
-    dense_x3g<FT, KH16, true>(ws, src, accB, tid);
-    store_tile<FT>(a.feat + mc * F, hi, valid, accB);
-  }
-}
-
-// d sdf/dx chain of the bf16x3 path as its own launch (appendix A.2): the forward kernel above and this one each fit the
-// register file without spills; h_{L-1} is re-read from the tensor the forward saved.
-template <int H, int LF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf_igrad3_kernel(SdfTrainFwdArgs a) {
-  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
-  const bool valid = m < a.M;
-  const int64_t mc = valid ? m : a.M - 1;
-  const int64_t lstride = a.Mp * H;
-  float px, py, pz;
-  fetch_point(a.pts, mc, px, py, pz);
-  f32x16 accA[NT], accB[NT];
-  float h[KC * 4];
-  load_regs<KC>(a.hs + (a.L - 2) * lstride + mc * H, hi, h);
-  WStream ws;
-  ws.begin(a.rev, lds, a.n_rev, tid);
-  {
-    float wv[KC * 4];
-    f32x4 sc;
-    rowvec_load<KC>(ws, wv, sc, tid);
-#pragma unroll
-    for (int i = 0; i < KC * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
-  }
-  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + m * H, hi, valid, h);
-  f32x16 pt[PT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pt[i][r] = 0.f;
-  auto zero = [&](f32x16 (&x)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) x[nt][r] = 0.f;
-  };
-  // op(l) = W_l^T abar_l.  abar_{L-2} comes from registers; for l < L-2 it is (accumulators of op(l+1)) * sigma(h_{l+1}),
-  // made (and stored to abars[l]) by the B preparation of op(l).  The skip layer's op is two ops over the same B operand:
-  // the hidden part and the PE part (which adds into pbar; its B preparation is recomputed, without the store).
-  {
-    X3RegSrc<KC * 4> src{h};
-    zero(accA);
-    dense_x3g<NT, KH16, false>(ws, src, accA, tid);       // l = L-2 (never the skip layer, checked by the host)
-  }
-  for (int l = a.L - 3; l >= 1; --l) {
-    const float* hrow = a.hs + l * lstride + mc * H;
-    X3RevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + m * H : nullptr, hi, valid};
-    zero(accB);
-    dense_x3g<NT, KH16, false>(ws, src, accB, tid);
-    if (l == a.skip) {
-      X3RevSrc<NT> src2{accA, hrow, nullptr, hi, valid};
-      dense_x3g<PT, KH16, false>(ws, src2, pt, tid);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  {
-    X3RevSrc<NT> src{accA, a.hs + mc * H, a.abars ? a.abars + m * H : nullptr, hi, valid};     // abar_0 = (.) * sigma(h_1)
-    dense_x3g<PT, KH16, false>(ws, src, pt, tid);       // pbar += W_0^T abar_0
-  }
   {
     float full[PEC * 8], coef[PEC * 8], n[3];
     pe_full<LF>(px, py, pz, full);
@@ -536,11 +391,10 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
   do {                                                                                               \
     SdfTrainFwdArgs a3 = a;                                                                          \
     a3.fwd = base + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;                                               \
-    a3.rev = base + p->sdf.rev3_chunk0 * CHUNK_FLOATS;                                               \
+    a3.rev = base + p->sdf.rev3_wsdf_chunk * CHUNK_FLOATS;                                               \
     a3.n_fwd = sdf_fwd3_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);      \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
-    launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, G_, st, a3);                               \
-    if (grad) launch_lds(sdf_igrad3_kernel<256, 6>, G_, st, a3);                                     \
+    i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st);                                            \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
   if (p->H == 256 && p->F == 256) {

@@ -1,0 +1,257 @@
+// bf16x3 split-arithmetic twins of the SDF training kernels (x3.h): forward with saves, d sdf/dx chain, backward sweeps.
+// Kept in their own translation unit: their fully unrolled K-outer stage loops need -mllvm -pragma-unroll-threshold (build.sh),
+// which the fp32 MFMA kernels must not be compiled with (it changes their unrolling and costs them ~4 %).
+#include "mlp_args.h"
+
+using namespace i2sdf;
+
+namespace {
+
+// bf16x3 variant (x3.h): same outputs and saved tensors, K-outer loops on the bf16 matrix pipe.  The activations of a layer
+// are produced (softplus, store, split) as the B operand of the NEXT op, one k-chunk ahead of their use; two accumulator
+// sets alternate between "previous layer" and "this layer".
+template <int H, int F, int LF, bool GRAD>
+__global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PT = cdiv(PEC * 8, 32), FT = F / 32;
+  constexpr int PE16 = cdiv(PED, 16), NPE = PE16 * 8;
+  static_assert(NT == FT, "feature tiles reuse the hidden accumulator set");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  float px, py, pz;
+  fetch_point(a.pts, mc, px, py, pz);
+  float pe[NPE];
+  {
+    float full[PEC * 8], pad[PE16 * 16], reg[PEC * 4];
+    pe_full<LF>(px, py, pz, full);
+    if (a.pe_save) { to_b_layout<PEC>(full, reg, hi); store_regs<PEC>(a.pe_save + m * (PEC * 8), hi, valid, reg); }
+#pragma unroll
+    for (int i = 0; i < PE16 * 16; ++i) pad[i] = (i < PED) ? full[i] : 0.f;
+    x3_select_pe<PE16>(pad, pe, hi);
+  }
+  const int64_t lstride = a.Mp * H;
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x16 accA[NT], accB[NT];
+  {
+    X3FwdSrc<NT, 0, NPE> src{accB, pe, nullptr, hi, valid};
+    dense_x3g<NT, PE16, 1>(ws, src, accA, tid);
+  }
+  // hidden layers: layer l reads accA (pre-activations of layer l-1, whose softplus is h_l -> hs[l-1]) and writes accB
+  for (int l = 1; l < a.L - 1; ++l) {
+    float* hrow = a.hs ? a.hs + (l - 1) * lstride + m * H : nullptr;
+    if (l == a.skip) {
+      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
+      dense_x3g<NT, KH16 + PE16, 1>(ws, src, accB, tid);
+    } else {
+      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
+      dense_x3g<NT, KH16, 1>(ws, src, accB, tid);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
+  }
+  float h[KC * 4];                     // h_{L-1} in the fp32 kernels' B layout: sdf row, feature op, top of the reverse chain
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accA[nt][r]);
+  if (a.hs) store_regs<KC>(a.hs + (a.L - 2) * lstride + m * H, hi, valid, h);
+  {
+    float s[1];
+    rowvec_op<1, KC>(ws, h, s, tid);
+    if (valid && hi == 0) a.sdf[m] = s[0];
+  }
+  if (a.feat != nullptr) {
+    X3RegSrc<KC * 4> src{h};
+    dense_x3g<FT, KH16, 1>(ws, src, accB, tid);
+    store_tile<FT>(a.feat + mc * F, hi, valid, accB);
+  }
+}
+
+// d sdf/dx chain of the bf16x3 path as its own launch (appendix A.2): the forward kernel above and this one each fit the
+// register file without spills; h_{L-1} is re-read from the tensor the forward saved.
+template <int H, int LF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf_igrad3_kernel(SdfTrainFwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float px, py, pz;
+  fetch_point(a.pts, mc, px, py, pz);
+  f32x16 accA[NT], accB[NT];
+  float h[KC * 4];
+  load_regs<KC>(a.hs + (a.L - 2) * lstride + mc * H, hi, h);
+  WStream ws;
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  {
+    float wv[KC * 4];
+    f32x4 sc;
+    rowvec_load<KC>(ws, wv, sc, tid);
+#pragma unroll
+    for (int i = 0; i < KC * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
+  }
+  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + m * H, hi, valid, h);
+  f32x16 pt[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pt[i][r] = 0.f;
+  auto zero = [&](f32x16 (&x)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[nt][r] = 0.f;
+  };
+  // op(l) = W_l^T abar_l.  abar_{L-2} comes from registers; for l < L-2 it is (accumulators of op(l+1)) * sigma(h_{l+1}),
+  // made (and stored to abars[l]) by the B preparation of op(l).  The skip layer's op is two ops over the same B operand:
+  // the hidden part and the PE part (which adds into pbar; its B preparation is recomputed, without the store).
+  {
+    X3RegSrc<KC * 4> src{h};
+    zero(accA);
+    dense_x3g<NT, KH16, 0>(ws, src, accA, tid);       // l = L-2 (never the skip layer, checked by the host)
+  }
+  for (int l = a.L - 3; l >= 1; --l) {
+    const float* hrow = a.hs + l * lstride + mc * H;
+    X3RevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + m * H : nullptr, hi, valid};
+    zero(accB);
+    dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
+    if (l == a.skip) {
+      X3RevSrc<NT> src2{accA, hrow, nullptr, hi, valid};
+      dense_x3g<PT, KH16, 0>(ws, src2, pt, tid);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
+  }
+  {
+    X3RevSrc<NT> src{accA, a.hs + mc * H, a.abars ? a.abars + m * H : nullptr, hi, valid};     // abar_0 = (.) * sigma(h_1)
+    dense_x3g<PT, KH16, 0>(ws, src, pt, tid);       // pbar += W_0^T abar_0
+  }
+  {
+    float full[PEC * 8], coef[PEC * 8], n[3];
+    pe_full<LF>(px, py, pz, full);
+    pe_coef<LF>(full, coef);
+    pe_jt_apply<LF, PT>(coef, pt, hi, n);
+    if (valid && hi == 0) { a.grad[m * 3 + 0] = n[0]; a.grad[m * 3 + 1] = n[1]; a.grad[m * 3 + 2] = n[2]; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16x3 variants (x3.h) of the two sweeps, one launch each (each fits the register file without spills).  K-outer: the
+// per-element epilogue of an op (loads of the saved tensors, sigma products, stores) is the B preparation of the next op;
+// the last op of a sweep is followed by a drain that only runs the epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+template <int H, int LF>
+__global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
+  constexpr int NT = H / 32, KH16 = H / 16, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NGP = PE16 * 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  float gpx[NGP];                       // G(pbar) in the fp32 kernels' B layout, zero padded to whole 16-chunks
+  {
+    float gp[PEC * 4];
+    float px, py, pz, full[PEC * 8], coef[PEC * 8], nb[3] = {0.f, 0.f, 0.f};
+    fetch_point(a.pts, mc, px, py, pz);
+    pe_full<LF>(px, py, pz, full);
+    pe_coef<LF>(full, coef);
+    if (a.nbar) { nb[0] = a.nbar[mc * 3 + 0]; nb[1] = a.nbar[mc * 3 + 1]; nb[2] = a.nbar[mc * 3 + 2]; }
+    pe_j_apply<LF>(coef, nb, hi, gp);
+    store_regs<PEC>(a.gpbar + m * (PEC * 8), hi, valid, gp);
+#pragma unroll
+    for (int i = 0; i < NGP; ++i) gpx[i] = i < PEC * 4 ? gp[i < PEC * 4 ? i : 0] : 0.f;
+  }
+  WStream ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x16 accA[NT], accB[NT];
+  {
+    X3Sweep1Src<NT, 0, NGP> src{accB, gpx, nullptr, nullptr, nullptr, nullptr, hi, valid};
+    dense_x3g<NT, PE16, 2>(ws, src, accA, tid);
+  }
+  for (int l = 1; l < a.L - 1; ++l) {
+    // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l], G2(a_{l-1}) -> gas[l-1]
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
+                                   a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    if (l == a.skip) dense_x3g<NT, KH16 + PE16, 2>(ws, src, accB, tid);
+    else dense_x3g<NT, KH16, 2>(ws, src, accB, tid);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
+  }
+  {
+    const int l = a.L - 1;
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
+                                   a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    x3_drain<KH16>(src);
+  }
+}
+
+template <int H, int F, int LF>
+__global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
+  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  const int64_t lstride = a.Mp * H;
+  const float sb = a.sbar ? a.sbar[mc] : 0.f;
+  if (valid && hi == 0) {
+    *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(a.ones4 + m * 4) = f32x4{1.f, 0.f, 0.f, 0.f};
+  }
+  WStream ws;
+  ws.begin(a.rev, lds, a.n_rev, tid);
+  f32x16 accA[NT], accB[NT];
+  auto zero = [&](f32x16 (&x)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[nt][r] = 0.f;
+  };
+  ws.skip(rowvec_chunks(KC, 1) / SC, tid);            // w_sdf is read straight from the packed buffer (X3Sweep2Src<TOP>)
+  {
+    X3RowSrc src{a.fbar ? a.fbar + mc * F : nullptr, hi, a.fbar != nullptr && mc < a.m_fbar};
+    zero(accA);
+    dense_x3g<NT, F / 16, 0>(ws, src, accA, tid);     // W_feat^T fbar
+  }
+  ws.skip(rowvec_chunks(KC, 1) / SC, tid);            // the d sdf/dx chain's copy of w_sdf
+  {
+    const int l = a.L - 2;                            // G(a_{L-2}) = (W_feat^T fbar + sbar w_sdf) sigma + G2, then W_{L-2}^T G(a_{L-2})
+    X3Sweep2Src<NT, true> src{accA, a.hs + l * lstride + mc * H, a.gas + l * lstride + mc * H, a.gas + l * lstride + m * H, hi, valid,
+                              sb, a.rev + lane * 4};
+    zero(accB);
+    dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
+  }
+  for (int l = a.L - 3; l >= 1; --l) {
+    X3Sweep2Src<NT, false> src{accA, a.hs + l * lstride + mc * H, a.gas + l * lstride + mc * H, a.gas + l * lstride + m * H, hi, valid,
+                               0.f, nullptr};
+    zero(accB);
+    dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
+    if (l == a.skip) ws.skip(x3_bwd_chunks(PT, KH16) / SC, tid);      // the PE rows of W_skip^T are not needed here
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
+  }
+  {
+    X3Sweep2Src<NT, false> src{accA, a.hs + mc * H, a.gas + mc * H, a.gas + m * H, hi, valid, 0.f, nullptr};     // G(a_0)
+    x3_drain<KH16>(src);
+  }
+}
+
+}  // namespace
+
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st) {
+  launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, grid, st, a);
+  if (grad) launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a);
+}
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
+  launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
+  launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);
+}

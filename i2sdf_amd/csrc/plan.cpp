@@ -175,6 +175,10 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
   np.rev3_chunk0 = b.chunk;
   if ((H / 32) % 2 == 0) {
     const int PT = cdiv(PEC * 8, 32);
+    // backward sweep 2 starts here: [w_sdf][W_feat^T]; the d sdf/dx chain starts at rev3_wsdf_chunk: [w_sdf][W_{L-2}^T]...
+    emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    if (F > 0 && F % 16 == 0) emit_dense_bwd3(b, np, L - 1, H / 32, F / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F, 1.0f);
+    np.rev3_wsdf_chunk = b.chunk;
     emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
     for (int l = L - 2; l >= 0; --l) {
       // the skip layer's transposed op is emitted as two ops over the same reduction: hidden part, then PE part
@@ -307,6 +311,11 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
   if (option == I2SDF_OPT_TRAIN_FWD_BF16X3) {
     if (value && (p->sdf.rev3_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
     p->train_fwd_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  if (option == I2SDF_OPT_SDF_BWD_BF16X3) {
+    if (value && (p->sdf.rev3_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
+    p->sdf_bwd_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_WGRAD_BF16X3) {

@@ -45,7 +45,8 @@ struct NetPlan {
   int64_t rev_chunk0 = 0, rev_chunks = 0;      // transposed / reverse stream
   int64_t rev_wsdf_chunk = 0;                  // where the igrad chain starts inside rev (sdf net)
   int64_t fwd3_chunk0 = 0, fwd3_chunks = 0;    // bf16x3 forward stream: hidden layers, sdf row, feature rows (sdf net, x3.h)
-  int64_t rev3_chunk0 = 0, rev3_chunks = 0;    // bf16x3 reverse stream: w_sdf row, W_{L-2}^T ... W_0^T
+  int64_t rev3_chunk0 = 0, rev3_chunks = 0;    // bf16x3 reverse stream: [w_sdf][W_feat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
+  int64_t rev3_wsdf_chunk = 0;                 // where the d sdf/dx chain starts inside it
   int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
   int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
 };
@@ -63,6 +64,7 @@ struct i2sdf_plan {
   int64_t total_chunks = 0;          // chunks after the scale region (+1 stage of slack for the DMA look-ahead)
   int64_t wgrad_floats = 0;
   int32_t H = 0, F = 0;              // sdf hidden width / feature size
+  int32_t sdf_bwd_bf16x3 = 0;        // I2SDF_OPT_SDF_BWD_BF16X3: SDF backward sweeps (full workgroups) in bf16x3 split arithmetic
   int32_t train_fwd_bf16x3 = 0;      // I2SDF_OPT_TRAIN_FWD_BF16X3: SDF forward + d sdf/dx kernel in bf16x3 split arithmetic
   int32_t wgrad_bf16x3 = 0;          // I2SDF_OPT_WGRAD_BF16X3: full 256x256 weight-gradient blocks in bf16x3 split arithmetic
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic

@@ -147,22 +147,28 @@ __device__ __forceinline__ void dense_x3(WStream& ws, const f32x16 (&accP)[NT], 
 
 // ---------------------------------------------------------------------------------------------
 // Generalised K-outer bf16x3 op for the training kernels:  acc[NT] (+)= W * src.
-//   BIAS  : the stream starts with NT*4 fp32 bias chunks that initialise acc; otherwise acc is used as the caller left it
-//           (zeroed, or holding a running sum such as pbar) and the stream holds weight chunks only.
+//   BIAS  : 1 = the stream starts with NT*4 fp32 bias chunks that initialise acc; 2 = the chunks are there but are skipped
+//           and acc starts at zero (backward sweeps over the forward stream); 0 = weight chunks only, acc is used as the
+//           caller left it (zeroed, or holding a running sum such as pbar).
 //   Src   : where the B operand comes from.  `float value(kc, u)` returns value u (0..7) of k-chunk kc for this lane --
 //           reduction index 16*kc + (u&3) + 8*(u>>2) + 4*hi -- and `void done(kc, v)` is called once all eight are known
 //           (global stores of the saved tensors).  Both are dealt into the MFMA shadows one k-chunk ahead of their use;
 //           `void ahead(kc)` is called two k-chunks ahead (issue global loads there).
 // ---------------------------------------------------------------------------------------------
-template <int NT, int KC16, bool BIAS, class Src>
+template <int NT, int KC16, int BIAS, class Src>
 __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io)[NT], int tid) {
   f32x16 acc[NT];
-  if (!BIAS) {
+  if (BIAS == 0) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_io[nt];
+  } else if (BIAS == 2) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
   }
   static_assert(NT % 2 == 0, "tiles are processed in pairs");
-  constexpr int NB = BIAS ? NT * 4 : 0, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
+  constexpr int NB = BIAS != 0 ? NT * 4 : 0, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
   constexpr int TOT = round_up(NB + NW, SC), NS = TOT / SC, PFP = 2;
   const int lane = tid & 63;
   float v[8];
@@ -188,7 +194,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       const int c = s * SC + j;
-      if (c < NB) {
+      if (c < NB && BIAS == 1) {
         const int nt = c / 4, q = c % 4;
         const f32x4 b = __builtin_bit_cast(f32x4, cur[j * 64]);
         acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
@@ -239,6 +245,20 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   for (int nt = 0; nt < NT; ++nt) acc_io[nt] = acc[nt];
 }
 
+// apply a source to every k-chunk without a consuming op (the last epilogue of a chain: loads, products, stores)
+template <int KC16, class Src>
+__device__ __forceinline__ void x3_drain(Src& src) {
+  float v[8];
+  src.ahead(0);
+#pragma unroll
+  for (int kc = 0; kc < KC16; ++kc) {
+    if (kc + 1 < KC16) src.ahead(kc + 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u);
+    src.done(kc, v);
+  }
+}
+
 // B-operand sources -------------------------------------------------------------------------------------------------
 // softplus100 of the previous layer's pre-activations (D layout) for k-chunks < KACC, this lane's PE values beyond;
 // stores the activations (h row of the saved tensor) as they are produced
@@ -283,6 +303,73 @@ struct X3RevSrc {
       *reinterpret_cast<f32x4*>(abrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
+};
+
+
+// ---- sources of the backward sweeps (appendix A.3) ------------------------------------------------------------------
+// two f32x4 of a point-major row covering this lane's 8 reduction indices of k-chunk kc
+__device__ __forceinline__ void x3_load8(const float* row, int kc, int hi, f32x4 (&q)[2]) {
+  q[0] = *reinterpret_cast<const f32x4*>(row + 16 * kc + 4 * hi);
+  q[1] = *reinterpret_cast<const f32x4*>(row + 16 * kc + 8 + 4 * hi);
+}
+__device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const float (&v)[8]) {
+  *reinterpret_cast<f32x4*>(row + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(row + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+}
+// sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
+//                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
+template <int NT, int KACC, int NREG>
+struct X3Sweep1Src {
+  const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
+  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
+  f32x4 hq[2][2], aq[2][2];
+  float g2[8];
+  __device__ __forceinline__ void ahead(int kc) {
+    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc & 1]); x3_load8(arow, kc, hi, aq[kc & 1]); }
+  }
+  __device__ __forceinline__ float value(int kc, int u) {
+    if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
+    const float ga = accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u];
+    const float sg = sp_sigma_from_h(hq[kc & 1][u >> 2][u & 3]);
+    g2[u] = ga * aq[kc & 1][u >> 2][u & 3] * (100.f * (1.0f - sg));
+    return ga * sg;
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v); x3_store8(g2row, kc, hi, g2); }
+  }
+};
+// sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
+template <int NT, bool TOP>
+struct X3Sweep2Src {
+  const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
+  float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
+  f32x4 hq[2][2], gq[2][2], wq[2][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    x3_load8(hrow, kc, hi, hq[kc & 1]); x3_load8(g2row, kc, hi, gq[kc & 1]);
+    if (TOP) {
+      wq[kc & 1][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
+      wq[kc & 1][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
+    }
+  }
+  __device__ __forceinline__ float value(int kc, int u) {
+    float x = accP[kc >> 1][8 * (kc & 1) + u];
+    if (TOP) x = fmaf(sb, wq[kc & 1][u >> 2][u & 3], x);
+    return fmaf(x, sp_sigma_from_h(hq[kc & 1][u >> 2][u & 3]), gq[kc & 1][u >> 2][u & 3]);
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+    if (valid) x3_store8(grow, kc, hi, v);
+  }
+};
+// a point-major row in global memory (or zeros) as B operand
+struct X3RowSrc {
+  const float* row; int hi; bool on;
+  f32x4 q[2][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    if (on) x3_load8(row, kc, hi, q[kc & 1]);
+    else { q[kc & 1][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  __device__ __forceinline__ float value(int kc, int u) { return q[kc & 1][u >> 2][u & 3]; }
+  __device__ __forceinline__ void done(int, const float (&)[8]) {}
 };
 
 }  // namespace i2sdf
