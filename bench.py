@@ -167,19 +167,26 @@ def main():
         # dominant = the kernel family with the largest share of the step
         mfma_names = [n for n in kern if "tflops" in kern[n]]
         dom = max(mfma_names, key=lambda n: kern[n]["ms_per_step"]) if mfma_names else None
-        PEAK = 157.3   # TFLOP/s, fp32-input MFMA on MI355X (MI355X_MICROARCH.md)
+        PEAK = 157.3            # TFLOP/s, fp32-input MFMA on MI355X (MI355X_MICROARCH.md)
+        PEAK_X3 = 2500.0 / 6    # bf16 dense MFMA peak / six bf16 MFMAs per fp32 product block (csrc/x3.h): fp32-equivalent TFLOP/s
+        x3 = {"i2sdf_sample_rays": eng.sdf_forward_bf16x3, "i2sdf_sdf_forward_grad": eng.train_forward_bf16x3,
+              "i2sdf_sdf_backward": eng.sdf_backward_bf16x3, "i2sdf_weight_grads": eng.wgrad_bf16x3}
         roof = None
         if dom:
             ach = kern[dom]["tflops"]
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s", "frac": round(ach / PEAK, 4),
-                    "traffic": None,
+            peak = PEAK_X3 if x3.get(dom) else PEAK
+            roof = {"bound": "mfma", "kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent)" if x3.get(dom) else "f32 MFMA",
+                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
+                    "traffic": profiled_traffic(dom),
                     "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
                                                      / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
         total_flops = sum(launch_flops.values())
         result = {
             "metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not any(x3.values()) else "f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
                        "rays_per_gpu": B, "shaded_samples_per_ray": n_shaded, "sampler_iters": iters, "sampler_samples_per_iter": cfg.sampler.N_samples_eval,
                        "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce)"},
@@ -195,6 +202,27 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def profiled_traffic(entry):
+    """HBM bytes per launch of an entry point from the committed PMC summaries (profiles/r1_pmc_{fetch,write}_summary.csv:
+    FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; FETCH doubled as MI355X_MICROARCH.md prescribes for
+    16-B-per-lane loads on gfx950).  None when the summaries are absent or do not cover the entry point's kernels."""
+    import csv
+    pat = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),
+           "i2sdf_sample_rays": ("sdf_fwd", "sampler_")}.get(entry)
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        tot = 0.0
+        for tag, col, mult in (("fetch", "FETCH_SIZE_per_dispatch", 2.0), ("write", "WRITE_SIZE_per_dispatch", 1.0)):
+            rows = list(csv.DictReader(open(os.path.join(here, "profiles", f"r1_pmc_{tag}_summary.csv"))))
+            steps = max([int(r["dispatches"]) for r in rows if "wn_backward" in r["kernel"]] or [0])
+            if not pat or steps == 0:
+                return None
+            tot += sum(float(r[col]) * 1024.0 * mult * int(r["dispatches"]) for r in rows if any(q in r["kernel"] for q in pat)) / steps
+        return round(tot) if tot > 0 else None
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, iters, n_shaded):

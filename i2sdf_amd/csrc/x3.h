@@ -26,6 +26,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// global loads of the B-operand sources are issued X3_AHEAD k-chunks before their use (ring of X3_RING register slots):
+// measured: a distance of 1 is enough (3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
+// STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
+#define X3_AHEAD 1
+#define X3_RING 2
 __host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -171,26 +176,48 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   constexpr int NB = BIAS != 0 ? NT * 4 : 0, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
   constexpr int TOT = round_up(NB + NW, SC), NS = TOT / SC, PFP = 2;
   const int lane = tid & 63;
-  float v[8];
+  float v[8], vx[8];
   u32x4 bq[2][3];
+  // Stores of the source (saved tensors) are not issued where their values become known but right after the next stage
+  // barrier: the barrier's vmcnt(0) drain (needed for the LDS DMA) would otherwise wait for stores issued moments before it.
+  float sv[2][8], sx[2][8];
+  int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
+  auto flush = [&]() __attribute__((always_inline)) {
+    if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
+    if (pk1 >= 0) { src.done(pk1, sv[1], sx[1]); pk1 = -1; }
+  };
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
-    if (u == 0 && kc + 1 < KC16) src.ahead(kc + 1);
-    if (u < 8) v[u] = src.value(kc, u);
+    if (u == 0 && kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
+    if (u < 8) v[u] = src.value(kc, u, vx[u]);
     else {
-      if (u == 8) src.done(kc, v);
+      if (u == 8 && Src::STORES) {
+        if (pk0 >= 0 && pk1 >= 0) flush();
+        if (pk0 < 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { sv[0][i] = v[i]; sx[0][i] = vx[i]; }
+          pk0 = kc;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { sv[1][i] = v[i]; sx[1][i] = vx[i]; }
+          pk1 = kc;
+        }
+      }
       const int i = u - 8;
       unsigned p0, p1, p2;
       split3_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
       b[0][i] = p0; b[1][i] = p1; b[2][i] = p2;
     }
   };
-  src.ahead(0);
+#pragma unroll
+  for (int k0 = 0; k0 < X3_AHEAD; ++k0)
+    if (k0 < KC16) src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+    flush();
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       const int c = s * SC + j;
@@ -241,6 +268,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     }
     if (!issued) ws.advance_issue(tid);
   }
+  flush();
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc_io[nt] = acc[nt];
 }
@@ -248,14 +276,16 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 // apply a source to every k-chunk without a consuming op (the last epilogue of a chain: loads, products, stores)
 template <int KC16, class Src>
 __device__ __forceinline__ void x3_drain(Src& src) {
-  float v[8];
-  src.ahead(0);
+  float v[8], vx[8];
+#pragma unroll
+  for (int k0 = 0; k0 < X3_AHEAD; ++k0)
+    if (k0 < KC16) src.ahead(k0);
 #pragma unroll
   for (int kc = 0; kc < KC16; ++kc) {
-    if (kc + 1 < KC16) src.ahead(kc + 1);
+    if (kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u);
-    src.done(kc, v);
+    for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u, vx[u]);
+    src.done(kc, v, vx);
   }
 }
 
@@ -264,13 +294,14 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 // stores the activations (h row of the saved tensor) as they are produced
 template <int NT, int KACC, int NPE>
 struct X3FwdSrc {
+  static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid;
   __device__ __forceinline__ void ahead(int) {}
-  __device__ __forceinline__ float value(int kc, int u) {
+  __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc < KACC) return softplus100(accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u]);
     return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (kc < KACC && hrow != nullptr && valid) {
       *reinterpret_cast<f32x4*>(hrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4*>(hrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
@@ -280,24 +311,26 @@ struct X3FwdSrc {
 // values held in registers in the fp32 kernels' B layout (register 4*c + t <-> index 8*c + 4*hi + t)
 template <int NREG>
 struct X3RegSrc {
+  static constexpr bool STORES = false;
   const float (&r)[NREG];
   __device__ __forceinline__ void ahead(int) {}
-  __device__ __forceinline__ float value(int kc, int u) { return r[8 * kc + u]; }
-  __device__ __forceinline__ void done(int, const float (&)[8]) {}
+  __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
 // reverse chain: abar = (previous op's accumulators) * sigma(h) with h re-read from the saved tensor; stores abar
 template <int NT>
 struct X3RevSrc {
+  static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid;
-  f32x4 hq[3][2];
+  f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    hq[kc % 3][0] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 4 * hi);
-    hq[kc % 3][1] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 8 + 4 * hi);
+    hq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 4 * hi);
+    hq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 8 + 4 * hi);
   }
-  __device__ __forceinline__ float value(int kc, int u) {
-    return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % 3][u >> 2][u & 3]);
+  __device__ __forceinline__ float value(int kc, int u, float&) {
+    return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (abrow != nullptr && valid) {
       *reinterpret_cast<f32x4*>(abrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
       *reinterpret_cast<f32x4*>(abrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
@@ -320,56 +353,59 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
 //                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
 template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
+  static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
-  f32x4 hq[2][2], aq[2][2];
-  float g2[8];
+  f32x4 hq[X3_RING][2], aq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc & 1]); x3_load8(arow, kc, hi, aq[kc & 1]); }
+    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc % X3_RING]); x3_load8(arow, kc, hi, aq[kc % X3_RING]); }
   }
-  __device__ __forceinline__ float value(int kc, int u) {
+  __device__ __forceinline__ float value(int kc, int u, float& g2) {
+    g2 = 0.f;
     if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
     const float ga = accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u];
-    const float sg = sp_sigma_from_h(hq[kc & 1][u >> 2][u & 3]);
-    g2[u] = ga * aq[kc & 1][u >> 2][u & 3] * (100.f * (1.0f - sg));
+    const float sg = sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
+    g2 = ga * aq[kc % X3_RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
     return ga * sg;
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
     if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v); x3_store8(g2row, kc, hi, g2); }
   }
 };
 // sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
 template <int NT, bool TOP>
 struct X3Sweep2Src {
+  static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
-  f32x4 hq[2][2], gq[2][2], wq[2][2];
+  f32x4 hq[X3_RING][2], gq[X3_RING][2], wq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    x3_load8(hrow, kc, hi, hq[kc & 1]); x3_load8(g2row, kc, hi, gq[kc & 1]);
+    x3_load8(hrow, kc, hi, hq[kc % X3_RING]); x3_load8(g2row, kc, hi, gq[kc % X3_RING]);
     if (TOP) {
-      wq[kc & 1][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
-      wq[kc & 1][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
+      wq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
+      wq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
     }
   }
-  __device__ __forceinline__ float value(int kc, int u) {
+  __device__ __forceinline__ float value(int kc, int u, float&) {
     float x = accP[kc >> 1][8 * (kc & 1) + u];
-    if (TOP) x = fmaf(sb, wq[kc & 1][u >> 2][u & 3], x);
-    return fmaf(x, sp_sigma_from_h(hq[kc & 1][u >> 2][u & 3]), gq[kc & 1][u >> 2][u & 3]);
+    if (TOP) x = fmaf(sb, wq[kc % X3_RING][u >> 2][u & 3], x);
+    return fmaf(x, sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]), gq[kc % X3_RING][u >> 2][u & 3]);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8]) {
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (valid) x3_store8(grow, kc, hi, v);
   }
 };
 // a point-major row in global memory (or zeros) as B operand
 struct X3RowSrc {
+  static constexpr bool STORES = false;
   const float* row; int hi; bool on;
-  f32x4 q[2][2];
+  f32x4 q[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    if (on) x3_load8(row, kc, hi, q[kc & 1]);
-    else { q[kc & 1][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (on) x3_load8(row, kc, hi, q[kc % X3_RING]);
+    else { q[kc % X3_RING][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc % X3_RING][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   }
-  __device__ __forceinline__ float value(int kc, int u) { return q[kc & 1][u >> 2][u & 3]; }
-  __device__ __forceinline__ void done(int, const float (&)[8]) {}
+  __device__ __forceinline__ float value(int kc, int u, float&) { return q[kc % X3_RING][u >> 2][u & 3]; }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
 
 }  // namespace i2sdf

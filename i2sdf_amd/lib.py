@@ -7,7 +7,7 @@ import os
 
 MAX_LAYERS = 12
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libi2sdf_hip.so")
+LIB_PATH = os.environ.get("I2SDF_LIB_PATH") or os.path.join(_HERE, "lib", "libi2sdf_hip.so")     # override: A/B of two builds on one box
 
 
 class MlpDesc(C.Structure):
