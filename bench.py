@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--bf16x3", type=int, default=-1,
                     help="bit mask of the kernels that run in bf16x3 split arithmetic (1 sampler forward, 2 weight gradients, "
-                         "4 training forward, 8 SDF backward); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
+                         "4 training forward, 8 SDF backward, 16 radiance net); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
     ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
 
@@ -55,6 +55,22 @@ def flops_per_point(cfg):
         "sdf_backward": 2 * (mac_igrad + mac_fwd - sdf[0][0] * sdf[0][1]),
         "wgrad_sdf": 2 * (mac_igrad + mac_fwd),
         "wgrad_rgb": 2 * mac_rgb,
+    }
+
+
+def bytes_per_point(cfg):
+    """Algorithmic (compulsory) HBM bytes per point of the per-point saved-tensor traffic, fp32 (DESIGN.md "Data layout"):
+    every tensor counted once per kernel that must read or write it."""
+    H, F = cfg.sdf.hidden, cfg.feature_size
+    nh = cfg.sdf.n_lin - 1                         # hidden activations h_1..h_{L-1} of the SDF net
+    nr = cfg.rgb.n_lin - 1
+    row, frow = 4 * H, 4 * F
+    return {
+        "i2sdf_sdf_forward_grad": nh * row * 3 + frow + 160 + 28,      # write h, write abar, re-read h (chain), feature, PE, sdf/grad
+        "i2sdf_sdf_backward": nh * row * (2 + 2 + 2 + 1) + frow + 200,  # sweep 1: read h, abar, write G(hbar), G2; sweep 2: read h, G2, write G(a)
+        "i2sdf_weight_grads": nh * row * 4 + row + frow + nr * 2 * 4 * cfg.rgb.hidden + frow + 288,   # A, A', B, B' per SDF layer; rgb G(a), r
+        "i2sdf_rgb_forward": frow + nr * 4 * cfg.rgb.hidden + 128 + 12,
+        "i2sdf_rgb_backward": nr * 4 * cfg.rgb.hidden * 2 + frow + 40,
     }
 
 
@@ -125,6 +141,7 @@ def main():
         eng.set_wgrad_bf16x3(bool(args.bf16x3 & 2))
         eng.set_train_forward_bf16x3(bool(args.bf16x3 & 4))
         eng.set_sdf_backward_bf16x3(bool(args.bf16x3 & 8))
+        eng.set_rgb_bf16x3(bool(args.bf16x3 & 16))
     for i in range(args.warmup):
         step(i)
     fence()
@@ -170,17 +187,29 @@ def main():
         PEAK = 157.3            # TFLOP/s, fp32-input MFMA on MI355X (MI355X_MICROARCH.md)
         PEAK_X3 = 2500.0 / 6    # bf16 dense MFMA peak / six bf16 MFMAs per fp32 product block (csrc/x3.h): fp32-equivalent TFLOP/s
         x3 = {"i2sdf_sample_rays": eng.sdf_forward_bf16x3, "i2sdf_sdf_forward_grad": eng.train_forward_bf16x3,
-              "i2sdf_sdf_backward": eng.sdf_backward_bf16x3, "i2sdf_weight_grads": eng.wgrad_bf16x3}
+              "i2sdf_sdf_backward": eng.sdf_backward_bf16x3, "i2sdf_weight_grads": eng.wgrad_bf16x3,
+              "i2sdf_rgb_forward": eng.rgb_bf16x3, "i2sdf_rgb_backward": eng.rgb_bf16x3}
         roof = None
         if dom:
+            # the roof that binds the dominant entry point: time at the arithmetic peak vs time at the HBM peak (8 TB/s) for its
+            # algorithmic FLOPs / bytes; `achieved` and `peak` are reported in the unit of the binding roof
             ach = kern[dom]["tflops"]
             peak = PEAK_X3 if x3.get(dom) else PEAK
-            roof = {"bound": "mfma", "kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent)" if x3.get(dom) else "f32 MFMA",
-                    "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
-                    "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
-                    "traffic": profiled_traffic(dom),
-                    "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
-                                                     / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
+            npts = {"i2sdf_rgb_forward": M_main, "i2sdf_rgb_backward": M_main}.get(dom, M_sdf)
+            alg_bytes = bytes_per_point(cfg).get(dom, 0) * npts
+            t_launch = kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1e-9) * 1e-3
+            t_mfma, t_hbm = launch_flops[dom] / (peak * 1e12), alg_bytes / 8.0e12
+            common = {"kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent)" if x3.get(dom) else "f32 MFMA",
+                      "traffic": profiled_traffic(dom), "tflops": round(ach, 2), "frac_of_arithmetic_peak": round(ach / peak, 4),
+                      "algorithmic_bytes": int(alg_bytes), "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
+                      "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
+                                                       / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
+            if t_hbm > t_mfma:
+                gbs = alg_bytes / t_launch / 1e9
+                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+            else:
+                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
+            roof.update(common)
         total_flops = sum(launch_flops.values())
         result = {
             "metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,

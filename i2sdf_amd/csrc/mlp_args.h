@@ -33,6 +33,29 @@ struct SdfBwdArgs {
   float* ones4;                         // (Mp,4) {1,0,0,0}
 };
 
+struct RgbFwdArgs {
+  const float* fwd; int n_fwd; int L;
+  const float* dirs; int n_per_ray;     // view dir of point m = dirs[m / n_per_ray]
+  const float* feat;                    // (Mp, F)
+  int64_t M, Mp;
+  float* rgb;                           // (M,3)
+  float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
+  float* pev_save;                      // (Mp, PECV*8) PE(view dir), or nullptr
+};
+
+struct RgbBwdArgs {
+  const float* rev; int n_rev; int L;
+  int64_t M, Mp;
+  const float* rgb;         // (M,3) forward output
+  const float* rgb_bar;     // (M,3)
+  const float* rs;          // (L-1, Mp, H)
+  float* gar;               // (L-1, Mp, H)  G(a_l), l = 0..L-2
+  float* ga_last;           // (Mp, 4)       G(a_{L-1}) (3 used)
+  float* fbar;              // (Mp, F)
+};
+
 // bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points
 void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st);
 void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st);

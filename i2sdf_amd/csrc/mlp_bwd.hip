@@ -232,16 +232,6 @@ __global__ __launch_bounds__(256) void sdf_bwd_split_kernel(SdfBwdArgs a, int64_
 }  // namespace
 
 // ---- radiance net backward ---------------------------------------------------------------------------------
-struct RgbBwdArgs {
-  const float* rev; int n_rev; int L;
-  int64_t M, Mp;
-  const float* rgb;         // (M,3) forward output
-  const float* rgb_bar;     // (M,3)
-  const float* rs;          // (L-1, Mp, H)
-  float* gar;               // (L-1, Mp, H)  G(a_l), l = 0..L-2
-  float* ga_last;           // (Mp, 4)       G(a_{L-1}) (3 used)
-  float* fbar;              // (Mp, F)
-};
 
 namespace {
 
@@ -455,13 +445,23 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
   if (d.hidden == 256 && p->F == 256) {
     a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
     const int64_t bulk = split_bulk_points(M);
+    auto full = [&](const RgbBwdArgs& x, unsigned g) {
+      if (p->rgb_bf16x3) {
+        RgbBwdArgs x3 = x;
+        x3.rev = packed + p->scale_floats + p->rgb.rev3_chunk0 * CHUNK_FLOATS;
+        x3.n_rev = rgb_rev3_stages(256, 256, d.n_lin);
+        i2sdf_launch_rgb_bwd3(x3, g, st);
+      } else {
+        launch_lds(rgb_bwd_kernel<256, 256>, g, st, x);
+      }
+    };
     if (bulk > 0) {
       a.M = bulk;
-      launch_lds(rgb_bwd_kernel<256, 256>, (unsigned)(bulk / PTS_PER_WG), st, a);
+      full(a, (unsigned)(bulk / PTS_PER_WG));
       a.M = M;
       launch_lds_bytes(KS_LDS_BYTES, rgb_bwd_split_kernel<256, 256>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
     } else {
-      launch_lds(rgb_bwd_kernel<256, 256>, grid, st, a);
+      full(a, grid);
     }
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_rev = rgb_rev_stages(64, 64, d.n_lin);

@@ -83,6 +83,12 @@ __host__ __device__ constexpr int sdf_rev3_bwd_stages(int H, int F, int PEC, int
   if (has_skip) c += x3_bwd_chunks(PT, H / 16);
   return c / SC;
 }
+__host__ __device__ constexpr int rgb_fwd3_stages(int H, int F, int PEDV, int L) {
+  return (x3_op_chunks(H / 32, cdiv(PEDV, 16) + F / 16) + (L - 2) * x3_op_chunks(H / 32, H / 16) + rowvec_chunks(H / 8, 3)) / SC;
+}
+__host__ __device__ constexpr int rgb_rev3_stages(int H, int F, int L) {
+  return (rowvec_chunks(H / 8, 3) + (L - 2) * x3_bwd_chunks(H / 32, H / 16) + x3_bwd_chunks(F / 32, H / 16)) / SC;
+}
 __host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
 // reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space
 __host__ __device__ constexpr int sdf_rev_stages(int H, int PEC, int L, bool has_skip) {

@@ -236,15 +236,6 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_split_kernel(SdfTrainFwdArg
 }  // namespace
 
 // ---- radiance network ---------------------------------------------------------------------------------------
-struct RgbFwdArgs {
-  const float* fwd; int n_fwd; int L;
-  const float* dirs; int n_per_ray;     // view dir of point m = dirs[m / n_per_ray]
-  const float* feat;                    // (Mp, F)
-  int64_t M, Mp;
-  float* rgb;                           // (M,3)
-  float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
-  float* pev_save;                      // (Mp, PECV*8) PE(view dir), or nullptr
-};
 
 namespace {
 
@@ -437,13 +428,24 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   if (d.hidden == 256 && p->F == 256) {
     a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
     const int64_t bulk = split_bulk_points(M);
+    // full workgroups optionally in bf16x3 split arithmetic (mlp_x3.hip); the split-K tail keeps the fp32 MFMA kernel
+    auto full = [&](const RgbFwdArgs& x, unsigned g) {
+      if (p->rgb_bf16x3) {
+        RgbFwdArgs x3 = x;
+        x3.fwd = packed + p->scale_floats + p->rgb.fwd3_chunk0 * CHUNK_FLOATS;
+        x3.n_fwd = rgb_fwd3_stages(256, 256, PE<4>::DIM, d.n_lin);
+        i2sdf_launch_rgb_fwd3(x3, g, st);
+      } else {
+        launch_lds(rgb_fwd_kernel<256, 256, 4>, g, st, x);
+      }
+    };
     if (bulk > 0) {          // full rounds with one 32-point tile per wave, the partial last round as split-K workgroups
       RgbFwdArgs b = a;
       b.M = bulk;
-      launch_lds(rgb_fwd_kernel<256, 256, 4>, (unsigned)(bulk / PTS_PER_WG), st, b);
+      full(b, (unsigned)(bulk / PTS_PER_WG));
       launch_lds_bytes(KS_LDS_BYTES, rgb_fwd_split_kernel<256, 256, 4>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
     } else {
-      launch_lds(rgb_fwd_kernel<256, 256, 4>, grid, st, a);
+      full(a, grid);
     }
   } else if (d.hidden == 64 && p->F == 64) {
     a.n_fwd = rgb_fwd_stages(64, 64, PE<4>::PEC, d.n_lin);

@@ -214,6 +214,22 @@ int build_rgb(i2sdf_plan* p, Builder& b) {
   for (int l = L - 2; l >= 1; --l) emit_dense_bwd(b, np, l, H / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H);
   emit_dense_bwd(b, np, 0, F / 32, H / 8, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H);   // feature columns only
   np.rev_chunks = b.chunk - np.rev_chunk0;
+  // bf16x3 streams (x3.h): layer 0 reduces over [PE(view) padded to 16-chunks | feature]
+  np.fwd3_chunk0 = b.chunk;
+  if ((H / 32) % 2 == 0 && F % 32 == 0 && (F / 32) % 2 == 0) {
+    const int PV16 = cdiv(PED, 16);
+    emit_dense_fwd3(b, np, 0, H / 32, PV16 + F / 16, ColMap{PV16 * 16, 0, PED, PED, F}, 1.0f);
+    for (int l = 1; l < L - 1; ++l) emit_dense_fwd3(b, np, l, H / 32, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1.0f);
+    emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  }
+  np.fwd3_chunks = b.chunk - np.fwd3_chunk0;
+  np.rev3_chunk0 = b.chunk;
+  if ((H / 32) % 2 == 0 && F % 32 == 0 && (F / 32) % 2 == 0) {
+    emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    for (int l = L - 2; l >= 1; --l) emit_dense_bwd3(b, np, l, H / 32, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H, 1.0f);
+    emit_dense_bwd3(b, np, 0, F / 32, H / 16, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H, 1.0f);
+  }
+  np.rev3_chunks = b.chunk - np.rev3_chunk0;
   return I2SDF_OK;
 }
 
@@ -316,6 +332,11 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
   if (option == I2SDF_OPT_SDF_BWD_BF16X3) {
     if (value && (p->sdf.rev3_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
     p->sdf_bwd_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  if (option == I2SDF_OPT_RGB_BF16X3) {
+    if (value && (p->rgb.rev3_chunks == 0 || p->rgb.d.hidden != 256 || p->F != 256 || p->rgb.d.n_lin < 3)) return I2SDF_EINVAL;
+    p->rgb_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_WGRAD_BF16X3) {

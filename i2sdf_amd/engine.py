@@ -33,11 +33,14 @@ class RenderEngine:
             self.set_sdf_forward_bf16x3(True)
         self.train_forward_bf16x3 = False
         self.sdf_backward_bf16x3 = False
+        self.rgb_bf16x3 = False
         if cfg.bf16x3:
             self.set_wgrad_bf16x3(True)
             if cfg.sdf.hidden == 256 and cfg.feature_size == 256:
                 self.set_train_forward_bf16x3(True)
                 self.set_sdf_backward_bf16x3(True)
+            if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
+                self.set_rgb_bf16x3(True)
         sc = cfg.sampler
         self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
                                   N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
@@ -120,6 +123,11 @@ class RenderEngine:
         """SDF backward sweeps (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_SDF_BWD_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SDF_BWD_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.sdf_backward_bf16x3 = bool(on)
+
+    def set_rgb_bf16x3(self, on: bool):
+        """Radiance forward / backward (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_RGB_BF16X3)."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
+        self.rgb_bf16x3 = bool(on)
 
     def set_wgrad_bf16x3(self, on: bool):
         """Full 256x256 weight-gradient blocks in bf16x3 split arithmetic (I2SDF_OPT_WGRAD_BF16X3)."""

@@ -89,6 +89,8 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
 #define I2SDF_OPT_TRAIN_FWD_BF16X3 4
 /*   I2SDF_OPT_SDF_BWD_BF16X3: the full workgroups of i2sdf_sdf_backward (both sweeps, 256-wide nets). */
 #define I2SDF_OPT_SDF_BWD_BF16X3 8
+/*   I2SDF_OPT_RGB_BF16X3: the full workgroups of i2sdf_rgb_forward / i2sdf_rgb_backward (256-wide nets). */
+#define I2SDF_OPT_RGB_BF16X3 16
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
