@@ -113,6 +113,26 @@ def test_entry_points_validate_arguments_without_a_gpu(lib):
     h.i2sdf_plan_destroy(plan)
 
 
+def test_plan_options(lib):
+    """i2sdf_plan_set_option: the bf16x3 twins exist for 256-wide nets only; unknown options are rejected."""
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    h = lib.load()
+    rc, plan, _, _ = _plan(lib, synthetic_conf())
+    assert rc == 0
+    for opt in (lib.OPT_SDF_FWD_BF16X3, lib.OPT_WGRAD_BF16X3, lib.OPT_TRAIN_FWD_BF16X3, lib.OPT_SDF_BWD_BF16X3, lib.OPT_RGB_BF16X3):
+        assert h.i2sdf_plan_set_option(plan, opt, 1) == 0 and h.i2sdf_plan_set_option(plan, opt, 0) == 0
+    assert h.i2sdf_plan_set_option(plan, 12345, 1) == -1
+    assert h.i2sdf_plan_set_option(None, lib.OPT_WGRAD_BF16X3, 1) == -1
+    h.i2sdf_plan_destroy(plan)
+    rc, plan, _, _ = _plan(lib, plumbing_conf())                 # 64-wide nets: sampler forward only
+    assert rc == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SDF_FWD_BF16X3, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_TRAIN_FWD_BF16X3, 1) == -1
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SDF_BWD_BF16X3, 1) == -1
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_RGB_BF16X3, 1) == -1
+    h.i2sdf_plan_destroy(plan)
+
+
 def test_missing_library_fails_loudly(monkeypatch, lib):
     from i2sdf_amd import lib as L
     monkeypatch.setattr(L, "_lib", None)

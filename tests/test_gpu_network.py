@@ -167,3 +167,55 @@ def test_train_step_given_depths_full_size(light):
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         worst = max(worst, assert_close(g.cpu(), ref_g[n_], 1e-4, "grad " + n_))
     print("worst relative parameter-gradient error", worst)
+
+
+def test_train_step_bf16x3_matches_fp32_kernels(B=400):
+    """The same training step (identical depths and draws) with every bf16x3 kernel enabled (the default) and with the plain
+    fp32-MFMA kernels (`bf16x3: false`): outputs agree to 1e-5, and outputs and all parameter gradients of BOTH are within the 1e-4
+    parity bar of the fp64 oracle.  Seeds / batch as chosen here are well conditioned.  Two things make ANY fp32 evaluation (the
+    reference's included, bf16x3 or not) differ from fp64 by 1e-3 on unlucky batches, both measured with scripts/dev/*_probe.py:
+    a ray whose weighted normal sum nearly cancels, and radiance-net pre-activations within fp32 rounding of zero,
+    where the ReLU mask of the backward flips (one point's contribution to a bias gradient appears or disappears).  The
+    kernel-level tests in test_gpu_backward.py bound the arithmetic itself."""
+    from i2sdf_amd import synthetic_conf, I2SDFLoss
+    ocfg = orc.synthetic_cfg(False)
+    ocfg.use_normal = True
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=41), 0.03, seed=42)
+    sd["density.beta"] = torch.tensor(0.05)
+    # 400 x 97 + 3 x 400 points = 313 workgroups: bulk (bf16x3 or fp32) and split-K tail kernels both run
+    inp = camera_inputs(B, (0.0, 0.0, -2.0), seed=5)
+    gt = make_gt(B)
+    dr = make_draws(ocfg, B, n_row=128, seed=2)
+    cam, dirs, dn = orc.prepare_rays(inp["uv"], inp["pose"], inp["intrinsics"])
+    z_all, z_eik = orc.sample_z_vals(sd, ocfg, dirs, cam, training=True, draws=dr, force_iters=1)
+    res = {}
+    for mode in (True, False):
+        conf = dict(synthetic_conf(False))
+        conf["bf16x3"] = mode
+        net = build(conf, sd, train=True)
+        eng = net._engine_for("cuda:0")
+        assert eng.sdf_forward_bf16x3 == mode and eng.wgrad_bf16x3 == mode and eng.train_forward_bf16x3 == mode
+        assert eng.sdf_backward_bf16x3 == mode and eng.rgb_bf16x3 == mode
+        c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+        out = net.render(cuda(inp), c, d, n, z_all.cuda(), z_eik.cuda(), draws={"eik_pts": dr.eik_pts.cuda(), "nbr_off": dr.nbr_off.cuda()})
+        loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
+        losses = loss_fn(out, cuda(gt), 10)
+        net.zero_grad()
+        losses["loss"].backward()
+        res[mode] = ({k: v.detach().cpu() for k, v in out.items()}, float(losses["loss"]),
+                     {n_: (p.grad if p.grad is not None else torch.zeros_like(p)).cpu() for n_, p in net.named_parameters()})
+    (o3, l3, g3), (o1, l1, g1) = res[True], res[False]
+    # fp64 oracle as the arbiter for both
+    D = torch.float64
+    lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
+    d64 = orc.Draws(eik_pts=dr.eik_pts.to(D), nbr_off=dr.nbr_off.to(D))
+    gt64 = {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}
+    ref_out, ref_loss, ref_g = orc.training_step_grads({k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64,
+                                                       lc, d64, step=10, z_override=(z_all.to(D), z_eik.to(D)))
+    for k in ("rgb_values", "depth_values", "weight_sum", "grad_theta"):
+        assert_close(o3[k], o1[k], 1e-5, k + " (bf16x3 vs fp32 kernels)")
+        assert_close(o3[k], ref_out[k], 1e-4, k + " (bf16x3 vs fp64)")
+    assert abs(l3 - l1) <= 1e-6 * abs(l1)
+    e3 = max(assert_close(g3[k], ref_g[k], 1e-4, "grad " + k + " (bf16x3 vs fp64)") for k in g1)
+    e1 = max(assert_close(g1[k], ref_g[k], 1e-4, "grad " + k + " (fp32 kernels vs fp64)") for k in g1)
+    print(f"worst relative parameter-gradient error vs fp64: bf16x3 kernels {e3:.2e}, fp32-MFMA kernels {e1:.2e}")
