@@ -80,7 +80,10 @@ struct WStream {
   // Returns the LDS buffer holding the next stage.  All 4 waves must call this in lock step.
   __device__ __forceinline__ const float* advance(int tid) {
 #ifndef I2SDF_ABL_NOBARRIER
-    __syncthreads();      // (a) my DMA for this stage landed (hipcc drains vmcnt before the barrier),
+    // (a) my DMA pieces of this stage have landed: hipcc usually drains vmcnt in front of the barrier by itself, but it
+    // tracks LDS DMA per address and was seen to leave the wait out (wgrad.hip) -- the protocol must not depend on that
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    __syncthreads();
 #endif
     // 
                           // (b) every wave's did, (c) every wave finished reading the other buffer
@@ -92,6 +95,7 @@ struct WStream {
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
   __device__ __forceinline__ const float* advance_barrier() {
 #ifndef I2SDF_ABL_NOBARRIER
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), see advance()
     __syncthreads();
 #endif
     return lds + cur * STAGE_FLOATS;

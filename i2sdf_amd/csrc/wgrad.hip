@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgLaunch L) {
     // ---- one stage: P = buffer holding this stage's planes
     auto stage = [&](int s, auto Pc) {
       constexpr int P = decltype(Pc)::value;
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA of stage s+1 has landed (hipcc does not insert this wait by itself)
       if (s > 0) __syncthreads();          // stage s+1 landed (issued one stage ago); everyone is done with stage s-1
       issue(s + 2);
       const bool more = s + 1 < nst;
@@ -286,6 +287,140 @@ __global__ __launch_bounds__(256) void wgrad3_kernel(WgLaunch L) {
 #pragma unroll
     for (int ta = 0; ta < 4; ++ta) bsum[ta] += __shfl_xor(bsum[ta], 32);
     if (kg == 0) *reinterpret_cast<f32x4*>(out + t.bias_off + wa * 128 + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Second generation of the bf16x3 block kernel: the split PLANES go through LDS.
+// wgrad3_kernel above lets every wave split both of its operand halves, i.e. every 128-column slice is split twice (by the
+// two waves that consume it) and the planes of two stages live in registers (no room left to interleave VALU and MFMA).
+// Here wave w owns one quarter of a stage (operand w>>1, column half w&1): it DMAs the raw fp32 rows, splits them ONCE and
+// writes the three bf16 planes back to LDS in MFMA operand layout; consumers read planes only.  Per stage and wave: 176
+// instead of 352 VALU ops of splitting, ~100 VGPRs instead of 250, one barrier.
+//   LDS: raw ring 2 x 32 KB + plane ring 2 x 48 KB = 160 KB.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int W3P_RAW = 2 * W3_PTS * 256;                 // floats per raw stage (32 KB)
+constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
+constexpr int W3P_LDS_BYTES = (2 * W3P_RAW + 2 * W3P_PL) * 4;
+
+__global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* rawb = lds;
+  float* plb = lds + 2 * W3P_RAW;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
+  const WgTask& t = L.t[blockIdx.y];
+  const int64_t chunk = blockIdx.x;
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const WgJob job = t.j[jb];
+    const int64_t m_lo = chunk * WG_CH;
+    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
+    if (m_hi <= m_lo) continue;
+    const int rows = (int)(m_hi - m_lo);
+    const int nst = (rows + W3_PTS - 1) / W3_PTS;
+    const float* dbase = (opB ? job.B : job.A) + m_lo * (opB ? job.ldb : job.lda) + 128 * (w & 1) + 4 * i32;
+    const int dld = opB ? job.ldb : job.lda;
+    const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
+    const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
+    // raw rows of stage s: 8 DMA pieces of this wave's quarter (clamped rows are masked when they are split)
+    auto issue = [&](int s) __attribute__((always_inline)) {
+      float* dst = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int row = s * W3_PTS + 8 * kg + j;
+        row = row < rows ? row : rows - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dbase + (int64_t)row * dld),
+                                         (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
+      }
+    };
+    unsigned pl[4][3][4];                 // planes of the quarter being split: [tile][plane][point pair]
+    // point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: read raw, mask / relu / bias sums, split
+    auto split_pair = [&](int s, int i) __attribute__((always_inline)) {
+      const float* src = rawb + (s & 1) * W3P_RAW + (w * 8 + 2 * i) * 256 + lane * 4;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi_ = *reinterpret_cast<const f32x4*>(src + 256);
+      const int p0 = s * W3_PTS + 8 * kg + 2 * i;
+      const float k0 = p0 < rows ? 1.f : 0.f, k1 = p0 + 1 < rows ? 1.f : 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const float x0 = fmaxf(lo[tt], relu_lo) * k0, x1 = fmaxf(hi_[tt], relu_lo) * k1;
+        bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
+        split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][2][i]);
+      }
+    };
+    auto write_planes = [&](int s) __attribute__((always_inline)) {
+      float* dst = plb + (s & 1) * W3P_PL + w * (4 * 3 * 256) + lane * 4;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          *reinterpret_cast<u32x4*>(dst + (tt * 3 + p) * 256) = u32x4{pl[tt][p][0], pl[tt][p][1], pl[tt][p][2], pl[tt][p][3]};
+    };
+    auto plane = [&](int s, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
+      return *reinterpret_cast<const u32x4*>(plb + (s & 1) * W3P_PL + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
+    };
+    __syncthreads();                       // the previous job is done with LDS
+    issue(0);
+    if (nst > 1) issue(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split_pair(0, i);
+    write_planes(0);
+    // one stage.  MORE: stage s+1 exists and is split here, spread over the four MFMA phases
+    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
+      constexpr bool MORE = decltype(Mc)::value;
+      // raw(s+1) was DMA'd one stage ago.  hipcc tracks LDS DMA per address and does NOT drain vmcnt at this barrier (the
+      // ISA shows lgkmcnt(0) only), so the wait is explicit: vmcnt(0) = every DMA piece this wave issued has landed.
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();                     // planes(s) written, raw(s+1) landed, everyone done with stage s-1
+      if (s + 2 < nst) issue(s + 2);       // into the raw slot of stage s (already split)
+      u32x4 ap[4][3];
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ap[ta][p] = plane(s, wa, ta, p);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        u32x4 bp[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bp[p] = plane(s, 2 + wb, tb, p);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? 2 : 0);
+          const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? 2 : 0);
+#pragma unroll
+          for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[sb], acc[ta][tb]);
+        }
+        if (MORE) split_pair(s + 1, tb);
+      }
+      if (MORE) write_planes(s + 1);
+    };
+    using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
+    for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
+    stage(nst - 1, BF{});
+  }
+  float* out = L.partials + chunk * L.chunk_stride;
+  const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
+#pragma unroll
+  for (int ta = 0; ta < 4; ++ta)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ri = (r & 3) + 8 * (r >> 2) + 4 * kg;
+      const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+      *reinterpret_cast<f32x4*>(out + toff + (int64_t)(4 * ri + ta) * t.ldo + 4 * i32) = v;
+    }
+  if (t.has_bias != 0 && !opB) {           // waves 0 / 1 hold the column sums of A half 0 / 1
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) bsum[tt] += __shfl_xor(bsum[tt], 32);
+    if (kg == 0) *reinterpret_cast<f32x4*>(out + t.bias_off + (w & 1) * 128 + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
   }
 }
 
@@ -519,8 +654,13 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
       dim3 grid((unsigned)n_chunks, (unsigned)L.n);
       if (var == 4) {
+#ifdef I2SDF_WGRAD3_REGISTER_PLANES
         (void)hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
         wgrad3_kernel<<<grid, 256, W3_LDS_BYTES, st>>>(L);
+#else
+        (void)hipFuncSetAttribute((const void*)wgrad3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
+        wgrad3p_kernel<<<grid, 256, W3P_LDS_BYTES, st>>>(L);
+#endif
       }
       else if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       else if (var == 1) wgrad_kernel<1, 0><<<grid, 64, 0, st>>>(L);
