@@ -400,6 +400,13 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
           for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[sb], acc[ta][tb]);
         }
         if (MORE) split_pair(s + 1, tb);
+#ifdef W3P_SGB
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          I2SDF_SGB(I2SDF_MASK_MFMA, 1);
+          I2SDF_SGB(0x002, W3P_SGB);
+        }
+#endif
       }
       if (MORE) write_planes(s + 1);
     };
