@@ -149,154 +149,16 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2) per block and chunk.
-// 16 points (one MFMA k-group of v_mfma_f32_32x32x16_bf16) form a stage: the four waves DMA the 16 x 256 slices of both
-// operands into LDS (ring of three stages, each slice is consumed by two waves), read their halves back in MFMA operand
-// layout (lane = column quad 4i..4i+3 x 8 consecutive points), split every fp32 value into three bf16 terms and run the six
-// leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
-// The splits of stage s+1 are dealt into the MFMA shadows of stage s.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int W3_PTS = 16;
-constexpr int W3_STAGE_FLOATS = 2 * W3_PTS * 256;        // A and B slices: 32 KB
-constexpr int W3_LDS_BYTES = 3 * W3_STAGE_FLOATS * 4;
-
-__global__ __launch_bounds__(256) void wgrad3_kernel(WgLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
-  const WgTask& t = L.t[blockIdx.y];
-  const int64_t chunk = blockIdx.x;
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = t.has_bias != 0 && wb == 0;
-  for (int jb = 0; jb < t.njobs; ++jb) {
-    const WgJob job = t.j[jb];
-    const int64_t m_lo = chunk * WG_CH;
-    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
-    if (m_hi <= m_lo) continue;
-    const int rows = (int)(m_hi - m_lo);
-    const int nst = (rows + W3_PTS - 1) / W3_PTS;
-    // DMA: wave w fetches operand (w>>1), column half (w&1); lane (i32, kg) addresses row 8*kg + j, columns 128*half + 4*i32
-    const float* dbase = ((w >> 1) ? job.B : job.A) + m_lo * ((w >> 1) ? job.ldb : job.lda) + 128 * (w & 1) + 4 * i32;
-    const int dld = (w >> 1) ? job.ldb : job.lda;
-    auto issue = [&](int s) {
-      if (s >= nst) return;
-      float* dst = lds + (s % 3) * W3_STAGE_FLOATS + (w * 8) * 256;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int row = s * W3_PTS + 8 * kg + j;
-        row = row < rows ? row : rows - 1;                       // clamp: rows beyond the chunk are masked after the read
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dbase + (int64_t)row * dld),
-                                         (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
-      }
-    };
-    auto rd = [&](int s, int op, int half, int j) -> f32x4 {
-      return *reinterpret_cast<const f32x4*>(lds + (s % 3) * W3_STAGE_FLOATS + (op * 16 + half * 8 + j) * 256 + lane * 4);
-    };
-    // rows of stage s that lie beyond the chunk read as zero (B) / do not count (bias sums of A)
-    auto rdB = [&](int s, int j) -> f32x4 {
-      f32x4 x = rd(s, 1, wb, j);
-      if ((s + 1) * W3_PTS > rows && s * W3_PTS + 8 * kg + j >= rows) x = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (t.relu_b) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
-      return x;
-    };
-    auto rdA = [&](int s, int j) -> f32x4 {
-      const f32x4 x = rd(s, 0, wa, j);
-      if (do_bias && jb == 0) {
-        const bool ok = !((s + 1) * W3_PTS > rows && s * W3_PTS + 8 * kg + j >= rows);
-        if (ok) { bsum[0] += x.x; bsum[1] += x.y; bsum[2] += x.z; bsum[3] += x.w; }
-      }
-      return x;
-    };
-    unsigned Apl[2][4][3][4];    // [buffer][tile ta][plane][point pair]: 8 bf16 = the lane's 8 points
-    unsigned Bpl[2][3][4];       // [tb & 1][plane][point pair]
-    auto q4 = [](const unsigned (&d)[4]) { return u32x4{d[0], d[1], d[2], d[3]}; };
-    f32x4 Braw[2][8];            // [buffer][point j]: 4 tb values
-    __syncthreads();             // the previous job's LDS reads are done
-    issue(0); issue(1);
-    __syncthreads();             // stage 0 (and 1) landed
-    // ---- prologue (exposed once per job): planes of stage 0
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f32x4 lo = rdA(0, 2 * i), hi_ = rdA(0, 2 * i + 1);
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta) split3_pair(lo[ta], hi_[ta], Apl[0][ta][0][i], Apl[0][ta][1][i], Apl[0][ta][2][i]);
-      Braw[0][2 * i] = rdB(0, 2 * i); Braw[0][2 * i + 1] = rdB(0, 2 * i + 1);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split3_pair(Braw[0][2 * i][0], Braw[0][2 * i + 1][0], Bpl[0][0][i], Bpl[0][1][i], Bpl[0][2][i]);
-    // ---- one stage: P = buffer holding this stage's planes
-    auto stage = [&](int s, auto Pc) {
-      constexpr int P = decltype(Pc)::value;
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the DMA of stage s+1 has landed (hipcc does not insert this wait by itself)
-      if (s > 0) __syncthreads();          // stage s+1 landed (issued one stage ago); everyone is done with stage s-1
-      issue(s + 2);
-      const bool more = s + 1 < nst;
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        // six leading partial products, tiles interleaved so that consecutive MFMAs hit different accumulators
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-          const int sa = (p == 2 || p == 5) ? 1 : (p == 4 ? 2 : 0);
-          const int sb = (p == 1 || p == 5) ? 1 : (p == 3 ? 2 : 0);
-#pragma unroll
-          for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(q4(Apl[P][ta][sa]), q4(Bpl[tb & 1][sb]), acc[ta][tb]);
-        }
-        if (more) {                        // planes of stage s+1: point pair tb of every A tile, and two rows of B
-          const f32x4 lo = rdA(s + 1, 2 * tb), hi_ = rdA(s + 1, 2 * tb + 1);
-#pragma unroll
-          for (int ta = 0; ta < 4; ++ta)
-            split3_pair(lo[ta], hi_[ta], Apl[P ^ 1][ta][0][tb], Apl[P ^ 1][ta][1][tb], Apl[P ^ 1][ta][2][tb]);
-          Braw[P ^ 1][2 * tb] = rdB(s + 1, 2 * tb); Braw[P ^ 1][2 * tb + 1] = rdB(s + 1, 2 * tb + 1);
-        }
-        if (tb < 3) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            split3_pair(Braw[P][2 * i][tb + 1], Braw[P][2 * i + 1][tb + 1], Bpl[(tb + 1) & 1][0][i], Bpl[(tb + 1) & 1][1][i],
-                        Bpl[(tb + 1) & 1][2][i]);
-        } else if (more) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            split3_pair(Braw[P ^ 1][2 * i][0], Braw[P ^ 1][2 * i + 1][0], Bpl[0][0][i], Bpl[0][1][i], Bpl[0][2][i]);
-        }
-      }
-    };
-    for (int s = 0; s < nst; s += 2) {
-      stage(s, std::integral_constant<int, 0>{});
-      if (s + 1 < nst) stage(s + 1, std::integral_constant<int, 1>{});
-    }
-  }
-  float* out = L.partials + chunk * L.chunk_stride;
-  const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
-#pragma unroll
-  for (int ta = 0; ta < 4; ++ta)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ri = (r & 3) + 8 * (r >> 2) + 4 * kg;
-      const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
-      *reinterpret_cast<f32x4*>(out + toff + (int64_t)(4 * ri + ta) * t.ldo + 4 * i32) = v;
-    }
-  if (do_bias) {
-#pragma unroll
-    for (int ta = 0; ta < 4; ++ta) bsum[ta] += __shfl_xor(bsum[ta], 32);
-    if (kg == 0) *reinterpret_cast<f32x4*>(out + t.bias_off + wa * 128 + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
-  }
-}
+constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
 
 // ---------------------------------------------------------------------------------------------------------------
-// Second generation of the bf16x3 block kernel: the split PLANES go through LDS.
-// wgrad3_kernel above lets every wave split both of its operand halves, i.e. every 128-column slice is split twice (by the
-// two waves that consume it) and the planes of two stages live in registers (no room left to interleave VALU and MFMA).
-// Here wave w owns one quarter of a stage (operand w>>1, column half w&1): it DMAs the raw fp32 rows, splits them ONCE and
-// writes the three bf16 planes back to LDS in MFMA operand layout; consumers read planes only.  Per stage and wave: 176
-// instead of 352 VALU ops of splitting, ~100 VGPRs instead of 250, one barrier.
+// bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2 tiles of 128x128) per block and chunk.
+// 16 points form a stage.  Wave w owns one quarter of a stage (operand w>>1, column half w&1): it DMAs the raw fp32 rows
+// into LDS, reads them back in MFMA operand layout (lane = column quad 4i..4i+3 x 8 consecutive points), splits every value
+// ONCE into three bf16 terms and writes the planes back to LDS; consumers (two waves per quarter) read planes only and run
+// the six leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
+// The splits of stage s+1 are spread over the four MFMA phases of stage s.  (A first generation that let every wave split
+// both of its halves in registers needed 250 VGPRs and twice the VALU work: 1.75 vs 1.55 ms.)
 //   LDS: raw ring 2 x 32 KB + plane ring 2 x 48 KB = 160 KB.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W3P_RAW = 2 * W3_PTS * 256;                 // floats per raw stage (32 KB)
@@ -400,13 +262,6 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
           for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[sb], acc[ta][tb]);
         }
         if (MORE) split_pair(s + 1, tb);
-#ifdef W3P_SGB
-#pragma unroll
-        for (int i = 0; i < 24; ++i) {
-          I2SDF_SGB(I2SDF_MASK_MFMA, 1);
-          I2SDF_SGB(0x002, W3P_SGB);
-        }
-#endif
       }
       if (MORE) write_planes(s + 1);
     };
@@ -661,13 +516,8 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
       dim3 grid((unsigned)n_chunks, (unsigned)L.n);
       if (var == 4) {
-#ifdef I2SDF_WGRAD3_REGISTER_PLANES
-        (void)hipFuncSetAttribute((const void*)wgrad3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS_BYTES);
-        wgrad3_kernel<<<grid, 256, W3_LDS_BYTES, st>>>(L);
-#else
         (void)hipFuncSetAttribute((const void*)wgrad3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
         wgrad3p_kernel<<<grid, 256, W3P_LDS_BYTES, st>>>(L);
-#endif
       }
       else if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       else if (var == 1) wgrad_kernel<1, 0><<<grid, 64, 0, st>>>(L);
