@@ -1,0 +1,47 @@
+"""GPU: bitwise run-to-run reproducibility of the MLP and weight-gradient kernels.
+
+Everything in the library is deterministic by construction (no atomics; split-M partials are reduced in a fixed order), so a
+mismatch between two runs on the same inputs means a synchronisation bug.  This test exists because one was found this way:
+hipcc does not reliably drain the LDS-DMA `vmcnt` in front of `s_barrier`, and the weight-gradient kernel read DMA pieces
+that had not landed about once in four launches (scripts/dev/wgrad_race.py)."""
+import pytest
+import torch
+
+from oracle import i2sdf_oracle as orc
+from test_gpu_train_forward import make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("bf16x3", [True, False])
+def test_kernels_are_bitwise_reproducible(bf16x3):
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=13), 0.05, seed=14)
+    conf = dict(synthetic_conf(False))
+    conf["bf16x3"] = bf16x3
+    eng = make_engine(conf, sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    g = torch.Generator().manual_seed(6)
+    B, n = 420, 97                               # 42 000 points: bulk + split-K tail kernels, 42 weight-gradient chunks
+    M = B * n + 3 * B
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.5).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).cuda()
+    cw = torch.randn(B * n, 3, generator=g).cuda()
+    nb, sb = torch.randn(M, 3, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+    ref = None
+    for rep in range(12):
+        fwd = eng.sdf_forward_grad(points=x)
+        rgb_h, rs, pev = eng.rgb_forward(dirs, n, fwd["feat"], B * n)
+        gar, ga_last, fbar = eng.rgb_backward(rgb_h, cw, rs, B * n)
+        bw = eng.sdf_backward(fwd, sbar=sb, fbar=fbar, m_fbar=B * n, nbar=nb)
+        gflat = torch.zeros_like(flat)
+        eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
+        cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": fwd["hs"][:, :M], "abars": fwd["abars"][:, :M],
+               "rgb": rgb_h, "rs": rs[:, :B * n], "gar": gar[:, :B * n], "fbar": fbar[:B * n], "gus": bw["gus"][1:, :M],
+               "gas": bw["gas"][:, :M], "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
+        if ref is None:
+            ref = {k: v.clone() for k, v in cur.items()}
+            continue
+        for k in cur:
+            assert torch.equal(cur[k], ref[k]), f"{k} differs between run 0 and run {rep} ({int((cur[k] != ref[k]).sum())} entries)"
