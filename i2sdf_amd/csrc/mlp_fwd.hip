@@ -83,16 +83,14 @@ __global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__
   WStream ws;
   ws.begin(stream, lds, n_stages, tid);
   f32x16 accP[NT], accN[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accP[nt][r] = 0.f;
-  dense_x3<NT, PE16, 0, NPE>(ws, accP, pe, accN, hi, tid);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
+  {
+    X3FwdSrc<NT, 0, NPE, false> src{accN, pe, nullptr, hi, valid};
+    dense_x3g<NT, PE16, 1>(ws, src, accP, tid);
+  }
   for (int l = 1; l < L - 1; ++l) {
-    if (l == skip) dense_x3<NT, KH16 + PE16, KH16, NPE>(ws, accP, pe, accN, hi, tid);
-    else dense_x3<NT, KH16, KH16, NPE>(ws, accP, pe, accN, hi, tid);
+    X3FwdSrc<NT, KH16, NPE, false> src{accP, pe, nullptr, hi, valid};
+    if (l == skip) dense_x3g<NT, KH16 + PE16, 1>(ws, src, accN, tid);
+    else dense_x3g<NT, KH16, 1>(ws, src, accN, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
   }

@@ -63,95 +63,8 @@ __device__ __forceinline__ void x3_select_pe(const float (&full)[NC16 * 16], flo
     }
 }
 
-// One K-outer bf16x3 layer:  acc[NT] = bias + W * src, src(kc) = 8 fp32 values per lane for k-chunk kc.
-//   KACC  k-chunks [0, KACC) come from softplus100(accP) (the previous layer's pre-activations, D layout),
-//         k-chunks [KACC, KC16) from pe[] (this lane's 8 values per k-chunk, already selected by lane half: x3_select_pe).
-template <int NT, int KC16, int KACC, int NPE>
-__device__ __forceinline__ void dense_x3(WStream& ws, const f32x16 (&accP)[NT], const float (&pe)[NPE], f32x16 (&acc)[NT], int hi,
-                                         int tid) {
-  static_assert(NT % 2 == 0, "tiles are processed in pairs");
-  static_assert((KC16 - KACC) * 8 <= NPE, "pe[] too short");
-  constexpr int NB = NT * 4, G = NT / 2, PPK = G * 3, NPAIR = KC16 * PPK, NW = NPAIR * 2;
-  constexpr int TOT = round_up(NB + NW, SC), NS = TOT / SC, PFP = 2;
-  const int lane = tid & 63;
-  float v[8];
-  u32x4 bq[2][3];                       // split B operands of the current / next k-chunk
-  // unit u of the preparation of k-chunk kc: u < 8 -> value u ; u >= 8 -> split of the value pair u-8
-  auto prep = [&](int kc, int u, u32x4 (&b)[3]) {
-    if (kc >= KC16) return;
-    if (u < 8) {
-      if (kc < KACC) v[u] = softplus100(accP[kc >> 1][8 * (kc & 1) + u]);
-      else v[u] = pe[8 * (kc - KACC) + u];
-    } else {
-      const int i = u - 8;
-      unsigned p0, p1, p2;
-      split3_pair(v[2 * i], v[2 * i + 1], p0, p1, p2);
-      b[0][i] = p0; b[1][i] = p1; b[2][i] = p2;
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
-    // ---- bias chunks of this stage (fp32, D layout)
-#pragma unroll
-    for (int j = 0; j < SC; ++j) {
-      const int c = s * SC + j;
-      if (c < NB) {
-        const int nt = c / 4, q = c % 4;
-        const f32x4 b = __builtin_bit_cast(f32x4, cur[j * 64]);
-        acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
-      }
-    }
-    // ---- weight chunk pairs of this stage: pair slots [p0, p1) of 16
-    const int p0 = (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0;
-    const int p1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2;
-    u32x4 ring[PFP][2];
-#pragma unroll
-    for (int i = 0; i < PFP; ++i)
-      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
-    __builtin_amdgcn_sched_barrier(0);
-    bool issued = false;
-#pragma unroll
-    for (int jp = 0; jp < SC / 2; ++jp) {
-      if (jp >= p0 && jp < p1) {
-        const int w = (s * SC + 2 * jp - NB) / 2;          // pair index inside the op
-        const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
-        const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
-        if (jp + PFP < p1) {
-          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
-          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
-        }
-        const u32x4 (&b)[3] = bq[kc & 1];
-        acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
-        acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
-        if (sp < 2) {
-          acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
-          acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
-        }
-        if (sp == 0) {
-          acc[nt] = mfma_bf16(a0, b[2], acc[nt]);
-          acc[nt + 1] = mfma_bf16(a1, b[2], acc[nt + 1]);
-        }
-        if (!issued) { ws.advance_issue(tid); issued = true; }       // next stage's DMA in the shadow of the first MFMAs
-        // this pair's share of the preparation of k-chunk kc+1: 12 units over the PPK pairs of a k-chunk
-        {
-          const int pi = w % PPK;
-#pragma unroll
-          for (int u = 0; u < 12; ++u)
-            if (u * PPK / 12 == pi) prep(kc + 1, u, bq[(kc + 1) & 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (!issued) ws.advance_issue(tid);
-  }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Generalised K-outer bf16x3 op for the training kernels:  acc[NT] (+)= W * src.
+// K-outer bf16x3 op:  acc[NT] (+)= W * src.
 //   BIAS  : 1 = the stream starts with NT*4 fp32 bias chunks that initialise acc; 2 = the chunks are there but are skipped
 //           and acc starts at zero (backward sweeps over the forward stream); 0 = weight chunks only, acc is used as the
 //           caller left it (zeroed, or holding a running sum such as pbar).
@@ -292,9 +205,9 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 // B-operand sources -------------------------------------------------------------------------------------------------
 // softplus100 of the previous layer's pre-activations (D layout) for k-chunks < KACC, this lane's PE values beyond;
 // stores the activations (h row of the saved tensor) as they are produced
-template <int NT, int KACC, int NPE>
+template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
-  static constexpr bool STORES = true;
+  static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) {
