@@ -84,7 +84,59 @@ def eval_image():
           f"finite {bool(torch.isfinite(out['normal_map']).all())}, peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 
 
+def dense128():
+    """BASELINE.json metric convention 'dense-128': 128 shaded samples per ray, sampler bypassed (uniform depths)."""
+    dev = torch.device("cuda:0")
+    conf = synthetic_conf(False); conf["use_normal"] = True
+    torch.manual_seed(0)
+    net = I2SDFNetwork(conf).to(dev).train()
+    with torch.no_grad():
+        net.density.beta.fill_(0.02)
+    loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
+    opt = torch.optim.Adam(net.get_param_groups(5e-4), eps=1e-15)
+    B, n = 1024, 128
+    inp, gt = cam_batch(B, dev)
+    eng = net._engine_for(dev)
+    c, d, nrm = eng.ray_setup(inp["uv"], inp["pose"], inp["intrinsics"])
+    z = torch.linspace(0.0, 6.0, n + 1, device=dev).repeat(B, 1).contiguous()      # n samples + z_max column
+    z_eik = z[:, n // 2:n // 2 + 1].contiguous()
+
+    def step(i):
+        out = net.render(inp, c, d, nrm, z, z_eik)
+        l = loss_fn(out, gt, i)["loss"]
+        opt.zero_grad(set_to_none=True); l.backward(); opt.step()
+        return l
+    for i in range(2):
+        step(i)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(5):
+        l = step(2 + i)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    print(f"dense-128: {B} rays x {n} samples, sampler bypassed: {dt*1e3:.2f} ms/step, {B*n/dt/1e6:.2f} M ray-samples/s, loss {float(l):.4f}", flush=True)
+
+
+def cpu_single_thread():
+    """the CPU restatement additionally with one thread (bounded sample)."""
+    import sys as _s
+    _s.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    from oracle import i2sdf_oracle as orc
+    from helpers import camera_inputs, make_draws, make_gt
+    torch.set_num_threads(1)
+    ocfg = orc.synthetic_cfg(False); ocfg.use_normal = True
+    sd = orc.init_params(ocfg, seed=0); sd["density.beta"] = torch.tensor(0.02)
+    B = 16
+    inp = camera_inputs(B, (0.0, 0.0, -2.0), seed=0); gt = make_gt(B)
+    dr = make_draws(ocfg, B, n_row=256, seed=0)
+    lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
+    t0 = time.perf_counter()
+    orc.training_step_grads(sd, ocfg, inp, gt, lc, dr, step=10, force_iters=2)
+    dt = time.perf_counter() - t0
+    print(f"CPU oracle, 1 thread: {B} rays x 97 samples, k=2, fwd+loss+bwd: {dt:.2f} s/step = {B*97/dt:.0f} ray-samples/s", flush=True)
+
+
 if __name__ == "__main__":
+    dense128()
+    cpu_single_thread()
     train_case("cfg3 light-mask", True, 1024, 2)
     train_case("cfg5 4096 rays/GPU", False, 4096, 2)
     train_case("cfg2 natural k", False, 1024, 0)
