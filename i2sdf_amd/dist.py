@@ -18,8 +18,9 @@ def attach_data_parallel(net, group=None):
     world = dist.get_world_size(group)
 
     def sync(flat_grad: torch.Tensor):
+        # always through the collective once attached (a 1-rank group is a no-op for RCCL): the N=1 and N>1 code paths are the same
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
         if world > 1:
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
             flat_grad.mul_(1.0 / world)
 
     net.grad_sync = sync

@@ -202,7 +202,7 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
         losses = loss_fn(out, cuda(gt), 10)
         net.zero_grad()
         losses["loss"].backward()
-        res[mode] = ({k: v.detach().cpu() for k, v in out.items()}, float(losses["loss"]),
+        res[mode] = ({k: v.detach().cpu() for k, v in out.items()}, float(losses["loss"].detach()),
                      {n_: (p.grad if p.grad is not None else torch.zeros_like(p)).cpu() for n_, p in net.named_parameters()})
     (o3, l3, g3), (o1, l1, g1) = res[True], res[False]
     # fp64 oracle as the arbiter for both
