@@ -20,34 +20,32 @@ struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64
 struct WgTask {
   WgJob j[2];
   int32_t njobs, relu_b, has_bias, rows_store, cols_store, ldo;
+  int32_t variant, pad;
   int64_t out_off, bias_off;
 };
 struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t pad; int64_t chunk_stride; float* partials; };
 
 // AM = 0: A tile 128 wide (16 B per lane, rows 4i+ta)      AM = 1: A narrower than 32 columns (4 B per lane, row i)
 // BM = 0: B tile 128 wide (16 B per lane, cols 4j+tb)      BM = 1 / 2: B at most 32 / 64 columns wide (4 B per lane, col j + 32 tb)
-template <int AM, int BM>
-__global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
+// One wave accumulates the points [lo, hi) of every job of task t (lo/hi relative to the operands' first row; hi is capped by
+// the job's point count).  PF = point pairs per load group.
+template <int AM, int BM, int PF>
+__device__ __forceinline__ void wgrad_accumulate(const WgTask& t, int64_t lo, int64_t hi_cap, int lane,
+                                                 f32x16 (&acc)[AM ? 1 : 4][BM ? BM : 4], float (&bsum)[AM ? 1 : 4]) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
-  const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.y;
-  const WgTask& t = L.t[tile];
-  const int64_t chunk = blockIdx.x;
   const int i32 = lane & 31, hi = lane >> 5;
-  f32x16 acc[TA][TB];
 #pragma unroll
   for (int a = 0; a < TA; ++a)
 #pragma unroll
     for (int b = 0; b < TB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float bsum[TA];
 #pragma unroll
   for (int a = 0; a < TA; ++a) bsum[a] = 0.f;
   for (int jb = 0; jb < t.njobs; ++jb) {
     const WgJob job = t.j[jb];
-    const int64_t m_lo = chunk * WG_CH;
-    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
+    const int64_t m_lo = lo;
+    const int64_t m_hi = (hi_cap < job.m_count) ? hi_cap : job.m_count;
     if (m_hi <= m_lo) continue;
     const int npairs = (int)((m_hi - m_lo + 1) / 2);
     // Buffer loads with hardware range checking: rows >= m_hi and columns >= the operand width read as 0, so the
@@ -71,13 +69,13 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
     const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;           // branch-free optional ReLU on the B operand
     const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;       // branch-free optional column sums of A
     // Group double buffering: while the MFMAs of one group of point pairs run, the loads of the NEXT group are in flight.
-    float a0[PFW][TA], b0[PFW][TB], a1[PFW][TA], b1[PFW][TB];
+    float a0[PF][TA], b0[PF][TB], a1[PF][TA], b1[PF][TB];
     auto ldw = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off, unsigned add) -> float {
       return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off == OOB ? OOB : off + add, 0, 0));
     };
-    auto load_group = [&](float (&A)[PFW][TA], float (&Bv)[PFW][TB], unsigned pbase) {
+    auto load_group = [&](float (&A)[PF][TA], float (&Bv)[PF][TB], unsigned pbase) {
 #pragma unroll
-      for (int u = 0; u < PFW; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const unsigned pn = pbase + u;
         if (AM) A[u][0] = ldw(ra, a_off, pn * a_step);
         else {
@@ -95,9 +93,9 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
         }
       }
     };
-    auto compute_group = [&](const float (&A)[PFW][TA], const float (&Bv)[PFW][TB]) {
+    auto compute_group = [&](const float (&A)[PF][TA], const float (&Bv)[PF][TB]) {
 #pragma unroll
-      for (int u = 0; u < PFW; ++u) {
+      for (int u = 0; u < PF; ++u) {
         float bq[TB];
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb) bq[tb] = fmaxf(Bv[u][tb], relu_lo);
@@ -110,18 +108,25 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
       }
     };
     load_group(a0, b0, 0);
-    for (int p = 0; p < npairs; p += 2 * PFW) {
-      load_group(a1, b1, (unsigned)(p + PFW));
+    for (int p = 0; p < npairs; p += 2 * PF) {
+      load_group(a1, b1, (unsigned)(p + PF));
       __builtin_amdgcn_sched_barrier(0);
       compute_group(a0, b0);
       __builtin_amdgcn_sched_barrier(0);
-      load_group(a0, b0, (unsigned)(p + 2 * PFW));
+      load_group(a0, b0, (unsigned)(p + 2 * PF));
       __builtin_amdgcn_sched_barrier(0);
       compute_group(a1, b1);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  float* out = L.partials + chunk * L.chunk_stride;
+}
+
+// one wave writes its tile (and, for the first column tile of a block, the column sums of A = the bias gradient) to the chunk's partials
+template <int AM, int BM>
+__device__ __forceinline__ void wgrad_store(const WgTask& t, float* __restrict__ out, int lane,
+                                            const f32x16 (&acc)[AM ? 1 : 4][BM ? BM : 4], float (&bsum)[AM ? 1 : 4]) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
+  const int i32 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
@@ -147,6 +152,80 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
       else if (4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = f32x4{bsum[0], bsum[TA > 1 ? 1 : 0], bsum[TA > 2 ? 2 : 0], bsum[TA > 3 ? 3 : 0]};
     }
   }
+}
+
+template <int AM, int BM>
+__global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
+  const int lane = threadIdx.x & 63;
+  const WgTask& t = L.t[blockIdx.y];
+  const int64_t chunk = blockIdx.x;
+  f32x16 acc[TA][TB];
+  float bsum[TA];
+  wgrad_accumulate<AM, BM, PFW>(t, chunk * WG_CH, chunk * WG_CH + WG_CH, lane, acc, bsum);
+  wgrad_store<AM, BM>(t, L.partials + chunk * L.chunk_stride, lane, acc, bsum);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The narrow blocks (an operand at most 64 columns wide: positional-encoding columns, the sdf / rgb output rows) are few:
+// 10 tiles x 100 chunks at synthetic.yml shapes, i.e. fewer single-wave tasks than the chip has SIMDs, each a long serial
+// stream.  They run as ONE launch of 4-wave workgroups: a wave takes a quarter of the chunk's points, the four partial tiles
+// are summed through LDS in a fixed order (deterministic) and wave 0 stores.  Three separate launches of single-wave
+// workgroups took 0.62 ms per step.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int PFN = 8;               // 128 point pairs per wave = 8 groups of 16
+constexpr int WGN_LDS_BYTES = 3 * (8 * 16 + 4) * 64 * 4;
+
+template <int AM, int BM>
+__device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTask& t, int64_t chunk, int wave, int lane, float* lds) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NW = TA * TB * 16 + TA;
+  f32x16 acc[TA][TB];
+  float bsum[TA];
+  const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
+  wgrad_accumulate<AM, BM, PFN>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
+  if (wave > 0) {
+    float* dst = lds + (wave - 1) * NW * 64 + lane;
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[((a * TB + b) * 16 + r) * 64] = acc[a][b][r];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int a = 0; a < TA; ++a) dst[(TA * TB * 16 + a) * 64] = bsum[a];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    // tile by tile (the scheduler would otherwise hoist all 3 x NW LDS reads in front of the adds and spill)
+#pragma unroll
+    for (int a = 0; a < TA; ++a)
+#pragma unroll
+      for (int b = 0; b < TB; ++b) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[a][b][r] += lds[(w * NW + (a * TB + b) * 16 + r) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int a = 0; a < TA; ++a) bsum[a] += lds[(w * NW + TA * TB * 16 + a) * 64 + lane];
+    wgrad_store<AM, BM>(t, L.partials + chunk * L.chunk_stride, lane, acc, bsum);
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float wgn_lds[];
+  // wave index as a scalar: the buffer descriptors built from it must be wave-uniform (else every load becomes a waterfall loop)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const WgTask& t = L.t[blockIdx.y];
+  const int64_t chunk = blockIdx.x;
+  if (t.variant == 1) wgrad_narrow_body<1, 0>(L, t, chunk, wave, lane, wgn_lds);
+  else if (t.variant == 2) wgrad_narrow_body<0, 1>(L, t, chunk, wave, lane, wgn_lds);
+  else wgrad_narrow_body<0, 2>(L, t, chunk, wave, lane, wgn_lds);
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
@@ -505,10 +584,8 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   auto variant = [](const WgTask& x) {
     return x.j[0].a_w == 256 ? 4 : (x.j[0].a_w <= 32 ? 1 : (x.j[0].b_w <= 32 ? 2 : (x.j[0].b_w <= 64 ? 3 : 0)));
   };
-  for (int var = 4; var >= 0; --var) {
-    std::vector<WgTask> sel;
-    for (const WgTask& x : tl.tasks) if (variant(x) == var) sel.push_back(x);
-    std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
+  for (WgTask& x : tl.tasks) x.variant = variant(x);
+  auto launch = [&](const std::vector<WgTask>& sel, int var) {
     for (size_t off = 0; off < sel.size(); off += MAX_TASKS) {
       WgLaunch L{};
       L.n = (int32_t)std::min<size_t>(MAX_TASKS, sel.size() - off);
@@ -518,12 +595,26 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       if (var == 4) {
         (void)hipFuncSetAttribute((const void*)wgrad3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
         wgrad3p_kernel<<<grid, 256, W3P_LDS_BYTES, st>>>(L);
+      } else if (var == 0) {
+        wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
+      } else {
+        (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
+        wgrad_narrow_kernel<<<grid, 256, WGN_LDS_BYTES, st>>>(L);
       }
-      else if (var == 0) wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
-      else if (var == 1) wgrad_kernel<1, 0><<<grid, 64, 0, st>>>(L);
-      else if (var == 2) wgrad_kernel<0, 1><<<grid, 64, 0, st>>>(L);
-      else wgrad_kernel<0, 2><<<grid, 64, 0, st>>>(L);
     }
+  };
+  for (int var : {4, 0}) {
+    std::vector<WgTask> sel;
+    for (const WgTask& x : tl.tasks) if (x.variant == var) sel.push_back(x);
+    std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
+    launch(sel, var);
+  }
+  {  // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
+    std::vector<WgTask> sel;
+    for (int var : {3, 1, 2})
+      for (int nj = 2; nj >= 1; --nj)
+        for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel.push_back(x);
+    launch(sel, 1);
   }
   WnTab tab{};
   int row0 = 0;
