@@ -387,17 +387,26 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
   const int brow = r < y.rsplit ? r : r - y.rsplit + y.rbase;
   const float* v = params + y.off_v + (int64_t)r * y.cols;
   constexpr int MAXC = 5;      // cols <= 320
+  // all columns of a chunk are loaded before any is added (5 independent loads in flight per lane, chunk loop unrolled)
+  const float* src[MAXC];
+  float sacc[MAXC];
 #pragma unroll
   for (int q = 0; q < MAXC; ++q) {
     const int c = lane + 64 * q;
-    float sacc = 0.f;
-    if (c < y.cols) {
-      const int kp = c < y.valid0 ? c : y.split + (c - y.base1);
-      const float* src = partials + y.blk_off + (int64_t)brow * y.ldo + kp;
-      for (int ch = wv; ch < n_chunks; ch += 4) sacc += src[ch * chunk_stride];
-    }
-    s_dw[wv][lane + 64 * q] = sacc;
+    const int kp = c < y.valid0 ? c : y.split + (c - y.base1);
+    src[q] = (c < y.cols) ? partials + y.blk_off + (int64_t)brow * y.ldo + kp : nullptr;
+    sacc[q] = 0.f;
   }
+#pragma unroll 2
+  for (int ch = wv; ch < n_chunks; ch += 4) {
+    float x[MAXC];
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) x[q] = src[q] ? src[q][ch * chunk_stride] : 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXC; ++q) sacc[q] += x[q];
+  }
+#pragma unroll
+  for (int q = 0; q < MAXC; ++q) s_dw[wv][lane + 64 * q] = sacc[q];
   if (lane == 0) {
     float b = 0.f;
     const float* bs = partials + y.bias_blk_off + brow;
