@@ -146,6 +146,79 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Eikonal / smoothness outputs of the network (model/network/__init__.py:188-193): from the gradients of the 3B extra points
+// [B uniform | B near-surface | B neighbours]   grad_theta = rows [0, 2B),
+//   diff_norm[i] = || normalize(g[B+i]) - normalize(g[2B+i]) ||_2,   normalize(v) = v / max(||v||, 1e-6)  (F.normalize eps)
+// and the backward of both in one launch.  In torch these are ~8 forward and ~25 autograd-backward kernels on (2B,3) tensors.
+// Conventions of the torch backward formulas are kept: d||x||/dx = 0 at x = 0; no gradient through ||v|| where ||v|| < eps.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr float NRM_EPS = 1e-6f;
+// No FMA contraction from here on: n1 - n2 must subtract the ROUNDED unit vectors, so that identical normals give exactly 0
+// (as they do in torch); contracted, the difference is the rounding error of n2 and the gradient an O(1) noise vector.
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ void unit3(const float* __restrict__ g, float (&v)[3], float (&n)[3], float& r) {
+  v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
+  r = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const float inv = 1.0f / fmaxf(r, NRM_EPS);
+  n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
+}
+
+__global__ __launch_bounds__(256) void eik_out_fwd_kernel(const float* __restrict__ g, int64_t B, float* __restrict__ theta,
+                                                           float* __restrict__ diff) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  float v1[3], n1[3], r1, v2[3], n2[3], r2;
+  unit3(g + (B + i) * 3, v1, n1, r1);
+  unit3(g + (2 * B + i) * 3, v2, n2, r2);
+  const float dx = n1[0] - n2[0], dy = n1[1] - n2[1], dz = n1[2] - n2[2];
+  diff[i] = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (theta) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { theta[i * 3 + c] = g[i * 3 + c]; theta[(B + i) * 3 + c] = v1[c]; }
+  }
+}
+
+__device__ __forceinline__ void unit3_bwd(const float (&n)[3], float r, const float (&gn)[3], float (&gv)[3]) {
+  if (r >= NRM_EPS) {       // clamp_min passes the gradient of ||v||: gv = (gn - n (gn.n)) / r
+    const float dot = gn[0] * n[0] + gn[1] * n[1] + gn[2] * n[2];
+    const float inv = 1.0f / r;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gv[c] = (gn[c] - n[c] * dot) * inv;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gv[c] = gn[c] * (1.0f / NRM_EPS);
+  }
+}
+
+__global__ __launch_bounds__(256) void eik_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ theta_bar,
+                                                           const float* __restrict__ diff_bar, int64_t B, float* __restrict__ g_bar) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= B) return;
+  float o0[3] = {0.f, 0.f, 0.f}, o1[3] = {0.f, 0.f, 0.f}, o2[3] = {0.f, 0.f, 0.f};
+  if (theta_bar) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o0[c] = theta_bar[i * 3 + c]; o1[c] = theta_bar[(B + i) * 3 + c]; }
+  }
+  if (diff_bar) {
+    float v1[3], n1[3], r1, v2[3], n2[3], r2;
+    unit3(g + (B + i) * 3, v1, n1, r1);
+    unit3(g + (2 * B + i) * 3, v2, n2, r2);
+    const float d[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
+    const float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    const float f = nd > 0.f ? diff_bar[i] / nd : 0.f;
+    const float gn1[3] = {f * d[0], f * d[1], f * d[2]}, gn2[3] = {-f * d[0], -f * d[1], -f * d[2]};
+    float a[3], b[3];
+    unit3_bwd(n1, r1, gn1, a);
+    unit3_bwd(n2, r2, gn2, b);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { o1[c] += a[c]; o2[c] += b[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { g_bar[i * 3 + c] = o0[c]; g_bar[(B + i) * 3 + c] = o1[c]; g_bar[(2 * B + i) * 3 + c] = o2[c]; }
+}
+
 }  // namespace
 
 extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N; }
@@ -174,4 +247,19 @@ extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B,
   loss_finalize_kernel<<<1, 64, 0, st>>>(a, nb);
   loss_grad_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(a);
   return i2sdf_hip_check(hipGetLastError(), "loss_forward_backward launch");
+}
+
+extern "C" int i2sdf_eikonal_outputs_forward(const float* grad_all, int64_t B, float* grad_theta, float* diff_norm, void* stream) {
+  if (B == 0) return I2SDF_OK;
+  if (!grad_all || !diff_norm || B < 0) return I2SDF_EINVAL;
+  eik_out_fwd_kernel<<<(unsigned)((B + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_all, B, grad_theta, diff_norm);
+  return i2sdf_hip_check(hipGetLastError(), "eikonal_outputs_forward launch");
+}
+
+extern "C" int i2sdf_eikonal_outputs_backward(const float* grad_all, const float* grad_theta_bar, const float* diff_norm_bar, int64_t B,
+                                              float* grad_all_bar, void* stream) {
+  if (B == 0) return I2SDF_OK;
+  if (!grad_all || !grad_all_bar || B < 0) return I2SDF_EINVAL;
+  eik_out_bwd_kernel<<<(unsigned)((B + 255) / 256), 256, 0, (hipStream_t)stream>>>(grad_all, grad_theta_bar, diff_norm_bar, B, grad_all_bar);
+  return i2sdf_hip_check(hipGetLastError(), "eikonal_outputs_backward launch");
 }

@@ -36,13 +36,17 @@ class _FusedLossFn(torch.autograd.Function):
             L.check(lib.i2sdf_loss_forward_backward(cfg, B, n_pc, *[L.ptr(t) for t in ins], L.ptr(gts[0]), L.ptr(gts[1]), L.ptr(gts[2]),
                                                     L.ptr(gts[3]), L.ptr(gts[4]), L.ptr(gts[5]), L.ptr(gts[6]), L.ptr(scratch), L.ptr(losses),
                                                     *[L.ptr(g) for g in grads], L.stream_ptr()), "i2sdf_loss_forward_backward")
+        if diff_norm is not None and not (cfg._obj.smooth_on and cfg._obj.smooth_w > 0):
+            grads[5] = None      # smoothness term inactive (:347-349): its gradient is identically zero -- let autograd skip that branch
         ctx.grads = grads
         return losses
 
     @staticmethod
     def backward(ctx, g):
         scale = g[0]            # only `loss` (entry 0) is differentiable; the itemised entries are reported values
-        out = [None, None, None] + [(gr * scale if gr is not None else None) for gr in ctx.grads]
+        live = [gr for gr in ctx.grads if gr is not None]
+        scaled = iter(torch._foreach_mul(live, scale))          # one launch for all of them
+        out = [None, None, None] + [(next(scaled) if gr is not None else None) for gr in ctx.grads]
         ctx.grads = None
         return tuple(out)
 

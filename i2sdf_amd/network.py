@@ -159,6 +159,39 @@ class _RenderFn(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _EikonalOutputsFn(torch.autograd.Function):
+    """grad_theta / diff_norm of the extra points (model/network/__init__.py:188-193): one HIP launch forward, one backward
+    (i2sdf_eikonal_outputs_*), instead of ~8 + ~25 element-wise torch kernels on (2B,3) tensors."""
+
+    @staticmethod
+    def forward(ctx, g_all, B):
+        from . import lib as L_
+        g_all = g_all.contiguous()
+        theta = torch.empty(2 * B, 3, device=g_all.device)
+        diff = torch.empty(B, device=g_all.device)
+        with torch.cuda.device(g_all.device):
+            L_.check(L_.load().i2sdf_eikonal_outputs_forward(L_.ptr(g_all), B, L_.ptr(theta), L_.ptr(diff), L_.stream_ptr()),
+                     "i2sdf_eikonal_outputs_forward")
+        ctx.save_for_backward(g_all)
+        ctx.B = B
+        ctx.set_materialize_grads(False)
+        return theta, diff
+
+    @staticmethod
+    def backward(ctx, g_theta, g_diff):
+        from . import lib as L_
+        (g_all,) = ctx.saved_tensors
+        if g_theta is None and g_diff is None:
+            return None, None
+        c = lambda t: None if t is None else t.contiguous()
+        g_theta, g_diff = c(g_theta), c(g_diff)
+        out = torch.empty_like(g_all)
+        with torch.cuda.device(g_all.device):
+            L_.check(L_.load().i2sdf_eikonal_outputs_backward(L_.ptr(g_all), L_.ptr(g_theta), L_.ptr(g_diff), ctx.B, L_.ptr(out),
+                                                              L_.stream_ptr()), "i2sdf_eikonal_outputs_backward")
+        return out, None
+
+
 class I2SDFNetwork(nn.Module):
     def __init__(self, conf):
         super().__init__()
@@ -381,9 +414,7 @@ class I2SDFNetwork(nn.Module):
 
     @staticmethod
     def _eikonal_outputs(out, g_all, surf, N, n_pc):
-        out["grad_theta"] = g_all[: 2 * N]
-        normals = F.normalize(g_all[N:], dim=1, eps=1e-6)
-        out["diff_norm"] = torch.norm(normals[:N] - normals[N:], dim=1)
+        out["grad_theta"], out["diff_norm"] = _EikonalOutputsFn.apply(g_all, N)
         if n_pc:
             out["surface_sdf"] = surf
 

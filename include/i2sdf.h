@@ -335,6 +335,18 @@ int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_
                                 float* g_normal, float* g_grad_theta, float* g_diff_norm, float* g_surface, float* g_lmask,
                                 void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Eikonal / smoothness outputs -- model/network/__init__.py:188-193.  grad_all (3B,3) = d sdf/dx at the extra points
+ * [B uniform | B near-surface | B neighbours] (the tail of i2sdf_sdf_forward_grad's `grad`):
+ *   forward : grad_theta (2B,3)|NULL = rows [0,2B) (:189);  diff_norm (B) = ||normalize(g[B+i]) - normalize(g[2B+i])||,
+ *             normalize = F.normalize(dim=1, eps=1e-6) (:190-192)
+ *   backward: grad_theta_bar (2B,3)|NULL, diff_norm_bar (B)|NULL -> grad_all_bar (3B,3), every row written
+ *             (torch's conventions: d||x|| = 0 at x = 0, no gradient through a norm below eps).
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_eikonal_outputs_forward(const float* grad_all, int64_t B, float* grad_theta, float* diff_norm, void* stream);
+int i2sdf_eikonal_outputs_backward(const float* grad_all, const float* grad_theta_bar, const float* diff_norm_bar, int64_t B,
+                                   float* grad_all_bar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
