@@ -112,7 +112,7 @@ def dense128():
     for i in range(5):
         l = step(2 + i)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-    print(f"dense-128: {B} rays x {n} samples, sampler bypassed: {dt*1e3:.2f} ms/step, {B*n/dt/1e6:.2f} M ray-samples/s, loss {float(l):.4f}", flush=True)
+    print(f"dense-128: {B} rays x {n} samples, sampler bypassed: {dt*1e3:.2f} ms/step, {B*n/dt/1e6:.2f} M ray-samples/s, loss {float(l.detach()):.4f}", flush=True)
 
 
 def cpu_single_thread():
