@@ -413,11 +413,13 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       i2sdf_launch_sdf_bwd3(a3, g, st);
     };
     if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
+      hipStream_t ts = i2sdf_tail_fork(p, st);       // tail first, on the side stream when the overlap is on (plan.h)
+      launch_lds_bytes(KS_LDS_BYTES, sdf_bwd_split_kernel<256, 256, 6>, (unsigned)((M - bulk + 31) / 32), ts, a, bulk);
       a.M = bulk;
       if (x3) launch3((unsigned)(bulk / PTS_PER_WG));
       else launch_lds(sdf_bwd_kernel<256, 256, 6>, (unsigned)(bulk / PTS_PER_WG), st, a);
       a.M = M;
-      launch_lds_bytes(KS_LDS_BYTES, sdf_bwd_split_kernel<256, 256, 6>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
+      i2sdf_tail_join(p, st, ts);
     } else if (x3) {
       launch3(grid);
     } else {

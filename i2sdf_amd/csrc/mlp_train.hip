@@ -392,15 +392,20 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     const int64_t bulk = split_bulk_points(M);
     if (bulk > 0 && feat != nullptr) {      // full rounds + the partial last round as split-K workgroups (ksplit.h)
       const int64_t M_all = a.M;
-      a.M = bulk;
-      if (x3) LAUNCH3((unsigned)(bulk / PTS_PER_WG));
-      else LAUNCH(256, 256, (unsigned)(bulk / PTS_PER_WG));
-      a.M = M_all;
       const unsigned tg = (unsigned)((M_all - bulk + 31) / 32);
-      a.n_fwd = sdf_fwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip, feat != nullptr);
-      a.n_rev = sdf_rev_stages(256, PE<6>::PEC, d.n_lin, has_skip);
-      if (grad) launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, true>, tg, st, a, bulk);
-      else launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, false>, tg, st, a, bulk);
+      {                                      // tail first, on the side stream when the overlap is on (plan.h)
+        auto t = a;
+        t.n_fwd = sdf_fwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip, feat != nullptr);
+        t.n_rev = sdf_rev_stages(256, PE<6>::PEC, d.n_lin, has_skip);
+        hipStream_t ts = i2sdf_tail_fork(p, st);
+        if (grad) launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, true>, tg, ts, t, bulk);
+        else launch_lds_bytes(KS_LDS_BYTES, sdf_train_fwd_split_kernel<256, 256, 6, false>, tg, ts, t, bulk);
+        a.M = bulk;
+        if (x3) LAUNCH3((unsigned)(bulk / PTS_PER_WG));
+        else LAUNCH(256, 256, (unsigned)(bulk / PTS_PER_WG));
+        a.M = M_all;
+        i2sdf_tail_join(p, st, ts);
+      }
     } else if (x3) {
       LAUNCH3(grid);
     } else {
@@ -443,6 +448,7 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
       RgbFwdArgs b = a;
       b.M = bulk;
       full(b, (unsigned)(bulk / PTS_PER_WG));
+      // (no side stream here: this tail is 32 short workgroups, the fork/join costs more than the overlap gains -- measured)
       launch_lds_bytes(KS_LDS_BYTES, rgb_fwd_split_kernel<256, 256, 4>, (unsigned)((M - bulk + 31) / 32), st, a, bulk);
     } else {
       full(a, grid);

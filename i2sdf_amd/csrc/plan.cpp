@@ -314,7 +314,35 @@ extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
 extern "C" void i2sdf_plan_destroy(i2sdf_plan* p) {
   if (!p) return;
   if (p->d_segs) (void)hipFree(p->d_segs);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+  if (p->side) (void)hipStreamDestroy(p->side);
   delete p;
+}
+
+hipStream_t i2sdf_tail_fork(const i2sdf_plan* p, hipStream_t st) {
+  if (!p->tail_overlap) return st;
+  if (!p->side) {
+    // non-blocking: torch's current stream is normally the NULL stream, and a blocking stream would serialise against it
+    if (hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) != hipSuccess) { p->side = nullptr; (void)hipGetLastError(); return st; }
+    if (hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipStreamDestroy(p->side); p->side = nullptr;
+      return st;
+    }
+  }
+  if (hipEventRecord(p->ev_fork, st) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return st;
+  }
+  return p->side;
+}
+
+void i2sdf_tail_join(const i2sdf_plan* p, hipStream_t st, hipStream_t side) {
+  if (side == st) return;
+  (void)hipEventRecord(p->ev_join, side);
+  (void)hipStreamWaitEvent(st, p->ev_join, 0);
 }
 
 extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t value) {
@@ -341,6 +369,10 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
   }
   if (option == I2SDF_OPT_WGRAD_BF16X3) {
     p->wgrad_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  if (option == I2SDF_OPT_TAIL_OVERLAP) {
+    p->tail_overlap = value ? 1 : 0;
     return I2SDF_OK;
   }
   return I2SDF_EINVAL;

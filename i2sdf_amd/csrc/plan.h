@@ -69,4 +69,14 @@ struct i2sdf_plan {
   int32_t train_fwd_bf16x3 = 0;      // I2SDF_OPT_TRAIN_FWD_BF16X3: SDF forward + d sdf/dx kernel in bf16x3 split arithmetic
   int32_t wgrad_bf16x3 = 0;          // I2SDF_OPT_WGRAD_BF16X3: full 256x256 weight-gradient blocks in bf16x3 split arithmetic
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
+  int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones
+  // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
+  mutable hipStream_t side = nullptr;
+  mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
+
+// Fork: returns the stream the split-K tail of an entry point should be launched on -- the plan's side stream, ordered after
+// everything already enqueued on `st`, or `st` itself when the overlap is off.  Join: `st` waits for the side stream.
+// Launch order at the call sites: fork, tail (few long workgroups), full workgroups on `st`, join.
+hipStream_t i2sdf_tail_fork(const i2sdf_plan* p, hipStream_t st);
+void i2sdf_tail_join(const i2sdf_plan* p, hipStream_t st, hipStream_t side);

@@ -5,6 +5,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib as L
@@ -41,6 +43,9 @@ class RenderEngine:
                 self.set_sdf_backward_bf16x3(True)
             if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
                 self.set_rgb_bf16x3(True)
+        self.tail_overlap = False
+        if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
+            self.set_tail_overlap(True)
         sc = cfg.sampler
         self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
                                   N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
@@ -128,6 +133,11 @@ class RenderEngine:
         """Radiance forward / backward (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_RGB_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.rgb_bf16x3 = bool(on)
+
+    def set_tail_overlap(self, on: bool):
+        """Split-K tail workgroups on the plan's side stream, concurrent with the full workgroups (I2SDF_OPT_TAIL_OVERLAP)."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TAIL_OVERLAP, int(bool(on))), "i2sdf_plan_set_option")
+        self.tail_overlap = bool(on)
 
     def set_wgrad_bf16x3(self, on: bool):
         """Full 256x256 weight-gradient blocks in bf16x3 split arithmetic (I2SDF_OPT_WGRAD_BF16X3)."""

@@ -45,3 +45,37 @@ def test_kernels_are_bitwise_reproducible(bf16x3):
             continue
         for k in cur:
             assert torch.equal(cur[k], ref[k]), f"{k} differs between run 0 and run {rep} ({int((cur[k] != ref[k]).sum())} entries)"
+
+
+@pytest.mark.parametrize("bf16x3", [True, False])
+def test_tail_overlap_changes_nothing(bf16x3):
+    """I2SDF_OPT_TAIL_OVERLAP: the split-K tail workgroups of the SDF training kernels on the plan's side stream, concurrent
+    with the full workgroups (fork/join with events).  Same kernels on the same points, so every output must be bitwise equal
+    to the single-stream run -- a difference would mean a missing dependency between the two streams."""
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=21), 0.05, seed=22)
+    conf = dict(synthetic_conf(False))
+    conf["bf16x3"] = bf16x3
+    eng = make_engine(conf, sd)
+    g = torch.Generator().manual_seed(8)
+    B, n = 420, 97
+    M = B * n + 3 * B                              # 42 000 points: 256 full workgroups + a 9 232-point split-K tail
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.5).cuda()
+    nb, sb = torch.randn(M, 3, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+    fb = torch.randn(B * n, 256, generator=g).cuda()
+
+    def run():
+        fwd = eng.sdf_forward_grad(points=x)
+        bw = eng.sdf_backward(fwd, sbar=sb, fbar=fb, m_fbar=B * n, nbar=nb)
+        # consumers on the caller's stream right behind the entry points: they must see the tail's results
+        return {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "hs": fwd["hs"][:, :M].clone(),
+                "abars": fwd["abars"][:, :M].clone(), "gus": bw["gus"][1:, :M].clone(), "gas": bw["gas"][:, :M].clone()}
+
+    eng.set_tail_overlap(False)
+    ref = run()
+    eng.set_tail_overlap(True)
+    for rep in range(8):
+        cur = run()
+        for k in cur:
+            assert torch.equal(cur[k], ref[k]), f"{k}: overlap run {rep} differs from the single-stream run ({int((cur[k] != ref[k]).sum())} entries)"
