@@ -466,7 +466,10 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
   const float near = sc->near, far = 2.0f * p->desc.scene_bounding_sphere;
   const unsigned grid = (unsigned)((B + 3) / 4);
   sampler_init_kernel<<<grid, 256, 0, st>>>(B, sc->N_samples_eval, t_lin, training ? strat_u : nullptr, near, far, sc->eps, zA, samples, beta, state);
-  for (int it = 0; it < sc->max_total_iters; ++it) {
+  // With a fixed iteration count the host knows where the loop ends; otherwise every iteration is enqueued and the ones after
+  // convergence return immediately (device flag, no host synchronisation).
+  const int n_it = (force_iters > 0 && force_iters < sc->max_total_iters) ? force_iters : sc->max_total_iters;
+  for (int it = 0; it < n_it; ++it) {
     const int n_new = sc->N_samples_eval;
     int rc = i2sdf_sdf_forward_rays_flagged(p, packed, cam, dirs, samples, NNEW, n_new, B, sdf_new, state + ST_DONE, stream);
     if (rc) return rc;
