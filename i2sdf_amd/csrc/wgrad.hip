@@ -594,6 +594,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     return x.j[0].a_w == 256 ? 4 : (x.j[0].a_w <= 32 ? 1 : (x.j[0].b_w <= 32 ? 2 : (x.j[0].b_w <= 64 ? 3 : 0)));
   };
   for (WgTask& x : tl.tasks) x.variant = variant(x);
+  hipStream_t st_main = st;
   auto launch = [&](const std::vector<WgTask>& sel, int var) {
     for (size_t off = 0; off < sel.size(); off += MAX_TASKS) {
       WgLaunch L{};
@@ -612,19 +613,24 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       }
     }
   };
+  hipStream_t side = st;
+  {  // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
+    std::vector<WgTask> sel;
+    for (int var : {3, 1, 2})
+      for (int nj = 2; nj >= 1; --nj)
+        for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel.push_back(x);
+    side = i2sdf_tail_fork(p, st_main);
+    st = side;
+    launch(sel, 1);
+    st = st_main;
+  }
   for (int var : {4, 0}) {
     std::vector<WgTask> sel;
     for (const WgTask& x : tl.tasks) if (x.variant == var) sel.push_back(x);
     std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
     launch(sel, var);
   }
-  {  // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
-    std::vector<WgTask> sel;
-    for (int var : {3, 1, 2})
-      for (int nj = 2; nj >= 1; --nj)
-        for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel.push_back(x);
-    launch(sel, 1);
-  }
+  i2sdf_tail_join(p, st_main, side);
   WnTab tab{};
   int row0 = 0;
   fill_wn(tab, p->sdf, 0, row0);

@@ -92,8 +92,9 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
 /*   I2SDF_OPT_RGB_BF16X3: the full workgroups of i2sdf_rgb_forward / i2sdf_rgb_backward (256-wide nets). */
 #define I2SDF_OPT_RGB_BF16X3 16
 /*   I2SDF_OPT_TAIL_OVERLAP: the split-K tail workgroups of i2sdf_sdf_forward_grad and i2sdf_sdf_backward (the partial last
- *   round of a launch) run on a side stream owned by the plan, concurrently with the full workgroups; the entry
- *   point still returns stream-ordered on the caller's stream (fork/join with events; capturable in a hipGraph). */
+ *   round of a launch) and the narrow blocks of i2sdf_weight_grads run on a side stream owned by the plan,
+ *   concurrently with the full workgroups / the 256x256 blocks; the entry point still returns stream-ordered on the
+ *   caller's stream (fork/join with events; capturable in a hipGraph). */
 #define I2SDF_OPT_TAIL_OVERLAP 32
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
