@@ -41,16 +41,16 @@ def train_case(name, light, B, k):
         l = loss_fn(out, gt, i)["loss"]
         opt.zero_grad(set_to_none=True); l.backward(); opt.step()
         return l
-    for i in range(2):
+    for i in range(5):
         step(i)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 5
+    n = 20
     for i in range(n):
-        l = step(2 + i)
+        l = step(5 + i)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     ns = net._engine_for(dev).n_z - 1
-    print(f"{name}: {B} rays x {ns} samples, k={k}: {dt*1e3:.2f} ms/step, {B*ns/dt/1e6:.2f} M ray-samples/s, loss {float(l):.4f}, "
-          f"peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    print(f"{name}: {B} rays x {ns} samples, k={k}: {dt*1e3:.2f} ms/step, {B*ns/dt/1e6:.2f} M ray-samples/s, sampler iterations {int(net.last_sampler_iters.item())}, "
+          f"loss {float(l.detach()):.4f}, peak mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 
 
 def eval_image():
@@ -139,5 +139,7 @@ if __name__ == "__main__":
     cpu_single_thread()
     train_case("cfg3 light-mask", True, 1024, 2)
     train_case("cfg5 4096 rays/GPU", False, 4096, 2)
+    train_case("cfg2 k=1", False, 1024, 1)
+    train_case("cfg2 k=5", False, 1024, 5)
     train_case("cfg2 natural k", False, 1024, 0)
     eval_image()
