@@ -74,6 +74,7 @@ class RayBatcher:
                 raise ValueError(f"{name} has {t.numel()} elements, expected {self.n_images}x{self.total_pixels}x{tail}")
         self.use_mask, self.use_lightmask = self.mask_images is not None, self.lightmask_images is not None
         self.use_depth, self.use_normal = self.depth_images is not None, self.normal_images is not None
+        self._n_bad = torch.zeros(1, dtype=torch.int32, device=dev)
         self._tables = L_.RayTables(L_.ptr(self.intrinsics_all), L_.ptr(self.pose_all), int(self.pose_is_quat), self.n_images,
                                     self.img_res[0], self.img_res[1], L_.ptr(self.rgb_images), L_.ptr(self.depth_images),
                                     L_.ptr(self.normal_images), L_.ptr(self.mask_images), L_.ptr(self.lightmask_images),
@@ -92,11 +93,21 @@ class RayBatcher:
     def __len__(self) -> int:
         return self.n_images * self.total_pixels
 
+    def bad_indices(self) -> int:
+        """Number of out-of-range pixel indices seen in device-side index tensors so far (one device->host read)."""
+        return int(self._n_bad.item())
+
     def batch(self, tidx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, RaySample, Dict[str, torch.Tensor]]:
         """tidx: global pixel indices (what the DataLoader's sampler yields) -> (tidx, image_idx, sample, ground_truth)."""
-        tidx = torch.as_tensor(tidx).to(self.device, torch.int64).contiguous()
+        tidx = torch.as_tensor(tidx)
         if tidx.dim() != 1:
             raise ValueError("tidx must be 1-D")
+        if not tidx.is_cuda and tidx.numel():
+            # host indices are validated here (free); device indices are clamped by the kernel and counted in `bad_indices`
+            lo, hi = int(tidx.min()), int(tidx.max())
+            if lo < 0 or hi >= len(self):
+                raise IndexError(f"pixel index out of range [0, {len(self)}): min {lo}, max {hi}")
+        tidx = tidx.to(self.device, torch.int64).contiguous()
         B, dev = tidx.shape[0], self.device
         e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
         image_idx, uv = e(B, dt=torch.int64), e(B, 1, 2)
@@ -114,7 +125,7 @@ class RayBatcher:
             gt["normal"], gt["normal_mask"] = e(B, 3), e(B, dt=torch.bool)
         out = L_.RayBatch(L_.ptr(image_idx), L_.ptr(uv), L_.ptr(cam), L_.ptr(dirs), L_.ptr(dnorm), L_.ptr(gt.get("rgb")),
                           L_.ptr(gt.get("depth")), L_.ptr(gt.get("normal")), L_.ptr(gt.get("mask")), L_.ptr(gt.get("light_mask")),
-                          L_.ptr(gt.get("depth_mask")), L_.ptr(gt.get("normal_mask")))
+                          L_.ptr(gt.get("depth_mask")), L_.ptr(gt.get("normal_mask")), L_.ptr(self._n_bad))
         with torch.cuda.device(dev):
             L_.check(self._lib.i2sdf_ray_batch(C.byref(self._tables), L_.ptr(tidx), B, C.byref(out), L_.stream_ptr()), "i2sdf_ray_batch")
         sample = RaySample(self, image_idx, uv=uv, rays={"cam_loc": cam, "dirs": dirs, "dnorm": dnorm})

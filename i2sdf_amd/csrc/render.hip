@@ -82,7 +82,11 @@ __global__ __launch_bounds__(256) void ray_batch_kernel(i2sdf_ray_tables t, cons
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
   const int64_t hw = (int64_t)t.height * t.width;
-  const int64_t g = tidx[i];
+  int64_t g = tidx[i];
+  if (g < 0 || g >= hw * t.n_images) {            // never read outside the tables: clamp, and count (i2sdf_ray_batch_out.n_bad)
+    if (o.n_bad) atomicAdd(o.n_bad, 1);
+    g = g < 0 ? 0 : hw * t.n_images - 1;
+  }
   const int64_t img = g / hw, pix = g - img * hw;
   const float x = (float)(pix % t.width), y = (float)(pix / t.width);     // dataset/train_dataset.py:67-70 (flipped mgrid: uv = (col, row))
   float p[12], d[3], nrm;

@@ -421,6 +421,32 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(int64_t B, const int
   }
 }
 
+// ---- get_error_bound as its own entry (ray_sampler.py:243-251) with the Theorem-1 d* (:99-114): the same device functions
+// the Algorithm-1 kernels above use, on caller-provided rows
+template <int E>
+__global__ __launch_bounds__(256) void error_bound_kernel(int64_t B, int n, const float* __restrict__ z, const float* __restrict__ sdf,
+                                                           const float* __restrict__ beta, int64_t ldbeta, const float* __restrict__ d_star_in,
+                                                           float* __restrict__ d_star_out, float* __restrict__ bound) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= B) return;
+  Row<E> r;
+  load_row<E>(r, z + ray * n, sdf + ray * n, n, lane);
+  row_intervals<E>(r, lane);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = lane * E + e;
+    if (j < n - 1) {
+      if (d_star_in) r.ds[e] = d_star_in[ray * (n - 1) + j];
+      if (d_star_out) d_star_out[ray * (n - 1) + j] = r.ds[e];
+    }
+  }
+  if (bound) {
+    const float eb = row_error_bound<E>(r, beta[ray * ldbeta], lane);
+    if (lane == 0) bound[ray] = eb;
+  }
+}
+
 template <int E>
 void launch_iter(const SamplerArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)((a.B + 3) / 4);
@@ -434,6 +460,29 @@ void launch_iter(const SamplerArgs& a, hipStream_t st) {
 extern "C" int64_t i2sdf_sampler_workspace_floats(int64_t B) {
   // z rows x2, sdf rows x2, idx rows x2 (as ints), samples, sdf_new, beta, state
   return B * (int64_t)(NMAX * 6 + NNEW * 2 + 1) + ST_WORDS + 64;
+}
+
+extern "C" int i2sdf_error_bound(const float* z, const float* sdf, int64_t B, int32_t n, const float* beta, int64_t ldbeta,
+                                 const float* d_star_in, float* d_star_out, float* bound, void* stream) {
+  if (B == 0) return I2SDF_OK;
+  if (!z || !sdf || B < 0 || n < 2 || n > NMAX || (bound && !beta) || (!bound && !d_star_out) || (ldbeta != 0 && ldbeta != 1)) return I2SDF_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned grid = (unsigned)((B + 3) / 4);
+#define I2SDF_EB(E_) error_bound_kernel<E_><<<grid, 256, 0, st>>>(B, n, z, sdf, beta, ldbeta, d_star_in, d_star_out, bound)
+  switch (cdiv(n, 64)) {
+    case 1: I2SDF_EB(1); break;
+    case 2: I2SDF_EB(2); break;
+    case 3: I2SDF_EB(3); break;
+    case 4: I2SDF_EB(4); break;
+    case 5: I2SDF_EB(5); break;
+    case 6: I2SDF_EB(6); break;
+    case 7: I2SDF_EB(7); break;
+    case 8: I2SDF_EB(8); break;
+    case 9: I2SDF_EB(9); break;
+    default: I2SDF_EB(10); break;
+  }
+#undef I2SDF_EB
+  return i2sdf_hip_check(hipGetLastError(), "error_bound launch");
 }
 
 int i2sdf_sdf_forward_rays_flagged(const i2sdf_plan* p, const float* packed, const float* cam, const float* dirs, const float* z, int64_t ldz,

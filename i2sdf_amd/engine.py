@@ -10,7 +10,6 @@ import os
 import torch
 
 from . import lib as L
-from . import lib as L_
 from .config import NetConfig
 from .params import ParamLayout
 
@@ -64,7 +63,6 @@ class RenderEngine:
     # -- live per-kernel timing (bench.py) -------------------------------------------------------------
     def start_timing(self):
         self._timing = []
-        self._orig_check = L_.check
         eng = self
 
         class _Timed:
@@ -80,7 +78,7 @@ class RenderEngine:
                 return rc
 
         self._timed_lib = type("TimedLib", (), {})()
-        for name in L_.SIGNATURES:
+        for name in L.SIGNATURES:
             fn = getattr(self._lib, name)
             if name in ("i2sdf_sdf_forward", "i2sdf_sdf_forward_grad", "i2sdf_rgb_forward", "i2sdf_rgb_backward", "i2sdf_sdf_backward",
                         "i2sdf_weight_grads", "i2sdf_sample_rays", "i2sdf_composite_forward", "i2sdf_composite_backward", "i2sdf_pack_weights",
@@ -164,7 +162,7 @@ class RenderEngine:
         """Point batch = [points generated from rays=(cam (B,3), dirs (B,3), z (B,n)) | explicit points (P,3)]; either may be None.
         Returns dict(sdf, feat, grad, hs, abars, pe, Mp, M, n_ray_pts)."""
         cfgs = self.cfg.sdf
-        H, L = cfgs.hidden, cfgs.n_lin
+        H, NL = cfgs.hidden, cfgs.n_lin
         pts = cam = dirs = z = None
         n_ray, ldz, npr = 0, 0, 1
         if rays is not None:
@@ -180,12 +178,12 @@ class RenderEngine:
         out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z, npr), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
         out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
         out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
-        out["hs"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
-        out["abars"] = torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
+        out["hs"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
+        out["abars"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
         out["pe"] = torch.empty(Mp, 40, dtype=torch.float32, device=dev) if save else None
-        L_.check(self._lib.i2sdf_sdf_forward_grad(self._plan, L_.ptr(self.packed), L_.ptr(pts), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
-                                                  ldz, npr, n_ray, M, Mp, L_.ptr(out["sdf"]), L_.ptr(out["feat"]), L_.ptr(out["grad"]),
-                                                  L_.ptr(out["hs"]), L_.ptr(out["abars"]), L_.ptr(out["pe"]), L_.stream_ptr()),
+        L.check(self._lib.i2sdf_sdf_forward_grad(self._plan, L.ptr(self.packed), L.ptr(pts), L.ptr(cam), L.ptr(dirs), L.ptr(z),
+                                                  ldz, npr, n_ray, M, Mp, L.ptr(out["sdf"]), L.ptr(out["feat"]), L.ptr(out["grad"]),
+                                                  L.ptr(out["hs"]), L.ptr(out["abars"]), L.ptr(out["pe"]), L.stream_ptr()),
                  "i2sdf_sdf_forward_grad")
         return out
 
@@ -195,8 +193,8 @@ class RenderEngine:
         Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
         rs = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=feat.device) if save else None
         pev = torch.empty(Mp, 32, dtype=torch.float32, device=feat.device) if save else None
-        L_.check(self._lib.i2sdf_rgb_forward(self._plan, L_.ptr(self.packed), L_.ptr(dirs.contiguous()), n_per_ray, L_.ptr(feat), M, Mp,
-                                             L_.ptr(rgb), L_.ptr(rs), L_.ptr(pev), L_.stream_ptr()), "i2sdf_rgb_forward")
+        L.check(self._lib.i2sdf_rgb_forward(self._plan, L.ptr(self.packed), L.ptr(dirs.contiguous()), n_per_ray, L.ptr(feat), M, Mp,
+                                             L.ptr(rgb), L.ptr(rs), L.ptr(pev), L.stream_ptr()), "i2sdf_rgb_forward")
         return rgb, rs, pev
 
     def rgb_backward(self, rgb, rgb_bar, rs, M):
@@ -205,30 +203,30 @@ class RenderEngine:
         gar = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=dev)
         ga_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
         fbar = torch.empty(Mp, self.F, dtype=torch.float32, device=dev)
-        L_.check(self._lib.i2sdf_rgb_backward(self._plan, L_.ptr(self.packed), L_.ptr(rgb), L_.ptr(rgb_bar.contiguous()), L_.ptr(rs), M, Mp,
-                                              L_.ptr(gar), L_.ptr(ga_last), L_.ptr(fbar), L_.stream_ptr()), "i2sdf_rgb_backward")
+        L.check(self._lib.i2sdf_rgb_backward(self._plan, L.ptr(self.packed), L.ptr(rgb), L.ptr(rgb_bar.contiguous()), L.ptr(rs), M, Mp,
+                                              L.ptr(gar), L.ptr(ga_last), L.ptr(fbar), L.stream_ptr()), "i2sdf_rgb_backward")
         return gar, ga_last, fbar
 
     def sdf_backward(self, fw, sbar=None, fbar=None, m_fbar=0, nbar=None):
         """fw = dict from sdf_forward_grad(save=True).  Returns the weight-gradient operands."""
         cfgs = self.cfg.sdf
-        H, L = cfgs.hidden, cfgs.n_lin
+        H, NL = cfgs.hidden, cfgs.n_lin
         Mp, M, dev = fw["Mp"], fw["M"], fw["hs"].device
         cam, dirs, z, npr = fw["rays"]
-        o = {"gus": torch.empty(L, Mp, H, dtype=torch.float32, device=dev), "gpbar": torch.empty(Mp, 40, dtype=torch.float32, device=dev),
-             "gas": torch.empty(L - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
+        o = {"gus": torch.empty(NL, Mp, H, dtype=torch.float32, device=dev), "gpbar": torch.empty(Mp, 40, dtype=torch.float32, device=dev),
+             "gas": torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
              "ones4": torch.empty(Mp, 4, dtype=torch.float32, device=dev)}
         c = lambda t: None if t is None else t.contiguous()
-        L_.check(self._lib.i2sdf_sdf_backward(self._plan, L_.ptr(self.packed), L_.ptr(fw["pts"]), L_.ptr(cam), L_.ptr(dirs), L_.ptr(z),
+        L.check(self._lib.i2sdf_sdf_backward(self._plan, L.ptr(self.packed), L.ptr(fw["pts"]), L.ptr(cam), L.ptr(dirs), L.ptr(z),
                                               z.shape[1] if z is not None else 0, npr, fw["n_ray_pts"], M, Mp,
-                                              L_.ptr(fw["hs"]), L_.ptr(fw["abars"]), L_.ptr(c(sbar)), L_.ptr(c(fbar)), m_fbar, L_.ptr(c(nbar)),
-                                              L_.ptr(o["gus"]), L_.ptr(o["gpbar"]), L_.ptr(o["gas"]), L_.ptr(o["ga_last4"]), L_.ptr(o["ones4"]),
-                                              L_.stream_ptr()), "i2sdf_sdf_backward")
+                                              L.ptr(fw["hs"]), L.ptr(fw["abars"]), L.ptr(c(sbar)), L.ptr(c(fbar)), m_fbar, L.ptr(c(nbar)),
+                                              L.ptr(o["gus"]), L.ptr(o["gpbar"]), L.ptr(o["gas"]), L.ptr(o["ga_last4"]), L.ptr(o["ones4"]),
+                                              L.stream_ptr()), "i2sdf_sdf_backward")
         return o
 
     def weight_grads(self, flat_params, grad_flat, fw, bw, M_main=0, fbar=None, rgb_fw=None, rgb_bw=None, light=None):
         """Runs the weight-gradient GEMMs + weight-norm backward; writes into grad_flat (layout of flat_params)."""
-        tb = L_.TrainBuffers()
+        tb = L.TrainBuffers()
         tb.M_sdf, tb.M_main, tb.Mp = fw["M"], M_main, fw["Mp"]
         P = lambda t: None if t is None else t.data_ptr()
         tb.pe, tb.hs, tb.abars = P(fw["pe"]), P(fw["hs"]), P(fw["abars"])
@@ -243,9 +241,8 @@ class RenderEngine:
         ch = int(self._lib.i2sdf_wgrad_chunk_points())
         n_chunks = (fw["M"] + ch - 1) // ch
         partials = torch.empty(n_chunks * self.wgrad_floats, dtype=torch.float32, device=flat_params.device)
-        import ctypes as C_
-        L_.check(self._lib.i2sdf_weight_grads(self._plan, C_.byref(tb), L_.ptr(flat_params), L_.ptr(partials), n_chunks, L_.ptr(grad_flat),
-                                              L_.stream_ptr()), "i2sdf_weight_grads")
+        L.check(self._lib.i2sdf_weight_grads(self._plan, C.byref(tb), L.ptr(flat_params), L.ptr(partials), n_chunks, L.ptr(grad_flat),
+                                              L.stream_ptr()), "i2sdf_weight_grads")
         return partials
 
     # -- per-ray kernels -------------------------------------------------------------------------
@@ -260,8 +257,8 @@ class RenderEngine:
         cam = torch.empty(N, 3, dtype=torch.float32, device=uv.device)
         dirs = torch.empty_like(cam)
         dnorm = torch.empty(N, dtype=torch.float32, device=uv.device)
-        L_.check(self._lib.i2sdf_ray_setup_ex(L_.ptr(uv), L_.ptr(pose), int(quat), L_.ptr(intrinsics), batch, pixels, L_.ptr(cam),
-                                              L_.ptr(dirs), L_.ptr(dnorm), L_.stream_ptr()), "i2sdf_ray_setup_ex")
+        L.check(self._lib.i2sdf_ray_setup_ex(L.ptr(uv), L.ptr(pose), int(quat), L.ptr(intrinsics), batch, pixels, L.ptr(cam),
+                                              L.ptr(dirs), L.ptr(dnorm), L.stream_ptr()), "i2sdf_ray_setup_ex")
         return cam, dirs, dnorm
 
     def sphere_intersections(self, cam_loc, dirs, radius):
@@ -270,8 +267,8 @@ class RenderEngine:
         N = cam_loc.shape[0]
         out = torch.empty(N, 2, dtype=torch.float32, device=cam_loc.device)
         miss = torch.zeros(1, dtype=torch.int32, device=cam_loc.device)
-        L_.check(self._lib.i2sdf_sphere_intersections(L_.ptr(cam_loc), L_.ptr(dirs), N, float(radius), L_.ptr(out), L_.ptr(miss),
-                                                      L_.stream_ptr()), "i2sdf_sphere_intersections")
+        L.check(self._lib.i2sdf_sphere_intersections(L.ptr(cam_loc), L.ptr(dirs), N, float(radius), L.ptr(out), L.ptr(miss),
+                                                      L.stream_ptr()), "i2sdf_sphere_intersections")
         if int(miss.item()) > 0:
             raise ValueError(f"BOUNDING SPHERE PROBLEM: {int(miss.item())} rays do not intersect the sphere of radius {radius}")
         return out
@@ -284,10 +281,10 @@ class RenderEngine:
         o["lmask"] = torch.empty(B, 1, device=dev) if lmask is not None else None
         o["w"] = torch.empty(B, n, device=dev) if save else None
         o["nsum"] = torch.empty(B, 3, device=dev) if (save and want_normal) else None
-        L_.check(self._lib.i2sdf_composite_forward(L_.ptr(beta_param), self.cfg.beta_min, L_.ptr(z_all), z_all.shape[1], L_.ptr(sdf),
-                                                   L_.ptr(rgb), L_.ptr(grad) if want_normal else None, L_.ptr(lmask), L_.ptr(dnorm), B, n,
-                                                   L_.ptr(o["rgb"]), L_.ptr(o["depth"]), L_.ptr(o["wsum"]), L_.ptr(o["normal"]),
-                                                   L_.ptr(o["lmask"]), L_.ptr(o["w"]), L_.ptr(o["nsum"]), L_.stream_ptr()),
+        L.check(self._lib.i2sdf_composite_forward(L.ptr(beta_param), self.cfg.beta_min, L.ptr(z_all), z_all.shape[1], L.ptr(sdf),
+                                                   L.ptr(rgb), L.ptr(grad) if want_normal else None, L.ptr(lmask), L.ptr(dnorm), B, n,
+                                                   L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["wsum"]), L.ptr(o["normal"]),
+                                                   L.ptr(o["lmask"]), L.ptr(o["w"]), L.ptr(o["nsum"]), L.stream_ptr()),
                  "i2sdf_composite_forward")
         return o
 
@@ -301,11 +298,11 @@ class RenderEngine:
         o["lmask_bar"] = torch.empty(M, device=dev) if g_lmask is not None else None
         part = torch.empty(B, device=dev)
         c = lambda t: None if t is None else t.contiguous()
-        L_.check(self._lib.i2sdf_composite_backward(L_.ptr(beta_param), self.cfg.beta_min, L_.ptr(z_all), z_all.shape[1], L_.ptr(sdf),
-                                                    L_.ptr(rgb), L_.ptr(grad), L_.ptr(dnorm), L_.ptr(nsum), B, n, L_.ptr(c(g_rgb)),
-                                                    L_.ptr(c(g_depth)), L_.ptr(c(g_wsum)), L_.ptr(c(g_normal)), L_.ptr(c(g_lmask)),
-                                                    L_.ptr(o["sdf_bar"]), L_.ptr(o["rgb_bar"]), L_.ptr(o["grad_bar"]), L_.ptr(o["lmask_bar"]),
-                                                    L_.ptr(part), L_.ptr(beta_grad_accum), L_.stream_ptr()), "i2sdf_composite_backward")
+        L.check(self._lib.i2sdf_composite_backward(L.ptr(beta_param), self.cfg.beta_min, L.ptr(z_all), z_all.shape[1], L.ptr(sdf),
+                                                    L.ptr(rgb), L.ptr(grad), L.ptr(dnorm), L.ptr(nsum), B, n, L.ptr(c(g_rgb)),
+                                                    L.ptr(c(g_depth)), L.ptr(c(g_wsum)), L.ptr(c(g_normal)), L.ptr(c(g_lmask)),
+                                                    L.ptr(o["sdf_bar"]), L.ptr(o["rgb_bar"]), L.ptr(o["grad_bar"]), L.ptr(o["lmask_bar"]),
+                                                    L.ptr(part), L.ptr(beta_grad_accum), L.stream_ptr()), "i2sdf_composite_backward")
         o["beta_partial"] = part
         return o
 
@@ -324,13 +321,28 @@ class RenderEngine:
             u_final, ldu = self.u_final, 0
         ex, ek = i32(extra_idx), i32(eik_idx)
         su = None if strat_u is None else strat_u.contiguous()
-        L_.check(self._lib.i2sdf_sample_rays(self._plan, L_.ptr(self.packed), L_.ptr(flat_params), C.byref(self._scfg), L_.ptr(cam.contiguous()),
-                                             L_.ptr(dirs.contiguous()), B, 1 if training else 0, L_.ptr(self.t_lin), L_.ptr(self.u_more),
-                                             L_.ptr(u_final), ldu, L_.ptr(self.extra_tab), L_.ptr(su), L_.ptr(ex), L_.ptr(ek), force_iters,
-                                             L_.ptr(ws), L_.ptr(z_out), self.n_z, L_.ptr(z_eik), L_.ptr(iters), L_.stream_ptr()),
+        L.check(self._lib.i2sdf_sample_rays(self._plan, L.ptr(self.packed), L.ptr(flat_params), C.byref(self._scfg), L.ptr(cam.contiguous()),
+                                             L.ptr(dirs.contiguous()), B, 1 if training else 0, L.ptr(self.t_lin), L.ptr(self.u_more),
+                                             L.ptr(u_final), ldu, L.ptr(self.extra_tab), L.ptr(su), L.ptr(ex), L.ptr(ek), force_iters,
+                                             L.ptr(ws), L.ptr(z_out), self.n_z, L.ptr(z_eik), L.ptr(iters), L.stream_ptr()),
                  "i2sdf_sample_rays")
         self._last_sampler_ws = ws
         return z_out, z_eik, iters
+
+    def error_bound(self, z, sdf, beta, d_star=None, want_d_star=False):
+        """ErrorBoundSampler.get_error_bound (ray_sampler.py:243-251) on rows z, sdf (B,n); beta scalar tensor or (B,) / (B,1).
+        d_star=None computes the Theorem-1 bound (:99-114).  Returns bound (B,) [, d_star (B,n-1)]."""
+        z, sdf = z.detach().float().contiguous(), sdf.detach().float().reshape(z.shape).contiguous()
+        B, n = z.shape
+        beta = beta.detach().float().reshape(-1).contiguous().to(z.device)
+        if beta.numel() not in (1, B):
+            raise ValueError("beta must be a scalar or one value per ray")
+        bound = torch.empty(B, dtype=torch.float32, device=z.device)
+        ds_out = torch.empty(B, n - 1, dtype=torch.float32, device=z.device) if want_d_star else None
+        ds_in = None if d_star is None else d_star.detach().float().contiguous()
+        L.check(self._lib.i2sdf_error_bound(L.ptr(z), L.ptr(sdf), B, n, L.ptr(beta), 0 if beta.numel() == 1 else 1, L.ptr(ds_in),
+                                            L.ptr(ds_out), L.ptr(bound), L.stream_ptr()), "i2sdf_error_bound")
+        return (bound, ds_out) if want_d_star else bound
 
     # -- light-mask head ---------------------------------------------------------------------------
     def light_forward(self, feat, M, save=True):
@@ -338,7 +350,7 @@ class RenderEngine:
         HL = self.cfg.light.hidden
         lm = torch.empty(M, dtype=torch.float32, device=dev)
         hl = torch.empty(Mp, HL, dtype=torch.float32, device=dev) if save else None
-        L_.check(self._lib.i2sdf_light_forward(self._plan, L_.ptr(self.packed), L_.ptr(feat), M, Mp, L_.ptr(lm), L_.ptr(hl), L_.stream_ptr()),
+        L.check(self._lib.i2sdf_light_forward(self._plan, L.ptr(self.packed), L.ptr(feat), M, Mp, L.ptr(lm), L.ptr(hl), L.stream_ptr()),
                  "i2sdf_light_forward")
         return lm, hl
 
@@ -346,6 +358,6 @@ class RenderEngine:
         Mp, dev = hl.shape[0], hl.device
         gal0 = torch.empty(Mp, hl.shape[1], dtype=torch.float32, device=dev)
         gal_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
-        L_.check(self._lib.i2sdf_light_backward(self._plan, L_.ptr(self.packed), L_.ptr(lm), L_.ptr(lm_bar.contiguous()), L_.ptr(hl), M, Mp,
-                                                L_.ptr(gal0), L_.ptr(gal_last), L_.stream_ptr()), "i2sdf_light_backward")
+        L.check(self._lib.i2sdf_light_backward(self._plan, L.ptr(self.packed), L.ptr(lm), L.ptr(lm_bar.contiguous()), L.ptr(hl), M, Mp,
+                                                L.ptr(gal0), L.ptr(gal_last), L.stream_ptr()), "i2sdf_light_backward")
         return gal0, gal_last

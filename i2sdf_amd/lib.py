@@ -46,7 +46,7 @@ class RayTables(C.Structure):
 
 class RayBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("image_idx", "uv", "cam_loc", "dirs", "dnorm", "rgb", "depth", "normal", "mask", "light_mask",
-                                          "depth_mask", "normal_mask")]
+                                          "depth_mask", "normal_mask", "n_bad")]
 
 
 OPT_SDF_FWD_BF16X3 = 1
@@ -87,6 +87,7 @@ SIGNATURES = {
     "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
     "i2sdf_wgrad_chunk_points": (_I64, []),
     "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
+    "i2sdf_error_bound": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
     "i2sdf_sampler_workspace_floats": (_I64, [_I64]),
     # plan, packed, params, cfg, cam, dirs, B, training, t_lin, u_more, u_final, ldu_final, extra_tab, strat_u, extra_idx, eik_idx,
     # force_iters, workspace, z_out, ldz, z_eik, iters_out, stream

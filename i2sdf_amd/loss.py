@@ -1,11 +1,12 @@
 """I2SDFLoss with the reference's semantics (model/network/__init__.py:289-406), including its quirks:
 `angular_loss` is the same L1 form as `normal_loss` (:368-369) and `angular_weight` defaults to 0.05 although the
-shipped configs omit it (:290).  Plain torch ops on tiny per-ray tensors (outside the kernel path)."""
+shipped configs omit it (:290).  Value and gradients come from ONE fused HIP entry point (i2sdf_loss_forward_backward,
+SURVEY row N1); the masked means are sums over selected rows / number of selected rows, i.e. what the reference's boolean
+indexing (`depth[depth_mask]`, :320-329) computes, without its device->host synchronisation."""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 
 class _FusedLossFn(torch.autograd.Function):
@@ -63,19 +64,6 @@ class I2SDFLoss(nn.Module):
         if self.bubble_weight > 0 and self.max_bubble_iter is not None and self.smooth_iter < self.max_bubble_iter:
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
-        self.fused = True          # CUDA inputs: one fused HIP forward+gradient call instead of ~100 element-wise torch kernels
-
-    # The reference indexes with boolean masks (`depth[depth_mask]`, `normal[normal_mask]`, :320-329), which costs a
-    # device->host synchronisation per call (the result size is data dependent).  The masked means below are the same
-    # numbers -- sum over selected rows / number of selected rows -- without the sync, and capturable in a hipGraph.
-    @staticmethod
-    def _masked_mean(values, mask):
-        m = mask.flatten().to(values.dtype)
-        return (values * m).sum() / m.sum()
-
-    @classmethod
-    def _normal_l1(cls, normal, normal_gt, mask):
-        return cls._masked_mean(torch.abs(1 - torch.sum(normal * normal_gt.reshape(-1, 3), dim=-1)), mask)
 
     def _forward_fused(self, out, gt, current_step):
         from . import lib as L
@@ -105,30 +93,7 @@ class I2SDFLoss(nn.Module):
         return res
 
     def forward(self, out, gt, current_step):
-        if self.fused and out["rgb_values"].is_cuda and out["rgb_values"].dtype == torch.float32:
-            return self._forward_fused(out, gt, current_step)
-        dev = out["rgb_values"].device
-        zero = lambda: torch.zeros((), device=dev, dtype=torch.float32)       # no host->device copy (graph-capturable)
-        rgb_loss = F.l1_loss(out["rgb_values"], gt["rgb"].reshape(-1, 3))
-        eik = ((out["grad_theta"].norm(2, dim=1) - 1) ** 2).mean() if "grad_theta" in out else zero()
-        smooth_on = self.smooth_iter is None or current_step > self.smooth_iter
-        smooth = out["diff_norm"].mean() if (smooth_on and self.smooth_weight > 0 and "diff_norm" in out) else zero()
-        if "mask" in gt and self.mask_weight > 0:
-            mask = F.binary_cross_entropy(out["weight_sum"].clip(1e-3, 1.0 - 1e-3), gt["mask"])
-        else:
-            mask = zero()
-        if "depth" in gt and self.depth_weight > 0:
-            depth = self._masked_mean((out["depth_values"] - gt["depth"].flatten()) ** 2, gt["depth_mask"])
-        else:
-            depth = zero()
-        normal = self._normal_l1(out["normal_values"], gt["normal"], gt["normal_mask"]) if ("normal" in gt and self.normal_weight > 0) else zero()
-        angular = self._normal_l1(out["normal_values"], gt["normal"], gt["normal_mask"]) if ("normal" in gt and self.angular_weight > 0) else zero()
-        bubble = out["surface_sdf"].abs().mean() if ("surface_sdf" in out and self.bubble_weight > 0) else zero()
-        if "light_mask" in out and self.light_mask_weight > 0:
-            lm = F.binary_cross_entropy(out["light_mask"].reshape(-1, 1).clip(1e-3, 1.0 - 1e-3), gt["light_mask"].reshape(-1, 1))
-        else:
-            lm = zero()
-        loss = (rgb_loss + self.eikonal_weight * eik + self.smooth_weight * smooth + self.mask_weight * mask + self.depth_weight * depth
-                + self.normal_weight * normal + self.angular_weight * angular + self.bubble_weight * bubble + self.light_mask_weight * lm)
-        return {"loss": loss, "rgb_loss": rgb_loss, "eikonal_loss": eik, "smooth_loss": smooth, "mask_loss": mask, "depth_loss": depth,
-                "normal_loss": normal, "angular_loss": angular, "bubble_loss": bubble, "light_mask_loss": lm}
+        if not (out["rgb_values"].is_cuda and out["rgb_values"].dtype == torch.float32):
+            raise RuntimeError("i2sdf_amd.I2SDFLoss runs on MI355X only (fp32 tensors on a cuda/HIP device); there is no "
+                               "eager-torch or CPU fallback -- oracle/i2sdf_oracle.py:i2sdf_loss is the CPU restatement")
+        return self._forward_fused(out, gt, current_step)

@@ -216,7 +216,7 @@ class I2SDFNetwork(nn.Module):
         self.last_sampler_iters = None  # device int32 tensor of the last forward
         object.__setattr__(self, "_engines", {})
         object.__setattr__(self, "_flat", None)
-        object.__setattr__(self, "_packed_version", {})
+        object.__setattr__(self, "_packed", set())
         self._init_parameters()
 
     # ------------------------------------------------------------------------------------------
@@ -246,13 +246,15 @@ class I2SDFNetwork(nn.Module):
                     ok = False
                     break
         if not ok:
-            flat = torch.empty(self.layout.n_params, dtype=torch.float32, device=dev)
-            with torch.no_grad():
+            # Lightning's validate/test loops run under torch.inference_mode(): a buffer created there would be an inference
+            # tensor (no version counter, not usable by autograd afterwards).  The flat buffer must be an ordinary tensor.
+            with torch.inference_mode(False), torch.no_grad():
+                flat = torch.empty(self.layout.n_params, dtype=torch.float32, device=dev)
                 for (name, off, shape), p in zip(self.layout.entries, params):
                     flat[off:off + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
                     p.data = flat[off:off + p.numel()].view(shape)
             object.__setattr__(self, "_flat", flat)
-            self._packed_version.clear()
+            self._packed.clear()
         return self._flat
 
     def _engine_for(self, device, fresh: bool = True) -> RenderEngine:
@@ -266,18 +268,17 @@ class I2SDFNetwork(nn.Module):
         key = str(device)
         eng = self._engines.get(key)
         if eng is None:
-            with torch.cuda.device(device):
+            with torch.inference_mode(False), torch.cuda.device(device):
                 eng = RenderEngine(self.cfg, device)
             self._engines[key] = eng
-        # The parameters are views of `flat` made through `.data`, so they keep their OWN version counters: an optimizer
-        # step bumps p._version, never flat._version -- and fused / foreach optimizers or raw-pointer writers need not
-        # bump anything.  Packing costs ~17 us, so every public entry point (fresh=True) simply repacks; only the
-        # internal second look-up of the same call (render() after forward()) reuses it.
-        ver = (flat.data_ptr(), flat._version, sum(p._version for p in self._param_list()))
-        if fresh or self._packed_version.get(key) != ver:
+        # The parameters are views of `flat` made through `.data`, so they keep their OWN version counters, and fused /
+        # foreach optimizers or raw-pointer writers need not bump any of them: no version key can tell whether the packed
+        # weight streams are stale.  Packing costs ~17 us, so every public entry point (fresh=True) simply repacks; only
+        # the internal second look-up of the same call (render() after forward()) reuses the streams.
+        if fresh or key not in self._packed:
             with torch.cuda.device(device):
                 eng.pack(flat)
-            self._packed_version[key] = ver
+            self._packed.add(key)
         return eng
 
     # ------------------------------------------------------------------------------------------

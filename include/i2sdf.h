@@ -219,6 +219,8 @@ typedef struct i2sdf_ray_batch_out {
   float* light_mask;               /* (n_rays,1) */
   uint8_t* depth_mask;             /* (n_rays)   */
   uint8_t* normal_mask;            /* (n_rays)   */
+  int32_t* n_bad;                  /* NULL or device counter (caller-zeroed): += number of tidx outside [0, n_images*H*W); such rays
+                                      are produced from the clamped index, nothing is read out of bounds */
 } i2sdf_ray_batch_out;
 
 int i2sdf_ray_batch(const i2sdf_ray_tables* tables, const int64_t* tidx, int64_t n_rays, const i2sdf_ray_batch_out* out, void* stream);
@@ -295,6 +297,14 @@ typedef struct i2sdf_sampler_cfg {
   float near, eps, add_tiny;
   int32_t N_samples, N_samples_eval, N_samples_extra, beta_iters, max_total_iters;
 } i2sdf_sampler_cfg;
+
+/* ErrorBoundSampler.get_error_bound (model/network/ray_sampler.py:243-251) and the Theorem-1 distance bound d* of
+ * get_z_vals (:99-114) on caller-provided rows -- the device functions the Algorithm-1 loop uses, as their own entry point.
+ *   z, sdf (B,n) sorted depths / sdf values, 2 <= n <= 640 ; beta: one value (ldbeta = 0) or one per ray (ldbeta = 1)
+ *   d_star_in (B,n-1)|NULL: use these bounds instead of computing them ; d_star_out (B,n-1)|NULL ; bound (B)|NULL
+ *   -> bound[r] = max_i (min(exp(cumsum err)_i, 1e6) - 1) * exp(-integral_i)                                       */
+int i2sdf_error_bound(const float* z, const float* sdf, int64_t B, int32_t n, const float* beta, int64_t ldbeta,
+                      const float* d_star_in, float* d_star_out, float* bound, void* stream);
 
 int64_t i2sdf_sampler_workspace_floats(int64_t B);
 int i2sdf_sample_rays(const i2sdf_plan* plan, const float* packed, const float* params, const i2sdf_sampler_cfg* cfg,

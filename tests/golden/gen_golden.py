@@ -110,6 +110,107 @@ class DrawRecorder:
         np.random.randint = self._nprandint
 
 
+def record_z(full):
+    """Wrap the model's sampler so that the (z_vals, z_samples_eik) it returns are recorded (model/network/__init__.py:95)."""
+    rec = []
+    orig = full.ray_sampler.get_z_vals
+
+    def wrapped(*a, **k):
+        zv, ze = orig(*a, **k)
+        rec.append((zv.detach().clone(), ze.detach().clone()))
+        return zv, ze
+
+    full.ray_sampler.get_z_vals = wrapped
+    return rec
+
+
+def grad_digest(named_grads, stride=61):
+    """Full-width gradients are 3.2 MB: keep every tensor of <= 1024 elements whole and a strided sample of the larger ones,
+    plus each tensor's max |g| (the denominator of the max-norm relative error) and its sum."""
+    out = {}
+    for n, g_ in named_grads:
+        f = g_.detach().reshape(-1)
+        out["gsample." + n] = f if f.numel() <= 1024 else f[::stride]
+        out["gmax." + n] = f.abs().max()
+        out["gsum." + n] = f.double().sum()
+    return out
+
+
+def full_width(ref_model, I2SDFLoss):
+    """G14/G15: the shipped synthetic.yml / synthetic_light_mask.yml networks end to end.  The 800 955 weights are not stored:
+    both sides build them with oracle.init_params(seed) + perturb_params (deterministic CPU torch generator) and the reference
+    model loads that state_dict, so the fixture holds inputs, the reference's own depths/draws, outputs, loss and a gradient digest."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import i2sdf_oracle as orc
+    gg = torch.Generator().manual_seed(1414)
+    for name, light, yml in (("g14_train_full", False, "synthetic.yml"), ("g14_train_full_light", True, "synthetic_light_mask.yml")):
+        ocfg = orc.synthetic_cfg(light)
+        sd = orc.perturb_params(orc.init_params(ocfg, seed=141), 0.03, seed=142)
+        sd["density.beta"] = torch.tensor(0.05)
+        cfg = ref_import.load_cfg(yml).model
+        cfg.use_normal = True
+        full = ref_model.I2SDFNetwork(cfg)
+        full.load_state_dict(sd)
+        full.train()
+        B = 32
+        inp = camera_batch(B, (0.0, 0.0, -2.0), W=640, H=480, f=600.0, seed=14)
+        gt = {"rgb": torch.rand(B, 3, generator=gg), "depth": torch.rand(B, generator=gg) * 3, "depth_mask": torch.rand(B, generator=gg) > 0.2,
+              "normal": torch.nn.functional.normalize(torch.randn(B, 3, generator=gg), dim=1), "normal_mask": torch.rand(B, generator=gg) > 0.1}
+        lkw = dict(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
+        if light:
+            gt["light_mask"] = (torch.rand(B, 1, generator=gg) > 0.5).float()
+            lkw["light_mask_weight"] = 0.5
+        inp["pointcloud"] = torch.rand(24, 3, generator=gg) * 2 - 1
+        lkw["bubble_weight"] = 0.5
+        torch.manual_seed(1)
+        np.random.seed(0)
+        zrec = record_z(full)
+        with DrawRecorder() as rec:
+            out = full(inp)
+        losses = I2SDFLoss(**lkw)(out, gt, 10)
+        full.zero_grad()
+        losses["loss"].backward()
+        kinds = [k for k, _ in rec.log]
+        assert kinds == ["rand", "rand", "randperm", "randint", "uniform", "uniform", "np.randint"], kinds
+        arrs = {"in." + k: v for k, v in inp.items()}
+        arrs.update({"gt." + k: v for k, v in gt.items()})
+        arrs.update({"out." + k: v for k, v in out.items()})
+        arrs.update({"loss." + k: v for k, v in losses.items()})
+        arrs.update(grad_digest([(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in full.named_parameters()]))
+        arrs.update({"draw.eik_pts": rec.log[4][1], "draw.nbr_off": rec.log[5][1]})
+        arrs["ref.z_vals"], arrs["ref.z_eik"] = zrec[0]
+        arrs["loss_kwargs"] = np.array(sorted(lkw.items(), key=lambda kv: kv[0]), dtype=object).astype(str)
+        arrs["init_seed"], arrs["perturb_seed"], arrs["perturb_scale"], arrs["grad_stride"] = np.int64(141), np.int64(142), np.float32(0.03), np.int64(61)
+        arrs["sd_checksum"] = torch.stack([v.double().sum() for v in sd.values()])      # guards the "same weights on both sides" premise
+        save(name, **arrs)
+    # G15: eval render (k data dependent), full width, with the reference's depths
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=151), 0.03, seed=152)
+    sd["density.beta"] = torch.tensor(0.02)
+    cfg = ref_import.load_cfg("synthetic.yml").model
+    cfg.use_normal = True
+    full = ref_model.I2SDFNetwork(cfg)
+    full.load_state_dict(sd)
+    full.eval()
+    P = 64
+    idx = torch.randperm(640 * 480, generator=gg)[:P]
+    K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2], K[1, 2] = 320.0, 240.0
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
+    inp = {"uv": torch.stack([idx % 640, idx // 640], -1).float().reshape(1, P, 2), "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0)}
+    zrec = record_z(full)
+    calls = []
+    orig = full.implicit_network.get_sdf_vals
+    full.implicit_network.get_sdf_vals = lambda pts, _o=orig: (calls.append(pts.shape[0]), _o(pts))[1]
+    out = full(inp)
+    arrs = {"in." + k: v for k, v in inp.items()}
+    arrs.update({"out." + k: v for k, v in out.items()})
+    arrs["ref.z_vals"], arrs["ref.z_eik"] = zrec[0]
+    arrs["iters"] = np.int64(len(calls))
+    arrs["init_seed"], arrs["perturb_seed"], arrs["perturb_scale"] = np.int64(151), np.int64(152), np.float32(0.03)
+    arrs["sd_checksum"] = torch.stack([v.double().sum() for v in sd.values()])
+    save("g15_eval_full", **arrs)
+
+
 def main():
     ref_model, ref_utils = ref_import.import_reference()
     from model.network.embedder import get_embedder
@@ -246,6 +347,7 @@ def main():
         lkw["bubble_weight"] = 0.5
         loss_fn = I2SDFLoss(**lkw)
         np.random.seed(0)
+        zrec = record_z(full)
         with DrawRecorder() as rec:
             out = full(inp)
         losses = loss_fn(out, gt, 10)
@@ -262,6 +364,7 @@ def main():
         arrs.update({"draw.strat_u": rec.log[0][1], "draw.cdf_u": rec.log[1][1], "draw.extra_idx": rec.log[2][1][:8],
                      "draw.eik_idx": rec.log[3][1], "draw.eik_pts": rec.log[4][1], "draw.nbr_off": rec.log[5][1]})
         arrs["loss_kwargs"] = np.array(sorted(lkw.items(), key=lambda kv: kv[0]), dtype=object).astype(str)
+        arrs["ref.z_vals"], arrs["ref.z_eik"] = zrec[0]          # the reference's own depths: feeds the 1e-4 end-to-end test
         save(name, **arrs)
 
     # ---- G10 get_camera_params with skew ---------------------------------------------------
@@ -332,6 +435,9 @@ def main():
     arrs.update({"sample." + k: v for k, v in sample.items()})
     arrs.update({"gt." + k: v for k, v in gtb.items()})
     save("g13_batcher", img_res=np.array([H, W]), tidx=t_out, image_idx=i_out, ray_dirs=dirs_b, cam_loc=cam_b, **arrs)
+
+    # ---- G14 / G15 full-width (synthetic.yml shapes) end-to-end fixtures ---------------------------
+    full_width(ref_model, I2SDFLoss)
 
 
 if __name__ == "__main__":

@@ -76,3 +76,38 @@ def make_gt(B, seed=0, dtype=torch.float32, light=False):
     if light:
         gt["light_mask"] = (torch.rand(B, 1, generator=g) > 0.5).to(dtype)
     return gt
+
+
+def full_width_state_dict(z, light=False):
+    """The weights of the full-width fixtures (G14/G15) are not stored: rebuild them exactly as gen_golden.py did
+    (oracle.init_params + perturb_params, deterministic CPU generator) and check the stored per-tensor checksums."""
+    cfg = orc.synthetic_cfg(light)
+    sd = orc.perturb_params(orc.init_params(cfg, seed=int(z["init_seed"])), float(z["perturb_scale"]), seed=int(z["perturb_seed"]))
+    chk = torch.stack([v.double().sum() for v in sd.values()])
+    assert torch.allclose(chk[:-1], t(z["sd_checksum"])[:-1], rtol=0, atol=1e-9), "rebuilt weights differ from the fixture's"
+    return cfg, sd
+
+
+def assert_grad_digest(z, grads, tol, stride_key="grad_stride"):
+    """grads: {name: tensor}.  Compares the fixture's gradient digest (whole small tensors, strided sample of large ones) with
+    the max-norm relative criterion, the denominator being the FULL reference tensor's max |g| (stored)."""
+    stride = int(z[stride_key])
+    worst = 0.0
+    for k in z.files:
+        if not k.startswith("gsample."):
+            continue
+        n = k[len("gsample."):]
+        g = torch.as_tensor(grads[n]).detach().cpu().double().reshape(-1)
+        ref = t(z[k]).double().reshape(-1)
+        mine = g if g.numel() <= 1024 else g[::stride]
+        assert mine.shape == ref.shape, n
+        gmax = float(z["gmax." + n])
+        if gmax == 0.0:
+            assert float(g.abs().max()) == 0.0, f"grad {n}: reference is exactly zero"
+            continue
+        err = float((mine - ref).abs().max()) / gmax
+        assert err <= tol, f"grad {n}: max-norm relative error {err:.3e} > {tol:.1e}"
+        worst = max(worst, err)
+        # the sum over the whole tensor guards the elements the sample skips (loose: cancellation)
+        assert abs(float(g.sum()) - float(z["gsum." + n])) <= 50 * tol * gmax * max(1.0, g.numel() ** 0.5), f"grad {n}: sum"
+    return worst

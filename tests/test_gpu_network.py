@@ -48,23 +48,65 @@ def test_state_dict_keys_and_order_match_reference(golden):
         assert tuple(v.shape) == tuple(z["sd." + k].shape), k
 
 
+def _spread(a, b, keys, hit=None):
+    """max-norm relative difference of two oracle runs (fp32 vs fp64): the conditioning of the quantity itself."""
+    out = {}
+    for k in keys:
+        x, y = a[k].detach().double(), b[k].detach().double()
+        if hit is not None and k.startswith("normal"):
+            x, y = x[hit], y[hit]
+        out[k] = rel_max(x, y)
+    return out
+
+
 @pytest.mark.parametrize("tag", ["in", "out"])
 def test_eval_forward_vs_reference_golden(golden, tag):
+    """Sampler in the loop.  Individual depths are ill-conditioned where the inverse CDF is flat, so the bound used per output
+    is MEASURED here: the oracle's own fp32-vs-fp64 spread on these rays (x3 margin), never below the 1e-4 parity bar."""
     from i2sdf_amd import plumbing_conf
     z = golden("g7_g8_eval")
     sd = sd_from_npz(z, "sd.")
     sd["density.beta"] = torch.tensor(float(z[f"{tag}.beta_param"]))
     net = build(plumbing_conf(), sd)
+    inp = _eval_rays(z[f"{tag}.t"])
     with torch.no_grad():
-        out = net(cuda(_eval_rays(z[f"{tag}.t"])))
+        out = net(cuda(inp))
     assert int(net.last_sampler_iters.item()) == int(z[f"{tag}.iters"])
-    for k, tol in (("rgb_values", 5e-4), ("depth_values", 1e-3), ("weight_sum", 5e-4)):
-        assert out[k].shape == tuple(z[f"{tag}.out.{k}"].shape)
-        assert_close(out[k].cpu(), z[f"{tag}.out.{k}"], tol, k)
-    # the normal of a ray that hits nothing (weight_sum ~ 0) is the direction of a vanishing sum: compare where it is defined
+    ocfg = orc.plumbing_cfg()
+    o32 = orc.network_forward(sd, ocfg, inp, training=False)
+    o64 = orc.network_forward({k: v.double() for k, v in sd.items()}, ocfg, {k: v.double() for k, v in inp.items()}, training=False)
     hit = t(z[f"{tag}.out.weight_sum"]).reshape(-1) > 1e-2
-    assert out["normal_map"].shape == tuple(z[f"{tag}.out.normal_map"].shape)
-    assert_close(out["normal_map"].cpu()[hit], t(z[f"{tag}.out.normal_map"])[hit], 5e-3, "normal_map (rays with weight_sum > 0.01)")
+    keys = ("rgb_values", "depth_values", "weight_sum", "normal_map")
+    spread = _spread(o32, o64, keys, hit)
+    print("fp32-vs-fp64 spread of the oracle with its own sampler:", spread)
+    for k in keys:
+        tol = max(1e-4, 3.0 * spread[k])
+        assert out[k].shape == tuple(z[f"{tag}.out.{k}"].shape)
+        if k == "normal_map":
+            # the normal of a ray that hits nothing (weight_sum ~ 0) is the direction of a vanishing sum: compare where it is defined
+            assert_close(out[k].cpu()[hit], t(z[f"{tag}.out.{k}"])[hit], tol, "normal_map (rays with weight_sum > 0.01)")
+        else:
+            assert_close(out[k].cpu(), z[f"{tag}.out.{k}"], tol, k)
+
+
+@pytest.mark.parametrize("tag", ["in", "out"])
+def test_eval_render_given_reference_depths_golden(golden, tag):
+    """The reference's OWN eval depths (G7 z_vals) through render(): every output of the reference's recorded render (G8) at 1e-4."""
+    from i2sdf_amd import plumbing_conf
+    z = golden("g7_g8_eval")
+    sd = sd_from_npz(z, "sd.")
+    sd["density.beta"] = torch.tensor(float(z[f"{tag}.beta_param"]))
+    net = build(plumbing_conf(), sd)
+    inp = _eval_rays(z[f"{tag}.t"])
+    eng = net._engine_for("cuda:0")
+    c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    zv = t(z[f"{tag}.z_vals"]).cuda()
+    with torch.no_grad():
+        out = net.render(cuda(inp), c, d, n, zv, zv[:, :1].contiguous())
+    for k in ("rgb_values", "depth_values", "weight_sum"):
+        assert_close(out[k].cpu(), z[f"{tag}.out.{k}"], 1e-4, k)
+    hit = t(z[f"{tag}.out.weight_sum"]).reshape(-1) > 1e-2
+    assert_close(out["normal_map"].cpu()[hit], t(z[f"{tag}.out.normal_map"])[hit], 1e-4, "normal_map (rays with weight_sum > 0.01)")
 
 
 @pytest.mark.parametrize("light", [False, True])
@@ -92,38 +134,160 @@ def test_eval_render_given_depths_full_size(light):
     assert_close(out["normal_map"].cpu()[hit], ref["normal_map"][hit], 1e-3, "normal_map (rays with weight_sum > 0.01)")
 
 
-@pytest.mark.parametrize("name,light", [("g9_train", False), ("g9_train_light", True)])
-def test_train_step_vs_reference_golden(golden, name, light):
-    """Forward + I2SDFLoss + backward with the reference's own recorded random draws; compares every output, the loss
-    and every parameter gradient with the reference's (fixture G9)."""
+def _g9_setup(z, light):
     from i2sdf_amd import plumbing_conf, I2SDFLoss
-    z = golden(name)
     sd = sd_from_npz(z, "sd.")
     net = build(plumbing_conf(skip=True, light=light), sd, train=True)
     inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
     gt = {k[3:]: t(z[k]) for k in z.files if k.startswith("gt.")}
-    draws = {k[5:]: t(z[k]).cuda() for k in z.files if k.startswith("draw.")}
     lk = {k: v for k, v in z["loss_kwargs"]}
     loss_fn = I2SDFLoss(**{k: (None if v == "None" else float(v)) for k, v in lk.items()})
+    return sd, net, inp, gt, lk, loss_fn
+
+
+def _oracle_lc(lk):
+    return orc.LossCfg(eikonal_weight=float(lk["eikonal_weight"]), smooth_weight=float(lk["smooth_weight"]), smooth_iter=None,
+                       depth_weight=float(lk["depth_weight"]), normal_weight=float(lk["normal_weight"]),
+                       bubble_weight=float(lk["bubble_weight"]), light_mask_weight=float(lk.get("light_mask_weight", 0.0)))
+
+
+@pytest.mark.parametrize("name,light", [("g9_train", False), ("g9_train_light", True)])
+def test_train_step_vs_reference_golden(golden, name, light):
+    """Sampler in the loop: forward + I2SDFLoss + backward with the reference's own recorded random draws; every output, the
+    loss and every parameter gradient vs the reference's (fixture G9).  The tolerance per quantity is measured in the test as
+    the oracle's fp32-vs-fp64 spread with ITS sampler in the loop (x3), floor 1e-4: what the ill-conditioned depths cost the
+    reference itself.  The tight check with identical depths is test_train_step_given_reference_depths_golden."""
+    z = golden(name)
+    sd, net, inp, gt, lk, loss_fn = _g9_setup(z, light)
+    draws = {k[5:]: t(z[k]).cuda() for k in z.files if k.startswith("draw.")}
     out = net(cuda(inp), draws=draws)
+    losses = loss_fn(out, cuda(gt), 10)
+    net.zero_grad()
+    losses["loss"].backward()
+    ocfg = orc.plumbing_cfg(skip=True, light=light)
+    ocfg.use_normal = True
+    dr = orc.Draws(**{k[5:]: t(z[k]) for k in z.files if k.startswith("draw.")})
+    D = torch.float64
+    dr64 = orc.Draws(**{k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in vars(dr).items()})
+    lc = _oracle_lc(lk)
+    o32, l32, g32 = orc.training_step_grads(sd, ocfg, inp, gt, lc, dr, step=10)
+    o64, l64, g64 = orc.training_step_grads({k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()},
+                                            {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}, lc, dr64, step=10)
+    hit = t(z["out.weight_sum"]).reshape(-1) > 1e-2
+    okeys = [k[4:] for k in z.files if k.startswith("out.")]
+    spread = _spread(o32, o64, okeys, hit)
+    gspread = {n_: rel_max(g32[n_], g64[n_]) for n_ in g32 if g64[n_].abs().max() > 0}
+    print("oracle fp32-vs-fp64 spread, outputs:", spread, " loss:", rel_max(l32["loss"], l64["loss"]), " worst gradient:", max(gspread.values()))
+    for k in okeys:
+        tol = max(1e-4, 3.0 * spread[k])
+        assert out[k].shape == tuple(z["out." + k].shape), k
+        if k == "normal_values":
+            assert_close(out[k].detach().cpu()[hit], t(z["out." + k])[hit], tol, k + " (weight_sum > 0.01)")
+        else:
+            assert_close(out[k].detach().cpu(), z["out." + k], tol, k)
+    assert_close(losses["loss"].detach().cpu(), z["loss.loss"], max(1e-4, 3.0 * rel_max(l32["loss"], l64["loss"])), "loss")
+    for n_, p in net.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert_close(g.cpu(), z["grad." + n_], max(1e-4, 3.0 * gspread.get(n_, 0.0)), "grad " + n_)
+
+
+@pytest.mark.parametrize("name,light", [("g9_train", False), ("g9_train_light", True)])
+def test_train_step_given_reference_depths_golden(golden, name, light):
+    """The reference's OWN recorded depths (ref.z_vals / ref.z_eik of G9) and draws through render(): every output, every loss
+    term and every parameter gradient against the reference's recorded numbers at 1e-4 (north_star)."""
+    z = golden(name)
+    sd, net, inp, gt, lk, loss_fn = _g9_setup(z, light)
+    eng = net._engine_for("cuda:0")
+    c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    out = net.render(cuda(inp), c, d, n, t(z["ref.z_vals"]).cuda(), t(z["ref.z_eik"]).cuda(),
+                     draws={"eik_pts": t(z["draw.eik_pts"]).cuda(), "nbr_off": t(z["draw.nbr_off"]).cuda()})
     losses = loss_fn(out, cuda(gt), 10)
     net.zero_grad()
     losses["loss"].backward()
     hit = t(z["out.weight_sum"]).reshape(-1) > 1e-2
     for k in z.files:
         if k.startswith("out."):
-            # grad_theta / diff_norm are evaluated AT sampler-chosen near-surface points (z_eik): they inherit the
-            # ill-conditioning of individual sample depths; the strict 1e-4 check is test_train_step_given_depths_full_size
-            tol = 5e-3 if k.endswith(("normal_values", "diff_norm", "grad_theta")) else 1e-3
             assert out[k[4:]].shape == tuple(z[k].shape), k
             if k.endswith("normal_values"):
-                assert_close(out[k[4:]].detach().cpu()[hit], t(z[k])[hit], tol, k + " (weight_sum > 0.01)")
+                assert_close(out[k[4:]].detach().cpu()[hit], t(z[k])[hit], 1e-4, k + " (weight_sum > 0.01)")
             else:
-                assert_close(out[k[4:]].detach().cpu(), z[k], tol, k)
-    assert_close(losses["loss"].detach().cpu(), z["loss.loss"], 1e-3, "loss")
+                assert_close(out[k[4:]].detach().cpu(), z[k], 1e-4, k)
+        if k.startswith("loss."):
+            if float(np.abs(z[k])) > 0:
+                assert_close(losses[k[5:]].detach().cpu(), z[k], 1e-4, k)
+    worst = 0.0
     for n_, p in net.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
-        assert_close(g.cpu(), z["grad." + n_], 2e-2, "grad " + n_)
+        if np.abs(z["grad." + n_]).max() == 0:
+            assert float(g.abs().max()) == 0.0, n_
+        else:
+            worst = max(worst, assert_close(g.cpu(), z["grad." + n_], 1e-4, "grad " + n_))
+    print("worst relative parameter-gradient error vs the reference's recorded gradients", worst)
+
+
+@pytest.mark.parametrize("name,light", [("g14_train_full", False), ("g14_train_full_light", True)])
+def test_full_width_train_step_vs_reference_golden(golden, name, light):
+    """synthetic.yml / synthetic_light_mask.yml networks (G14): the reference's depths and draws; outputs, loss terms and the
+    gradient digest of the reference's own backward at 1e-4."""
+    from i2sdf_amd import synthetic_conf, I2SDFLoss
+    from helpers import full_width_state_dict, assert_grad_digest
+    z = golden(name)
+    ocfg, sd = full_width_state_dict(z, light)
+    sd["density.beta"] = torch.tensor(0.05)
+    net = build(synthetic_conf(light), sd, train=True)
+    inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
+    gt = {k[3:]: t(z[k]) for k in z.files if k.startswith("gt.")}
+    lk = {k: v for k, v in z["loss_kwargs"]}
+    loss_fn = I2SDFLoss(**{k: (None if v == "None" else float(v)) for k, v in lk.items()})
+    eng = net._engine_for("cuda:0")
+    c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    out = net.render(cuda(inp), c, d, n, t(z["ref.z_vals"]).cuda(), t(z["ref.z_eik"]).cuda(),
+                     draws={"eik_pts": t(z["draw.eik_pts"]).cuda(), "nbr_off": t(z["draw.nbr_off"]).cuda()})
+    losses = loss_fn(out, cuda(gt), 10)
+    net.zero_grad()
+    losses["loss"].backward()
+    hit = t(z["out.weight_sum"]).reshape(-1) > 1e-2
+    for k in z.files:
+        if k.startswith("out."):
+            if k.endswith("normal_values"):
+                assert_close(out[k[4:]].detach().cpu()[hit], t(z[k])[hit], 1e-4, k + " (weight_sum > 0.01)")
+            else:
+                assert_close(out[k[4:]].detach().cpu(), z[k], 1e-4, k)
+        if k.startswith("loss.") and float(np.abs(z[k])) > 0:
+            assert_close(losses[k[5:]].detach().cpu(), z[k], 1e-4, k)
+    grads = {n_: (p.grad if p.grad is not None else torch.zeros_like(p)) for n_, p in net.named_parameters()}
+    print("worst gradient-digest error vs the reference", assert_grad_digest(z, grads, 1e-4))
+
+
+def test_full_width_eval_vs_reference_golden(golden):
+    """G15: synthetic.yml networks, eval.  (i) the reference's depths through render(): 1e-4; (ii) sampler in the loop: the
+    iteration count is exact and outputs agree within the oracle's measured fp32-vs-fp64 spread."""
+    from i2sdf_amd import synthetic_conf
+    from helpers import full_width_state_dict
+    z = golden("g15_eval_full")
+    ocfg, sd = full_width_state_dict(z, False)
+    sd["density.beta"] = torch.tensor(0.02)
+    net = build(synthetic_conf(False), sd)
+    inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
+    eng = net._engine_for("cuda:0")
+    c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+    hit = t(z["out.weight_sum"]).reshape(-1) > 1e-2
+    with torch.no_grad():
+        out = net.render(cuda(inp), c, d, n, t(z["ref.z_vals"]).cuda(), t(z["ref.z_eik"]).cuda())
+        for k in ("rgb_values", "depth_values", "weight_sum"):
+            assert_close(out[k].cpu(), z["out." + k], 1e-4, k)
+        assert_close(out["normal_map"].cpu()[hit], t(z["out.normal_map"])[hit], 1e-4, "normal_map (weight_sum > 0.01)")
+        out = net(cuda(inp))
+    assert int(net.last_sampler_iters.item()) == int(z["iters"])
+    o32 = orc.network_forward(sd, ocfg, inp, training=False)
+    o64 = orc.network_forward({k: v.double() for k, v in sd.items()}, ocfg, {k: v.double() for k, v in inp.items()}, training=False)
+    keys = ("rgb_values", "depth_values", "weight_sum", "normal_map")
+    spread = _spread(o32, o64, keys, hit)
+    print("fp32-vs-fp64 spread of the oracle with its own sampler:", spread)
+    for k in keys:
+        tol = max(1e-4, 3.0 * spread[k])
+        a, b = (out[k].cpu()[hit], t(z["out." + k])[hit]) if k == "normal_map" else (out[k].cpu(), t(z["out." + k]))
+        assert_close(a, b, tol, k + " (sampler in the loop)")
 
 
 @pytest.mark.parametrize("light", [False, True])

@@ -110,3 +110,50 @@ def test_sampler_train_with_draws(force):
     robust_z_check(zo, z64, what="z_vals(train)", noise=noise)
     got = torch.gather(zo.cpu(), 1, dr.eik_idx.long().unsqueeze(-1))
     assert torch.equal(got, zeik.cpu()), "z_eik must be z_vals[eik_idx]"
+
+
+def test_error_bound_golden(golden):
+    """S1 in isolation: ErrorBoundSampler.get_error_bound (ray_sampler.py:243-251) vs the reference's recorded values (G7b),
+    scalar beta and one beta per ray, with the fixture's explicit d*."""
+    from i2sdf_amd.config import plumbing_conf
+    z = golden("g7b_error_bound")
+    eng = make_engine(plumbing_conf(), orc.init_params(orc.plumbing_cfg(), seed=0))
+    zr, sr, ds = t(z["z"]).cuda(), t(z["sdf"]).cuda(), t(z["d_star"]).cuda()
+    eb = eng.error_bound(zr, sr, torch.tensor(float(z["beta_scalar"])), d_star=ds)
+    np.testing.assert_allclose(eb.cpu().numpy(), z["eb_scalar"], rtol=2e-5, atol=1e-30)
+    eb = eng.error_bound(zr, sr, t(z["beta_rows"]).cuda(), d_star=ds)
+    np.testing.assert_allclose(eb.cpu().numpy(), z["eb_rows"], rtol=2e-5, atol=1e-30)
+
+
+def test_d_star_four_cases():
+    """Theorem-1 bound d* per interval (ray_sampler.py:99-114): rows built so that every branch occurs -- first_cond
+    (a^2+b^2<=c^2 -> |d_i|), second_cond (-> |d_{i+1}|), the Heron height of the triangle, a sign change (-> 0), and the
+    degenerate b+c<=a case (-> 0) -- vs the oracle's restatement, elementwise; then the error bound that uses it."""
+    from i2sdf_amd.config import plumbing_conf
+    eng = make_engine(plumbing_conf(), orc.init_params(orc.plumbing_cfg(), seed=0))
+    g = torch.Generator().manual_seed(5)
+    B, n = 64, 150                                         # n > 128: rows of 3 samples per lane
+    zr = torch.sort(torch.rand(B, n, generator=g) * 6.0, -1)[0]
+    sr = torch.randn(B, n, generator=g) * 0.5
+    sr[0] = sr[0].abs() + 5.0                              # |d| >> interval: first/second cond everywhere
+    sr[1, ::2] *= 0.01                                     # alternating tiny/large: second_cond then first_cond
+    sr[2] = sr[2].abs() * 0.02 + 1e-3                      # |d| << interval: b + c - a <= 0 -> 0
+    sr[3] = 0.3 + 0.01 * torch.rand(n, generator=g)        # nearly equal, same sign: Heron branch
+    sr[4, 10] = 0.0                                        # sign(0) * sign(x) != 1 -> 0
+    ref_ds = orc.d_star_bound(zr, sr)
+    first = ((zr[:, 1:] - zr[:, :-1]) ** 2 + sr[:, :-1] ** 2 <= sr[:, 1:] ** 2)
+    second = ((zr[:, 1:] - zr[:, :-1]) ** 2 + sr[:, 1:] ** 2 <= sr[:, :-1] ** 2)
+    same = sr[:, 1:].sign() * sr[:, :-1].sign() == 1
+    heron = ~first & ~second & (sr[:, :-1].abs() + sr[:, 1:].abs() - (zr[:, 1:] - zr[:, :-1]) > 0)
+    for name, m in (("first", first & ~second & same), ("second", second & same), ("heron", heron & same), ("sign change", ~same),
+                    ("degenerate", ~first & ~second & ~heron & same)):
+        assert int(m.sum()) > 0, f"case '{name}' does not occur in the test rows"
+    beta = torch.linspace(0.02, 0.4, B)
+    eb, ds = eng.error_bound(zr.cuda(), sr.cuda(), beta.cuda(), want_d_star=True)
+    ds = ds.cpu()
+    # the Heron height is a difference of nearly equal products: compare it relative to the interval's scale
+    scale = torch.maximum(torch.maximum(sr[:, :-1].abs(), sr[:, 1:].abs()), zr[:, 1:] - zr[:, :-1])
+    assert float(((ds - ref_ds).abs() / scale).max()) <= 5e-5
+    assert torch.equal(ds == 0, ref_ds == 0)               # branch selection is exact
+    ref_eb = orc.error_bound(beta.unsqueeze(-1), sr, zr[:, 1:] - zr[:, :-1], ref_ds)
+    np.testing.assert_allclose(eb.cpu().numpy(), ref_eb.numpy(), rtol=1e-3, atol=1e-30)

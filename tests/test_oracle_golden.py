@@ -168,6 +168,73 @@ def test_g9_train_forward_loss_backward(golden, name, light):
             assert_close(grads[k[5:]], z[k], 2e-3, k)
 
 
+@pytest.mark.parametrize("name,light", [("g9_train", False), ("g9_train_light", True)])
+def test_g9_train_step_given_reference_depths(golden, name, light):
+    """Same as above but with the reference's OWN recorded depths (ref.z_vals): the ill-conditioned inverse-CDF depths are out
+    of the comparison, and fp32 oracle vs fp32 reference must agree at fp32 rounding level on every output and gradient."""
+    z = golden(name)
+    cfg = orc.plumbing_cfg(skip=True, light=light)
+    cfg.use_normal = True
+    sd = sd_from_npz(z, "sd.")
+    inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
+    gt = {k[3:]: t(z[k]) for k in z.files if k.startswith("gt.")}
+    dr = orc.Draws(eik_pts=t(z["draw.eik_pts"]), nbr_off=t(z["draw.nbr_off"]))
+    lk = {k: v for k, v in z["loss_kwargs"]}
+    lc = orc.LossCfg(eikonal_weight=float(lk["eikonal_weight"]), smooth_weight=float(lk["smooth_weight"]), smooth_iter=None,
+                     depth_weight=float(lk["depth_weight"]), normal_weight=float(lk["normal_weight"]),
+                     bubble_weight=float(lk["bubble_weight"]), light_mask_weight=float(lk.get("light_mask_weight", 0.0)))
+    out, losses, grads = orc.training_step_grads(sd, cfg, inp, gt, lc, dr, step=10, z_override=(t(z["ref.z_vals"]), t(z["ref.z_eik"])))
+    for k in z.files:
+        if k.startswith("out."):
+            assert_close(out[k[4:]], z[k], 2e-5, k)
+        if k.startswith("loss."):
+            assert_close(losses[k[5:]], z[k], 1e-5, k)
+        if k.startswith("grad."):
+            assert_close(grads[k[5:]], z[k], 5e-5, k)
+
+
+@pytest.mark.parametrize("name,light", [("g14_train_full", False), ("g14_train_full_light", True)])
+def test_g14_full_width_train_step(golden, name, light):
+    """synthetic.yml / synthetic_light_mask.yml networks, the reference's depths and draws: outputs, loss, gradient digest."""
+    from helpers import full_width_state_dict, assert_grad_digest
+    z = golden(name)
+    cfg, sd = full_width_state_dict(z, light)
+    cfg.use_normal = True
+    sd["density.beta"] = torch.tensor(0.05)
+    inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
+    gt = {k[3:]: t(z[k]) for k in z.files if k.startswith("gt.")}
+    dr = orc.Draws(eik_pts=t(z["draw.eik_pts"]), nbr_off=t(z["draw.nbr_off"]))
+    lk = {k: v for k, v in z["loss_kwargs"]}
+    lc = orc.LossCfg(eikonal_weight=float(lk["eikonal_weight"]), smooth_weight=float(lk["smooth_weight"]), smooth_iter=None,
+                     depth_weight=float(lk["depth_weight"]), normal_weight=float(lk["normal_weight"]),
+                     bubble_weight=float(lk["bubble_weight"]), light_mask_weight=float(lk.get("light_mask_weight", 0.0)))
+    out, losses, grads = orc.training_step_grads(sd, cfg, inp, gt, lc, dr, step=10, z_override=(t(z["ref.z_vals"]), t(z["ref.z_eik"])))
+    for k in z.files:
+        if k.startswith("out."):
+            assert_close(out[k[4:]], z[k], 2e-5, k)
+        if k.startswith("loss."):
+            assert_close(losses[k[5:]], z[k], 1e-5, k)
+    print("worst gradient-digest error", assert_grad_digest(z, grads, 5e-5))
+
+
+def test_g15_full_width_eval(golden):
+    from helpers import full_width_state_dict
+    z = golden("g15_eval_full")
+    cfg, sd = full_width_state_dict(z, False)
+    sd["density.beta"] = torch.tensor(0.02)
+    inp = {k[3:]: t(z[k]) for k in z.files if k.startswith("in.")}
+    out = orc.network_forward(sd, cfg, inp, training=False, z_override=(t(z["ref.z_vals"]), t(z["ref.z_eik"])))
+    for k in ("rgb_values", "depth_values", "weight_sum"):
+        assert_close(out[k], z["out." + k], 2e-5, k)
+    hit = t(z["out.weight_sum"]).reshape(-1) > 1e-2
+    assert_close(out["normal_map"][hit], t(z["out.normal_map"])[hit], 1e-4, "normal_map (weight_sum > 0.01)")
+    # and the sampler itself: iteration count exact
+    tr = orc.SamplerTrace()
+    cam, dirs, _ = orc.prepare_rays(inp["uv"], inp["pose"], inp["intrinsics"])
+    orc.sample_z_vals(sd, cfg, dirs, cam, training=False, trace=tr)
+    assert tr.iters == int(z["iters"])
+
+
 def test_g10_camera(golden):
     z = golden("g10_camera")
     d, c = orc.get_camera_params(t(z["uv"]), t(z["pose"]), t(z["intrinsics"]))
