@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: one training step of the I2-SDF render core on synthetic rays / random-weight networks.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 without a torch.distributed environment: this script launches N ranks itself (torch.distributed.run on 127.0.0.1, one
+rank per GPU, RCCL); under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.  Rank 0 prints ONE
+JSON line.
 
 Workload (BASELINE.json configs[1]): synthetic.yml networks (8x256 SDF + 4x256 radiance MLP, 800 955 parameters,
 reference init), 1024 rays per GPU, N_samples 64 -> 97 shaded samples per ray, camera (ii) of BASELINE.md (t=(0,0,-2),
@@ -9,11 +13,22 @@ beta=0.02, looking at the init sphere), sampler iteration count fixed to k=2 (it
 A step = ray set-up -> error-bounded sampler (k SDF-MLP passes over 128 samples/ray) -> SDF MLP with d sdf/dx ->
 radiance MLP -> density/compositing -> I2SDFLoss -> backward (double backward through the SDF MLP, all parameter
 gradients) -> [N>1: one flat all-reduce] -> Adam step.  Inputs are resident in HBM before the timed region.
-`value` = rays x 97 x N / step time (whole job).  fp32 throughout (fp32 MFMA: the 1e-4 parity bar excludes bf16).
+`value` = rays x 97 x N / step time (whole job, weak scaling: every rank draws its own 1024 rays).
+
+Arithmetic: fp32 storage and fp32 accumulation everywhere; the matrix products run either on fp32-input MFMA or (default) as
+bf16x3 split products on the bf16 MFMA pipe (three bf16 terms per fp32 operand, six partial products, error 2^-24:
+fp32-equivalent, csrc/x3.h) -- `dtype` says which.
+
+Sub-records of the same JSON line: `dense128` (BASELINE.json's metric convention: 128 shaded samples/ray, sampler bypassed),
+`strong` (fixed global batch of --strong-rays rays split over the ranks), `natural_k` (the data-dependent sampler loop instead
+of k=2), `roofline`, `cpu_baseline` (the CPU restatement on this node's host cores), `eager_rocm_baseline` (the same
+restatement as stock PyTorch-ROCm eager ops on this GPU: the un-fused baseline of BASELINE.md section 3).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,18 +40,39 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=1024, help="rays per GPU (weak-scaling headline)")
+    ap.add_argument("--strong-rays", type=int, default=8192, help="global batch of the strong-scaling sub-record (split over the ranks)")
+    ap.add_argument("--scaling", default="both", choices=["weak", "strong", "both"],
+                    help="which scaling mode(s) to time; `value`/`scaling` of the JSON line are the weak ones unless --scaling strong")
     ap.add_argument("--sampler-iters", type=int, default=2, help="fixed sampler iterations k (0 = data dependent)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the dense128 / natural_k / eager_rocm_baseline sub-records")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-rays", type=int, default=512)
+    ap.add_argument("--fused-adam", type=int, default=1, help="1: i2sdf_amd.FusedAdam (one HIP launch over the flat buffer); 0: torch.optim.Adam")
     ap.add_argument("--bf16x3", type=int, default=-1,
                     help="bit mask of the kernels that run in bf16x3 split arithmetic (1 sampler forward, 2 weight gradients, "
                          "4 training forward, 8 SDF backward, 16 radiance net); -1 = the engine's default (all available), 0 = plain fp32 MFMA everywhere")
-    ap.add_argument("--profile-kernels", action="store_true", default=True)
     return ap.parse_args()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn(args):
+    """--gpus N with no torch.distributed environment: become the launcher (one rank per GPU, rendezvous on 127.0.0.1)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def flops_per_point(cfg):
@@ -59,8 +95,9 @@ def flops_per_point(cfg):
 
 
 def bytes_per_point(cfg):
-    """Algorithmic (compulsory) HBM bytes per point of the per-point saved-tensor traffic, fp32 (DESIGN.md "Data layout"):
-    every tensor counted once per kernel that must read or write it."""
+    """HBM bytes per point of the saved-tensor traffic THIS DESIGN moves, fp32 (DESIGN.md "Data layout"): every tensor counted
+    once per kernel that reads or writes it.  It is the design's own traffic, not a compulsory minimum: the compulsory I/O of these
+    kernels is ~1 KB/point (the MLP kernels are MFMA-bound)."""
     H, F = cfg.sdf.hidden, cfg.feature_size
     nh = cfg.sdf.n_lin - 1                         # hidden activations h_1..h_{L-1} of the SDF net
     nr = cfg.rgb.n_lin - 1
@@ -74,101 +111,159 @@ def bytes_per_point(cfg):
     }
 
 
+class Workload:
+    """One rank's training-step workload: `rays` rays of the synthetic camera, the synthetic.yml networks, loss, optimizer."""
+
+    def __init__(self, args, dev, rank, world):
+        import torch
+        from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
+        from i2sdf_amd import dist as i2dist
+        self.torch, self.dev, self.rank, self.world, self.args = torch, dev, rank, world, args
+        conf = synthetic_conf()
+        conf["use_normal"] = True
+        torch.manual_seed(0)                                  # identical initial weights on every rank
+        self.net = I2SDFNetwork(conf).to(dev)
+        with torch.no_grad():
+            self.net.density.beta.fill_(0.02)
+        self.net.train()
+        self.loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)   # synthetic.yml:15-23
+        if args.fused_adam:
+            from i2sdf_amd import FusedAdam
+            self.opt = FusedAdam(self.net, lr=5.0e-4, eps=1e-15)         # model/trainer/recon.py:203 (Adam, lr 5e-4)
+        else:
+            self.opt = torch.optim.Adam(self.net.get_param_groups(5.0e-4), eps=1e-15)
+        if world > 1:
+            i2dist.attach_data_parallel(self.net)
+        self.step_no = 0
+
+    def inputs(self, B, seed):
+        torch, dev = self.torch, self.dev
+        g = torch.Generator().manual_seed(seed)
+        W_, H_ = 640, 480
+        K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2] = W_ / 2; K[1, 2] = H_ / 2
+        pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
+        uv = torch.stack([torch.randint(0, W_, (B,), generator=g), torch.randint(0, H_, (B,), generator=g)], -1).float().reshape(B, 1, 2)
+        inp = {"uv": uv.to(dev), "intrinsics": K.repeat(B, 1, 1).to(dev), "pose": pose.repeat(B, 1, 1).to(dev)}
+        gt = {"rgb": torch.rand(B, 3, generator=g).to(dev), "depth": (torch.rand(B, generator=g) * 3).to(dev),
+              "depth_mask": torch.ones(B, dtype=torch.bool, device=dev),
+              "normal": torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).to(dev),
+              "normal_mask": torch.ones(B, dtype=torch.bool, device=dev)}
+        return inp, gt
+
+    def fence(self):
+        if self.world > 1:
+            self.torch.distributed.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False):
+        """-> dict(dt seconds for `steps` steps (max over ranks), loss, iters, ktimes).  dense > 0: `dense` uniform samples per ray,
+        sampler bypassed (the dense-128 convention)."""
+        torch, net = self.torch, self.net
+        inp, gt = self.inputs(B, seed)
+        net.force_iters = k_iters
+        zs = None
+        if dense:
+            eng = net._engine_for(self.dev)
+            c, d, nrm = eng.ray_setup(inp["uv"], inp["pose"], inp["intrinsics"])
+            z = torch.linspace(0.0, 6.0, dense + 1, device=self.dev).repeat(B, 1).contiguous()      # n samples + z_max column
+            zs = (c, d, nrm, z, z[:, dense // 2:dense // 2 + 1].contiguous())
+
+        def step():
+            out = net.render(inp, *zs) if zs else net(inp)
+            losses = self.loss_fn(out, gt, self.step_no)
+            self.opt.zero_grad(set_to_none=True)
+            losses["loss"].backward()
+            self.opt.step()
+            self.step_no += 1
+            return losses["loss"]
+
+        for _ in range(max(warmup, 1)):
+            step()
+        eng = net._engine_for(self.dev)
+        self.fence()
+        if timing:
+            eng.start_timing()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        ktimes = eng.stop_timing() if timing else None
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return {"dt": float(t.item()), "loss": float(loss.item()), "iters": int(net.last_sampler_iters.item()) if not dense else 0,
+                "ktimes": ktimes, "eng": eng}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn(args))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible "
+                         "(--share-gpu --backend gloo runs all ranks on cuda:0 to smoke-test the N>1 path)")
     dev_index = 0 if (world == 1 or args.share_gpu) else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(dev_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
     dev = torch.device("cuda", dev_index)
-    torch.cuda.set_device(dev)
 
-    from i2sdf_amd import I2SDFNetwork, I2SDFLoss, NetConfig, synthetic_conf
-    from i2sdf_amd import dist as i2dist
-
-    conf = synthetic_conf()
-    conf["use_normal"] = True
-    torch.manual_seed(0)                                  # identical initial weights on every rank
-    net = I2SDFNetwork(conf).to(dev)
-    with torch.no_grad():
-        net.density.beta.fill_(0.02)
-    net.train()
-    net.force_iters = args.sampler_iters
-    loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)   # synthetic.yml:15-23
-    opt = torch.optim.Adam(net.get_param_groups(5.0e-4), eps=1e-15)   # model/trainer/recon.py:203
-    if world > 1:
-        i2dist.attach_data_parallel(net)
-
+    wl = Workload(args, dev, rank, world)
     B = args.rays
-    g = torch.Generator().manual_seed(1000 + rank)        # each rank draws its own rays (ray-sharded data parallelism)
-    W_, H_ = 640, 480
-    K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2] = W_ / 2; K[1, 2] = H_ / 2
-    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
-    uv = torch.stack([torch.randint(0, W_, (B,), generator=g), torch.randint(0, H_, (B,), generator=g)], -1).float().reshape(B, 1, 2)
-    inp = {"uv": uv.to(dev), "intrinsics": K.repeat(B, 1, 1).to(dev), "pose": pose.repeat(B, 1, 1).to(dev)}
-    gt = {"rgb": torch.rand(B, 3, generator=g).to(dev), "depth": (torch.rand(B, generator=g) * 3).to(dev),
-          "depth_mask": torch.ones(B, dtype=torch.bool, device=dev),
-          "normal": torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).to(dev),
-          "normal_mask": torch.ones(B, dtype=torch.bool, device=dev)}
-
-    def step(i):
-        out = net(inp)
-        losses = loss_fn(out, gt, i)
-        opt.zero_grad(set_to_none=True)
-        losses["loss"].backward()
-        opt.step()
-        return losses["loss"]
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    step(0)                                   # builds the engine (and the flat parameter buffer) the way a trainer would
-    eng = net._engine_for(dev)
+    wl.run(B, 1000 + rank, args.sampler_iters, 1, 1)        # builds the engine (and the flat parameter buffer) the way a trainer would
+    eng = wl.net._engine_for(dev)
     if args.bf16x3 >= 0:
         eng.set_sdf_forward_bf16x3(bool(args.bf16x3 & 1))
         eng.set_wgrad_bf16x3(bool(args.bf16x3 & 2))
         eng.set_train_forward_bf16x3(bool(args.bf16x3 & 4))
         eng.set_sdf_backward_bf16x3(bool(args.bf16x3 & 8))
         eng.set_rgb_bf16x3(bool(args.bf16x3 & 16))
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    eng.start_timing()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    ktimes = eng.stop_timing()
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    iters = int(net.last_sampler_iters.item())
     n_shaded = eng.n_z - 1
-    ms = dt / args.steps * 1e3
-    value = B * n_shaded * world / (dt / args.steps)
+    K, W = args.steps, args.warmup
+
+    # ---- headline: weak scaling, every rank draws its own `rays` rays -----------------------------------------------
+    weak = strong = None
+    if args.scaling in ("weak", "both"):
+        weak = wl.run(B, 1000 + rank, args.sampler_iters, K, W, timing=True)      # each rank draws its own rays (ray-sharded data parallelism)
+    if args.scaling in ("strong", "both"):
+        Bs = args.strong_rays // world                    # fixed GLOBAL batch, split over the ranks
+        strong = wl.run(Bs, 2000 + rank, args.sampler_iters, K, W, timing=(weak is None))
+        strong["rays_per_gpu"] = Bs
+    head = weak if weak is not None else strong
+    head_B = B if weak is not None else strong["rays_per_gpu"]
+    dt, iters, ktimes = head["dt"], head["iters"], head["ktimes"]
+    ms = dt / K * 1e3
+    value = head_B * n_shaded * world / (dt / K)
+
+    extras = {}
+    if not args.no_extras:
+        d128 = wl.run(B, 1000 + rank, 0, K, W, dense=128)
+        extras["dense128"] = {"value": round(B * 128 * world / (d128["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(d128["dt"] / K * 1e3, 4),
+                              "workload": f"{B} rays/GPU x 128 uniform shaded samples, sampler bypassed (BASELINE.json metric convention), same step otherwise"}
+        nat = wl.run(B, 1000 + rank, 0, K, W)
+        extras["natural_k"] = {"value": round(B * n_shaded * world / (nat["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(nat["dt"] / K * 1e3, 4),
+                               "sampler_iters_observed": nat["iters"],
+                               "workload": "same as the headline with the data-dependent sampler loop (all max_total_iters iterations enqueued, device flag)"}
 
     result = None
     if rank == 0:
-        cfg = net.cfg
+        cfg = wl.net.cfg
         fp = flops_per_point(cfg)
-        M_main, M_sdf = B * n_shaded, B * n_shaded + 3 * B
+        M_main, M_sdf = head_B * n_shaded, head_B * n_shaded + 3 * head_B
         launch_flops = {
             # the sampler entry point = k SDF-MLP passes over 128 samples/ray + the per-ray Algorithm-1 kernels (counted as 0 FLOP)
-            "i2sdf_sample_rays": fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * max(iters, 1),
+            "i2sdf_sample_rays": fp["sdf_forward"] * head_B * cfg.sampler.N_samples_eval * max(iters, 1),
             "i2sdf_sdf_forward_grad": fp["sdf_forward_grad"] * M_sdf,
             "i2sdf_rgb_forward": fp["rgb_forward"] * M_main,
             "i2sdf_rgb_backward": fp["rgb_backward"] * M_main,
@@ -177,54 +272,66 @@ def main():
         }
         kern = {}
         for name, (tot_ms, cnt) in ktimes.items():
-            kern[name] = {"ms_per_step": tot_ms / args.steps, "launches_per_step": cnt / args.steps}
-            key = name
-            if key in launch_flops and cnt:
-                kern[name]["tflops"] = launch_flops[key] / (tot_ms / cnt * 1e-3) / 1e12
-        # dominant = the kernel family with the largest share of the step
+            kern[name] = {"ms_per_step": tot_ms / K, "launches_per_step": cnt / K}
+            if name in launch_flops and cnt:
+                kern[name]["tflops"] = launch_flops[name] / (tot_ms / cnt * 1e-3) / 1e12
         mfma_names = [n for n in kern if "tflops" in kern[n]]
-        dom = max(mfma_names, key=lambda n: kern[n]["ms_per_step"]) if mfma_names else None
+        dom = max(mfma_names, key=lambda n: kern[n]["ms_per_step"]) if mfma_names else None    # dominant = largest share of the step
         PEAK = 157.3            # TFLOP/s, fp32-input MFMA on MI355X (MI355X_MICROARCH.md)
-        PEAK_X3 = 2500.0 / 6    # bf16 dense MFMA peak / six bf16 MFMAs per fp32 product block (csrc/x3.h): fp32-equivalent TFLOP/s
+        PEAK_BF16 = 2500.0      # TFLOP/s dense bf16 MFMA
+        PEAK_X3 = PEAK_BF16 / 6  # six bf16 MFMAs per fp32 product block (csrc/x3.h): fp32-equivalent TFLOP/s at 100 % bf16 issue
         x3 = {"i2sdf_sample_rays": eng.sdf_forward_bf16x3, "i2sdf_sdf_forward_grad": eng.train_forward_bf16x3,
               "i2sdf_sdf_backward": eng.sdf_backward_bf16x3, "i2sdf_weight_grads": eng.wgrad_bf16x3,
               "i2sdf_rgb_forward": eng.rgb_bf16x3, "i2sdf_rgb_backward": eng.rgb_bf16x3}
         roof = None
         if dom:
-            # the roof that binds the dominant entry point: time at the arithmetic peak vs time at the HBM peak (8 TB/s) for its
-            # algorithmic FLOPs / bytes; `achieved` and `peak` are reported in the unit of the binding roof
+            # the MLP kernels are dense contractions at ~1e6 FLOP per 12-byte point -> the roof is the MFMA peak of
+            # the datatype used.  achieved = algorithmic FLOPs (fp32 products, SURVEY per-point figures x points) / mean duration.
             ach = kern[dom]["tflops"]
             peak = PEAK_X3 if x3.get(dom) else PEAK
             npts = {"i2sdf_rgb_forward": M_main, "i2sdf_rgb_backward": M_main}.get(dom, M_sdf)
-            alg_bytes = bytes_per_point(cfg).get(dom, 0) * npts
+            design_bytes = bytes_per_point(cfg).get(dom, 0) * npts
             t_launch = kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1e-9) * 1e-3
-            t_mfma, t_hbm = launch_flops[dom] / (peak * 1e12), alg_bytes / 8.0e12
-            common = {"kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent)" if x3.get(dom) else "f32 MFMA",
-                      "traffic": profiled_traffic(dom), "tflops": round(ach, 2), "frac_of_arithmetic_peak": round(ach / peak, 4),
-                      "algorithmic_bytes": int(alg_bytes), "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
-                      "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
-                                                       / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
-            if t_hbm > t_mfma:
-                gbs = alg_bytes / t_launch / 1e9
-                roof = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
-            else:
-                roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)}
-            roof.update(common)
+            traffic, src = profiled_traffic(dom)
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per product block)"
+                    if x3.get(dom) else "f32 MFMA",
+                    "bf16_mfma_issue_tflops": round(ach * 6, 1) if x3.get(dom) else None,
+                    "algorithmic_flops": int(launch_flops[dom]), "launch_ms": round(t_launch * 1e3, 4),
+                    "traffic": traffic, "traffic_source": src,
+                    # the design's own saved-tensor traffic (NOT compulsory: recomputation / fusion would remove it) against HBM peak
+                    "hbm_view": {"design_bytes": int(design_bytes), "gbs": round(design_bytes / t_launch / 1e9, 1), "peak_gbs": 8000.0,
+                                 "frac": round(design_bytes / t_launch / 8.0e12, 4)},
+                    "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
+                    "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
+                                                     / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
         total_flops = sum(launch_flops.values())
+        any_x3 = any(x3.values())
         result = {
-            "metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not any(x3.values()) else "f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate)",
+            "metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak" if weak is not None else "strong",
+            "vs_baseline": None,
+            "dtype": "f32" if not any_x3 else "f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
-                       "rays_per_gpu": B, "shaded_samples_per_ray": n_shaded, "sampler_iters": iters, "sampler_samples_per_iter": cfg.sampler.N_samples_eval,
-                       "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce)"},
-            "rays_per_s": round(B * world / (dt / args.steps), 1),
-            "step_tflops": round(total_flops * world / (dt / args.steps) / 1e12, 2),
-            "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / args.steps) / 1e12 / PEAK, 4),   # per GPU (weak scaling)
-            "final_loss": float(loss.item()),
+                       "rays_per_gpu": head_B, "shaded_samples_per_ray": n_shaded, "sampler_iters": iters, "sampler_samples_per_iter": cfg.sampler.N_samples_eval,
+                       "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce)",
+                       "optimizer": "i2sdf_amd.FusedAdam (1 launch)" if args.fused_adam else "torch.optim.Adam",
+                       "backend": (args.backend if world > 1 else None), "world_size_observed": (dist.get_world_size() if world > 1 else 1)},
+            "rays_per_s": round(head_B * world / (dt / K), 1),
+            "step_tflops": round(total_flops * world / (dt / K) / 1e12, 2),
+            "frac_bf16x3_mfma_roofline_whole_step": round(total_flops / (dt / K) / 1e12 / PEAK_X3, 4) if any_x3 else None,   # per GPU
+            "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / K) / 1e12 / PEAK, 4),   # per GPU (weak scaling)
+            "final_loss": head["loss"],
             "roofline": roof, "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
         }
+        if weak is not None and strong is not None:
+            Bs = strong["rays_per_gpu"]
+            result["strong"] = {"value": round(Bs * world * n_shaded / (strong["dt"] / K), 1), "unit": "ray-samples/s", "scaling": "strong",
+                                "ms_per_step": round(strong["dt"] / K * 1e3, 4), "global_rays": Bs * world, "rays_per_gpu": Bs, "n_gpus": world}
+        result.update(extras)
+        if not args.no_extras and world == 1:
+            result["eager_rocm_baseline"] = eager_rocm_baseline(dev, iters, n_shaded)
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, iters, n_shaded)
         print(json.dumps(result), flush=True)
@@ -234,40 +341,42 @@ def main():
 
 
 def profiled_traffic(entry):
-    """HBM bytes per launch of an entry point from the committed PMC summaries (profiles/r1_pmc_{fetch,write}_summary.csv:
+    """HBM bytes per launch of an entry point from the newest committed PMC summaries (profiles/r*_pmc_{fetch,write}_summary.csv:
     FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; FETCH doubled as MI355X_MICROARCH.md prescribes for
-    16-B-per-lane loads on gfx950).  None when the summaries are absent or do not cover the entry point's kernels."""
+    16-B-per-lane loads on gfx950).  It is a profile of the same command from an earlier run, not a live counter read:
+    -> (bytes | None, source label)."""
     import csv
+    import glob
     pat = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),
            "i2sdf_sample_rays": ("sdf_fwd", "sampler_")}.get(entry)
     here = os.path.dirname(os.path.abspath(__file__))
+    rounds = sorted({os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(here, "profiles", "r*_pmc_fetch_summary.csv"))},
+                    key=lambda r: int(r[1:]) if r[1:].isdigit() else -1)
+    if not rounds or not pat:
+        return None, None
+    tag_r = rounds[-1]
     try:
         tot = 0.0
         for tag, col, mult in (("fetch", "FETCH_SIZE_per_dispatch", 2.0), ("write", "WRITE_SIZE_per_dispatch", 1.0)):
-            rows = list(csv.DictReader(open(os.path.join(here, "profiles", f"r1_pmc_{tag}_summary.csv"))))
+            rows = list(csv.DictReader(open(os.path.join(here, "profiles", f"{tag_r}_pmc_{tag}_summary.csv"))))
             steps = max([int(r["dispatches"]) for r in rows if "wn_backward" in r["kernel"]] or [0])
-            if not pat or steps == 0:
-                return None
+            if steps == 0:
+                return None, None
             tot += sum(float(r[col]) * 1024.0 * mult * int(r["dispatches"]) for r in rows if any(q in r["kernel"] for q in pat)) / steps
-        return round(tot) if tot > 0 else None
+        return (round(tot), f"profiles/{tag_r}_pmc_{{fetch,write}}_summary.csv (committed rocprofv3 --pmc passes of `bench.py`, not measured in this run)") \
+            if tot > 0 else (None, None)
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
-def cpu_baseline(args, iters, n_shaded):
-    """The CPU oracle (a port of the reference's PyTorch path, validated against it) timed on this node's host cores on
-    a bounded sample of the same workload: same networks, same camera, same fixed k, fewer rays."""
+def _oracle_case(Bc, iters, n_shaded, device, dtype_seed=7):
     import torch
     from oracle import i2sdf_oracle as orc
-    # torch's CPU GEMMs on 256-wide layers stop scaling (and then collapse) beyond a few tens of threads: use at most 32
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
     ocfg = orc.synthetic_cfg(False)
     ocfg.use_normal = True
     sd = orc.init_params(ocfg, seed=0)
     sd["density.beta"] = torch.tensor(0.02)
-    Bc = args.cpu_rays
-    g = torch.Generator().manual_seed(7)
+    g = torch.Generator().manual_seed(dtype_seed)
     K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2] = 320.0; K[1, 2] = 240.0
     pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
     uv = torch.stack([torch.randint(0, 640, (Bc,), generator=g), torch.randint(0, 480, (Bc,), generator=g)], -1).float().reshape(Bc, 1, 2)
@@ -281,6 +390,22 @@ def cpu_baseline(args, iters, n_shaded):
                    eik_idx=torch.randint(n_shaded + 1, (Bc,), generator=g), eik_pts=(torch.rand(Bc, 3, generator=g) * 2 - 1) * R,
                    nbr_off=(torch.rand(Bc, 3, generator=g) * 2 - 1) * 0.005)
     lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
+    mv = lambda d: {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}
+    dr = orc.Draws(**mv(vars(dr)))
+    return orc, ocfg, mv(sd), mv(inp), mv(gt), lc, dr
+
+
+def cpu_baseline(args, iters, n_shaded):
+    """The CPU oracle (a port of the reference's PyTorch path, validated against it) timed on this node's host cores on
+    a bounded sample of the same workload: same networks, same camera, same fixed k, fewer rays."""
+    import torch
+    ncpu = os.cpu_count() or 1
+    # torch's CPU GEMMs on 256-wide layers stop scaling (and then collapse) beyond a few tens of threads: the headline CPU number
+    # uses at most 32; the all-threads figure SURVEY 8(d) asks for is measured next to it on a smaller sample.
+    cores = min(ncpu, 32)
+    torch.set_num_threads(cores)
+    Bc = args.cpu_rays
+    orc, ocfg, sd, inp, gt, lc, dr = _oracle_case(Bc, iters, n_shaded, "cpu")
     times = []
     for i in range(4):
         t0 = time.perf_counter()
@@ -289,9 +414,39 @@ def cpu_baseline(args, iters, n_shaded):
         if sum(times) > 40.0 and len(times) >= 2:      # keep the default run within minutes on any host
             break
     med = sorted(times[1:])[len(times[1:]) // 2]
-    return {"value": round(Bc * n_shaded / med, 1), "unit": "ray-samples/s", "cores": cores, "kind": "port",
-            "sample": f"{Bc} rays x {n_shaded} shaded samples, same nets/camera/k={iters}, fwd+loss+bwd (no optimizer), torch CPU fp32 "
-                      f"{cores} threads (host has {os.cpu_count()}), median of {len(times) - 1} after 1 warm-up, {med:.2f} s/step"}
+    out = {"value": round(Bc * n_shaded / med, 1), "unit": "ray-samples/s", "cores": cores, "kind": "port",
+           "sample": f"{Bc} rays x {n_shaded} shaded samples, same nets/camera/k={iters}, fwd+loss+bwd (no optimizer), torch CPU fp32 "
+                     f"{cores} threads (host has {ncpu}), median of {len(times) - 1} after 1 warm-up, {med:.2f} s/step"}
+    if ncpu > cores and sum(times) < 30.0:
+        torch.set_num_threads(ncpu)
+        Ba = 64
+        orc, ocfg, sd, inp, gt, lc, dr = _oracle_case(Ba, iters, n_shaded, "cpu")
+        t0 = time.perf_counter()
+        orc.training_step_grads(sd, ocfg, inp, gt, lc, dr, step=10, force_iters=iters or None)
+        ta = time.perf_counter() - t0
+        out["all_threads"] = {"value": round(Ba * n_shaded / ta, 1), "cores": ncpu, "sample": f"{Ba} rays, 1 step, no warm-up, {ta:.2f} s"}
+        torch.set_num_threads(cores)
+    return out
+
+
+def eager_rocm_baseline(dev, iters, n_shaded, Bc=1024):
+    """The un-fused GPU baseline of BASELINE.md section 3: the CPU restatement's own torch ops (autograd double backward
+    included) run as stock PyTorch-ROCm eager kernels on this MI355X, same nets/camera/k, fwd+loss+bwd, no optimizer."""
+    import torch
+    try:
+        orc, ocfg, sd, inp, gt, lc, dr = _oracle_case(Bc, iters, n_shaded, dev)
+        times = []
+        for i in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            orc.training_step_grads(sd, ocfg, inp, gt, lc, dr, step=10, force_iters=iters or None)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        med = sorted(times[1:])[len(times[1:]) // 2]
+        return {"value": round(Bc * n_shaded / med, 1), "unit": "ray-samples/s", "kind": "port on stock PyTorch-ROCm eager ops (fp32, no TF32 on gfx950)",
+                "sample": f"{Bc} rays x {n_shaded} shaded samples, k={iters}, median of 3 after 1 warm-up, {med * 1e3:.1f} ms/step"}
+    except Exception as e:          # the oracle is CPU-first test infrastructure; a device-placement slip must not kill the headline
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
 
 if __name__ == "__main__":

@@ -14,6 +14,9 @@ def __getattr__(name):
     if name in ("RayBatcher", "RaySample"):
         from . import batcher
         return getattr(batcher, name)
+    if name == "FusedAdam":
+        from .optim import FusedAdam
+        return FusedAdam
     if name == "RenderEngine":
         from .engine import RenderEngine
         return RenderEngine

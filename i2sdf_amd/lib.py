@@ -87,6 +87,7 @@ SIGNATURES = {
     "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
     "i2sdf_wgrad_chunk_points": (_I64, []),
     "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
+    "i2sdf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
     "i2sdf_error_bound": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
     "i2sdf_sampler_workspace_floats": (_I64, [_I64]),
     # plan, packed, params, cfg, cam, dirs, B, training, t_lin, u_more, u_final, ldu_final, extra_tab, strat_u, extra_idx, eik_idx,

@@ -280,6 +280,15 @@ int i2sdf_weight_grads(const i2sdf_plan* plan, const i2sdf_train_buffers* bufs, 
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Optimizer step over the flat parameter buffer -- torch.optim.Adam(model.get_param_groups(lr), eps=1e-15) of
+ * model/trainer/recon.py:201-203 (same update rule and operation order, bias corrections in double on the host) as ONE
+ * launch.  step = 1 for the first update.  grad_scale multiplies the gradient first (1/world for a summed all-reduce).
+ *   params, grads, exp_avg, exp_avg_sq: (n) fp32, updated in place (grads is read-only)
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Error-bounded ray sampler -- ErrorBoundSampler.get_z_vals incl. UniformSampler and get_error_bound
  * (model/network/ray_sampler.py:22-43,67-251), bg disabled.  Runs the whole Algorithm-1 loop on the device:
  * all max_total_iters iterations are enqueued, a device flag turns the remaining ones into no-ops once the

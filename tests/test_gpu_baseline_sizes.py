@@ -1,0 +1,165 @@
+"""GPU: the BASELINE.json configurations at THEIR sizes (synthetic.yml networks): 1024-ray and 4096-ray training steps (cfg 2,
+cfg 5 per-GPU batch), the shipped 1600-ray batch (config/synthetic.yml:4), and one 12 000-ray eval chunk (cfg 4,
+split_n_pixels 12000, config/synthetic.yml:7).
+
+The CPU oracle cannot run these sizes in seconds, so each case is checked two ways:
+  * a RAY SUBSET against the fp64 oracle at 1e-4.  The module renders the full batch with its own sampler; the depths it chose for
+    the subset rays are handed to the oracle (identical batch composition on both sides).  For the training step the
+    probe loss weights only the subset rays (the kernels still process every ray, with zero upstream gradient elsewhere), so the
+    oracle's parameter gradients of the subset are the full step's gradients.  The subset spans rays handled by full workgroups,
+    by the split-K tail workgroups and the first/last rows of the batch;
+  * size-independent properties of the full batch: shapes, finiteness, sorted depths inside [near, far] ending at far,
+    0 <= weight_sum <= 1, unit normals, sampler iteration count within [1, max_total_iters]."""
+import pytest
+import torch
+
+from oracle import i2sdf_oracle as orc
+from helpers import assert_close, camera_inputs, make_gt
+
+pytestmark = pytest.mark.gpu
+D = torch.float64
+
+
+def _build(train, seed=61, beta=0.02):
+    from i2sdf_amd import I2SDFNetwork, synthetic_conf
+    conf = dict(synthetic_conf(False))
+    conf["use_normal"] = True
+    ocfg = orc.synthetic_cfg(False)
+    ocfg.use_normal = True
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=seed), 0.03, seed=seed + 1)
+    sd["density.beta"] = torch.tensor(beta)
+    net = I2SDFNetwork(conf)
+    net.load_state_dict(sd)
+    return net.cuda().train(train), ocfg, sd
+
+
+def _cuda(d):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def _subset(B, n=20):
+    """first rows, a spread over the middle, and the last rows (the split-K tail workgroups own the end of the point batch)"""
+    idx = torch.cat([torch.arange(0, 4), torch.linspace(5, B - 12, n - 12).long(), torch.arange(B - 8, B)])
+    return torch.unique(idx)
+
+
+def _check_depths(z_all, far=6.0):
+    z = z_all.detach().cpu()
+    assert torch.isfinite(z).all()
+    assert (z[:, 1:] >= z[:, :-1]).all(), "depth rows must be sorted"
+    assert float(z.min()) >= 0.0 and float(z.max()) <= far and bool((z[:, -1] == far).all())
+
+
+@pytest.mark.parametrize("B", [1024, 1600, 4096])
+def test_training_step_full_size(B):
+    net, ocfg, sd = _build(True)
+    inp = camera_inputs(B, (0.0, 0.0, -2.0), seed=7)
+    g = torch.Generator().manual_seed(B)
+    R = ocfg.scene_bounding_sphere
+    eik_pts = (torch.rand(B, 3, generator=g) * 2 - 1) * R
+    nbr_off = (torch.rand(B, 3, generator=g) * 2 - 1) * 0.005
+    S = _subset(B)
+    # full-batch forward with the module's own sampler (natural, data-dependent k); capture the depths it used
+    cinp = _cuda(inp)
+    eng = net._engine_for("cuda:0")
+    cam, dirs, dn = eng.ray_setup(cinp["uv"], cinp["pose"], cinp["intrinsics"])
+    sc = net.cfg.sampler
+    strat_u = torch.rand(B, sc.N_samples_eval, generator=g).cuda()
+    cdf_u = torch.rand(B, sc.N_samples, generator=g).cuda()
+    extra = torch.stack([torch.randperm(sc.N_samples_eval * (it + 1), generator=g)[: sc.N_samples_extra] for it in range(sc.max_total_iters)]).cuda()
+    eik_idx = torch.randint(eng.n_z, (B,), generator=g).cuda()
+    z_all, z_eik, iters = eng.sample_rays(net._flat, cam, dirs, training=True, strat_u=strat_u, cdf_u=cdf_u, extra_idx=extra, eik_idx=eik_idx)
+    k = int(iters.item())
+    assert 1 <= k <= sc.max_total_iters
+    _check_depths(z_all)
+    assert z_all.shape == (B, eng.n_z) and z_eik.shape == (B, 1)
+    out = net.render(cinp, cam, dirs, dn, z_all, z_eik, draws={"eik_pts": eik_pts.cuda(), "nbr_off": nbr_off.cuda()})
+    # ---- properties of the full batch
+    assert out["rgb_values"].shape == (B, 3) and out["depth_values"].shape == (B,) and out["weight_sum"].shape == (B, 1)
+    assert out["normal_values"].shape == (B, 3) and out["grad_theta"].shape == (2 * B, 3) and out["diff_norm"].shape == (B,)
+    for name, v in out.items():
+        assert torch.isfinite(v).all(), name
+    ws = out["weight_sum"].detach()
+    assert float(ws.min()) >= -1e-6 and float(ws.max()) <= 1.0 + 1e-5
+    hit = ws.reshape(-1) > 1e-2
+    nn = out["normal_values"].detach()[hit].norm(dim=1)
+    assert float((nn - 1).abs().max()) < 1e-4
+    # ---- probe loss on the subset rays only
+    w = {"rgb": torch.randn(len(S), 3, generator=g), "depth": torch.randn(len(S), generator=g), "nrm": torch.randn(len(S), 3, generator=g)}
+    Sc = S.cuda()
+    # the normal of a ray that hits nothing is the direction of a vanishing sum (ill-conditioned in the reference itself): the probe
+    # weights normals only on rays with weight_sum > 0.01, the same rays on both sides
+    hit_s = (ws.reshape(-1)[Sc] > 1e-2).float().cpu()
+    w["nrm"] = w["nrm"] * hit_s.unsqueeze(1)
+    gth = out["grad_theta"]
+    loss = ((out["rgb_values"][Sc] * w["rgb"].cuda()).sum() + (out["depth_values"][Sc] * w["depth"].cuda()).sum()
+            + 0.3 * (out["normal_values"][Sc] * w["nrm"].cuda()).sum()
+            + 0.1 * ((gth[Sc].norm(2, dim=1) - 1) ** 2).sum() + 0.1 * ((gth[B + Sc].norm(2, dim=1) - 1) ** 2).sum()
+            + 0.05 * out["diff_norm"][Sc].sum())
+    net.zero_grad()
+    loss.backward()
+    for n_, p in net.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n_
+    # ---- the same subset through the fp64 oracle with the depths the module used
+    sub_inp = {kk: v[S].to(D) for kk, v in inp.items()}
+    params = {kk: v.to(D).clone().requires_grad_(True) for kk, v in sd.items()}
+    dr = orc.Draws(eik_pts=eik_pts[S].to(D), nbr_off=nbr_off[S].to(D))
+    ref = orc.network_forward(params, ocfg, sub_inp, True, dr, z_override=(z_all.cpu()[S].to(D), z_eik.cpu()[S].to(D)))
+    n_s = len(S)
+    for kk, sl in (("rgb_values", S), ("depth_values", S), ("weight_sum", S), ("diff_norm", S)):
+        assert_close(out[kk].detach().cpu()[sl], ref[kk].detach(), 1e-4, kk + " (subset)")
+    assert_close(torch.cat([gth.detach().cpu()[S], gth.detach().cpu()[B + S]]), ref["grad_theta"].detach(), 1e-4, "grad_theta (subset)")
+    hs = ref["weight_sum"].detach().reshape(-1) > 1e-2
+    assert_close(out["normal_values"].detach().cpu()[S][hs], ref["normal_values"].detach()[hs], 1e-4, "normal_values (subset, weight_sum > 0.01)")
+    rth = ref["grad_theta"]
+    rloss = ((ref["rgb_values"] * w["rgb"].to(D)).sum() + (ref["depth_values"] * w["depth"].to(D)).sum()
+             + 0.3 * (ref["normal_values"] * w["nrm"].to(D)).sum()
+             + 0.1 * ((rth[:n_s].norm(2, dim=1) - 1) ** 2).sum() + 0.1 * ((rth[n_s:].norm(2, dim=1) - 1) ** 2).sum()
+             + 0.05 * ref["diff_norm"].sum())
+    assert_close(loss.detach().cpu(), rloss.detach(), 1e-5, "probe loss")
+    names = list(params)
+    rg = dict(zip(names, torch.autograd.grad(rloss, [params[kk] for kk in names], allow_unused=True)))
+    worst = 0.0
+    for n_, p in net.named_parameters():
+        r = rg[n_] if rg[n_] is not None else torch.zeros_like(params[n_])
+        if float(r.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, n_
+        else:
+            worst = max(worst, assert_close(p.grad.cpu(), r, 1e-4, "grad " + n_))
+    print(f"B={B}: sampler iterations {k}; worst relative parameter-gradient error of the subset probe vs fp64 {worst:.2e}")
+
+
+def test_eval_chunk_12000_rays():
+    """cfg 4: one split_n_pixels = 12 000 chunk of a 640x480 view (the chunk that contains the centre of the image, so the rays
+    actually hit the sphere), eval mode, the module's own sampler."""
+    net, ocfg, sd = _build(False)
+    W, H, P = 640, 480, 12000
+    lo = (H // 2) * W - P // 2                                    # pixels [lo, lo + P) of the row-major image
+    idx = torch.arange(lo, lo + P)
+    K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2], K[1, 2] = W / 2, H / 2
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
+    inp = {"uv": torch.stack([idx % W, idx // W], -1).float().reshape(1, P, 2), "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0)}
+    cinp = _cuda(inp)
+    eng = net._engine_for("cuda:0")
+    with torch.no_grad():
+        cam, dirs, dn = eng.ray_setup(cinp["uv"], cinp["pose"], cinp["intrinsics"])
+        z_all, z_eik, iters = eng.sample_rays(net._flat, cam, dirs, training=False)
+        out = net.render(cinp, cam, dirs, dn, z_all, z_eik)
+        out2 = net(cinp)
+    k = int(iters.item())
+    assert 1 <= k <= net.cfg.sampler.max_total_iters
+    _check_depths(z_all)
+    for kk in out:
+        assert out[kk].shape[0] == P and torch.isfinite(out[kk]).all(), kk
+        assert torch.equal(out[kk], out2[kk]), kk + ": forward() and sample_rays()+render() are the same launches"
+    ws = out["weight_sum"]
+    assert float(ws.min()) >= -1e-6 and float(ws.max()) <= 1.0 + 1e-5 and float(ws.max()) > 0.5, "the chunk must see the sphere"
+    S = _subset(P, 24)
+    sub = {"uv": inp["uv"][:, S].to(D), "intrinsics": inp["intrinsics"].to(D), "pose": inp["pose"].to(D)}
+    ref = orc.network_forward({kk: v.to(D) for kk, v in sd.items()}, ocfg, sub, training=False,
+                              z_override=(z_all.cpu()[S].to(D), z_eik.cpu()[S].to(D)))
+    for kk in ("rgb_values", "depth_values", "weight_sum"):
+        assert_close(out[kk].cpu()[S], ref[kk], 1e-4, kk + " (subset)")
+    hs = ref["weight_sum"].reshape(-1) > 1e-2
+    assert_close(out["normal_map"].cpu()[S][hs], ref["normal_map"][hs], 1e-4, "normal_map (subset, weight_sum > 0.01)")
+    print(f"12000-ray eval chunk: sampler iterations {k}, rays hitting (weight_sum > 0.5): {int((ws > 0.5).sum())}")

@@ -84,3 +84,42 @@ def test_render_image_equals_manual_chunk_loop_and_grid_sdf():
     pts = (torch.rand(5000, 3) * 2 - 1) * 1.5
     got = net.sdf_grid(pts.cuda(), chunk=1024)
     assert_close(got.cpu(), orc.sdf_forward(sd, ocfg.sdf, pts)[:, 0], 2e-5, "sdf_grid")
+
+
+def test_first_call_under_inference_mode_then_train():
+    """Lightning 1.9's validate/test loops run under torch.inference_mode() and may be the FIRST callers of the module (fit sanity
+    check, `implicit_network(batch)` in the mesh test step, model/eval/recon.py:89-90): the flat parameter buffer and the engine
+    built there must be ordinary tensors, and training afterwards must work."""
+    from i2sdf_amd import I2SDFLoss
+    net, ocfg, sd = _net(False)
+    inp = {k: v.cuda() for k, v in camera_inputs(40, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=9, train_layout=False).items()}
+    pts = (torch.rand(300, 3) * 2 - 1).cuda()
+    with torch.inference_mode():
+        o = net.implicit_network(pts)
+        out = net(inp)
+    assert o.shape == (300, 65) and out["rgb_values"].shape == (40, 3)
+    assert not net._flat.is_inference()
+    assert_close(o.cpu()[:, 0], orc.sdf_forward(sd, ocfg.sdf, pts.cpu())[:, 0], 2e-5, "sdf under inference_mode")
+    net.train()
+    tin = {k: v.cuda() for k, v in camera_inputs(24, (0.0, 0.2, -1.8), W=32, H=32, f=30.0, seed=10).items()}
+    gt = {k: v.cuda() for k, v in make_gt(24).items()}
+    opt = torch.optim.Adam(net.get_param_groups(1e-3), eps=1e-15)
+    w0 = net._flat.clone()
+    loss = I2SDFLoss(eikonal_weight=0.1, depth_weight=0.1, normal_weight=0.05)(net(tin), gt, 0)["loss"]
+    loss.backward()
+    opt.step()
+    assert torch.isfinite(loss) and float((net._flat - w0).abs().max()) > 0
+
+
+def test_ray_batcher_rejects_bad_indices():
+    from i2sdf_amd import RayBatcher
+    n, H, W = 2, 4, 5
+    K = torch.eye(4).repeat(n, 1, 1); pose = torch.eye(4).repeat(n, 1, 1)
+    rb = RayBatcher(K, pose, [H, W], rgb_images=torch.rand(n, H * W, 3))
+    with pytest.raises(IndexError):
+        rb.batch(torch.tensor([0, n * H * W]))                         # host indices: validated before the launch
+    with pytest.raises(IndexError):
+        rb.batch(torch.tensor([-1, 3]))
+    t_, i_, sample, gt = rb.batch(torch.tensor([0, 7, n * H * W + 5, -3], device="cuda"))   # device indices: clamped + counted
+    assert rb.bad_indices() == 2
+    assert torch.isfinite(gt["rgb"]).all() and int(i_.max()) <= n - 1 and int(i_.min()) >= 0
