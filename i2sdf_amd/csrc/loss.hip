@@ -11,6 +11,8 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 namespace {
 
 enum { S_RGB = 0, S_EIK, S_SMOOTH, S_MASK, S_DEPTH, S_DEPTH_CNT, S_NORMAL, S_NORMAL_CNT, S_BUBBLE, S_LIGHT, S_N };
+// denominators of the means: local values, or (data parallel, i2sdf_loss_cfg.exchange) their mean over the ranks
+enum { C_B = 0, C_NPC, C_DEPTH, C_NORMAL, C_N };
 constexpr int LOSS_BLOCKS = 64;
 
 struct LossArgs {
@@ -21,6 +23,7 @@ struct LossArgs {
   const uint8_t *depth_mask, *normal_mask;
   float* partial;      // (LOSS_BLOCKS, S_N)
   float* sums;         // (S_N)
+  float* cnt;          // (C_N)
   float* losses;       // (10): loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask
   float *g_rgb, *g_depth, *g_wsum, *g_normal, *g_grad_theta, *g_diff_norm, *g_surface, *g_lmask;
 };
@@ -74,25 +77,32 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
   if (threadIdx.x < S_N) a.partial[blockIdx.x * S_N + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
-__global__ void loss_finalize_kernel(LossArgs a, int nblocks) {
-  __shared__ float tot[S_N];
+// stage 1 of the finalisation: block partials -> sums, and the local denominators
+__global__ void loss_sums_kernel(LossArgs a, int nblocks) {
   if (threadIdx.x < S_N) {
     float v = 0.f;
     for (int b = 0; b < nblocks; ++b) v += a.partial[b * S_N + threadIdx.x];
-    tot[threadIdx.x] = v;
     a.sums[threadIdx.x] = v;
+    if (threadIdx.x == S_DEPTH_CNT) a.cnt[C_DEPTH] = v;
+    if (threadIdx.x == S_NORMAL_CNT) a.cnt[C_NORMAL] = v;
   }
+  if (threadIdx.x == 0) { a.cnt[C_B] = (float)a.B; a.cnt[C_NPC] = (float)a.n_pc; }
+}
+
+__global__ void loss_finalize_kernel(LossArgs a) {
+  __shared__ float tot[S_N];
+  if (threadIdx.x < S_N) tot[threadIdx.x] = a.sums[threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float B = (float)a.B;
+    const float B = a.cnt[C_B];
     const float rgb = tot[S_RGB] / (3.0f * B);
     const float eik = a.grad_theta ? tot[S_EIK] / (2.0f * B) : 0.f;
     const float smooth = (a.diff_norm && a.c.smooth_on && a.c.smooth_w > 0.f) ? tot[S_SMOOTH] / B : 0.f;
     const float mask = (a.gt_mask && a.c.mask_w > 0.f) ? tot[S_MASK] / B : 0.f;
-    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / tot[S_DEPTH_CNT] : 0.f;
-    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / tot[S_NORMAL_CNT] : 0.f;
+    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / a.cnt[C_DEPTH] : 0.f;
+    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / a.cnt[C_NORMAL] : 0.f;
     const float normal = a.c.normal_w > 0.f ? nl1 : 0.f, angular = a.c.angular_w > 0.f ? nl1 : 0.f;
-    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / (float)a.n_pc : 0.f;
+    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / a.cnt[C_NPC] : 0.f;
     const float light = (a.lmask && a.gt_lmask && a.c.light_w > 0.f) ? tot[S_LIGHT] / B : 0.f;
     a.losses[0] = rgb + a.c.eikonal_w * eik + a.c.smooth_w * smooth + a.c.mask_w * mask + a.c.depth_w * depth + a.c.normal_w * normal +
                   a.c.angular_w * angular + a.c.bubble_w * bubble + a.c.light_w * light;
@@ -103,7 +113,7 @@ __global__ void loss_finalize_kernel(LossArgs a, int nblocks) {
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const float B = (float)a.B;
+  const float B = a.cnt[C_B];
   if (i < a.B) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -111,7 +121,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
       a.g_rgb[i * 3 + k] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (3.0f * B);
     }
     float gd = 0.f;
-    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / a.sums[S_DEPTH_CNT];
+    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / a.cnt[C_DEPTH];
     a.g_depth[i] = gd;
     float gw = 0.f;
     if (a.gt_mask && a.c.mask_w > 0.f) { float d; (void)bce(a.wsum[i], a.gt_mask[i], d); gw = a.c.mask_w * d / B; }
@@ -119,7 +129,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
     if (a.g_normal) {
       float g0 = 0.f, g1 = 0.f, g2 = 0.f;
       if (a.gt_normal && a.normal && a.normal_mask[i]) {
-        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / a.sums[S_NORMAL_CNT];
+        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / a.cnt[C_NORMAL];
         const float n0 = a.gt_normal[i * 3], n1 = a.gt_normal[i * 3 + 1], n2 = a.gt_normal[i * 3 + 2];
         const float u = 1.0f - (a.normal[i * 3] * n0 + a.normal[i * 3 + 1] * n1 + a.normal[i * 3 + 2] * n2);
         const float sg = u > 0.f ? -1.f : (u < 0.f ? 1.f : 0.f);          // d|1-dot| / d dot
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
   }
   if (a.g_surface && i < a.n_pc) {
     const float sv = a.surface[i];
-    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / (float)a.n_pc : 0.f;
+    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / a.cnt[C_NPC] : 0.f;
   }
 }
 
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256) void eik_out_bwd_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N; }
+extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N + C_N + 2; }
 
 extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_pc, const float* rgb, const float* depth,
                                            const float* wsum, const float* normal, const float* grad_theta, const float* diff_norm,
@@ -237,14 +247,20 @@ extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B,
   a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.normal = normal; a.grad_theta = grad_theta; a.diff_norm = diff_norm; a.surface = surface;
   a.lmask = lmask; a.gt_rgb = gt_rgb; a.gt_depth = gt_depth; a.gt_normal = gt_normal; a.gt_mask = gt_mask; a.gt_lmask = gt_lmask;
   a.depth_mask = depth_mask; a.normal_mask = normal_mask;
-  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.losses = losses;
+  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.cnt = a.sums + S_N; a.losses = losses;
   a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_wsum = g_wsum; a.g_normal = g_normal; a.g_grad_theta = g_grad_theta; a.g_diff_norm = g_diff_norm;
   a.g_surface = g_surface; a.g_lmask = g_lmask;
   hipStream_t st = (hipStream_t)stream;
   const int64_t work = std::max<int64_t>(2 * B, a.n_pc);
   const int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (work + 255) / 256);
   loss_partial_kernel<<<nb, 256, 0, st>>>(a);
-  loss_finalize_kernel<<<1, 64, 0, st>>>(a, nb);
+  loss_sums_kernel<<<1, 64, 0, st>>>(a, nb);
+  if (cfg->exchange) {       // data parallel: denominators -> their mean over the ranks (global count / world)
+    if (!cfg->exchange->allreduce) return I2SDF_EINVAL;
+    const int rc = cfg->exchange->allreduce(cfg->exchange->ctx, a.cnt, C_N, I2SDF_XCHG_F32, I2SDF_XCHG_AVG, stream);
+    if (rc) return rc;
+  }
+  loss_finalize_kernel<<<1, 64, 0, st>>>(a);
   loss_grad_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(a);
   return i2sdf_hip_check(hipGetLastError(), "loss_forward_backward launch");
 }

@@ -16,19 +16,20 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, float beta1, float beta2, float eps, float wd,
-                                      float step_size, float bc2_sqrt, float gscale) {
-  g *= gscale;
+struct AdamC { float omb1, beta2, omb2, eps, wd, step_size, bc2_sqrt, gscale; };
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamC& c) {
+  const float eps = c.eps, wd = c.wd, step_size = c.step_size, bc2_sqrt = c.bc2_sqrt;
+  g *= c.gscale;
   if (wd != 0.f) g = fmaf(wd, p, g);
-  m = m + (1.0f - beta1) * (g - m);
-  v = beta2 * v + (1.0f - beta2) * g * g;
+  m = m + c.omb1 * (g - m);
+  v = c.beta2 * v + c.omb2 * g * g;
   const float den = sqrtf(v) / bc2_sqrt + eps;
   p = p - step_size * (m / den);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                    float* __restrict__ v, int64_t n, float beta1, float beta2, float eps, float wd,
-                                                    float step_size, float bc2_sqrt, float gscale, int vec_ok) {
+                                                    float* __restrict__ v, int64_t n, AdamC c, int vec_ok) {
   const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;
   if (vec_ok && i + 4 <= n) {
@@ -37,26 +38,28 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float pk = pp[k], mk = mm[k], vk = vv[k];
-      adam1(pk, gg[k], mk, vk, beta1, beta2, eps, wd, step_size, bc2_sqrt, gscale);
+      adam1(pk, gg[k], mk, vk, c);
       pp[k] = pk; mm[k] = mk; vv[k] = vk;
     }
     *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
   } else {
-    for (int64_t j = i; j < n && j < i + 4; ++j) adam1(p[j], g[j], m[j], v[j], beta1, beta2, eps, wd, step_size, bc2_sqrt, gscale);
+    for (int64_t j = i; j < n && j < i + 4; ++j) adam1(p[j], g[j], m[j], v[j], c);
   }
 }
 
 }  // namespace
 
-extern "C" int i2sdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream) {
+extern "C" int i2sdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                               double beta2, double eps, double weight_decay, int64_t step, double grad_scale, void* stream) {
   if (n == 0) return I2SDF_OK;
   if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return I2SDF_EINVAL;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-  const float step_size = (float)((double)lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+  // hyper-parameters arrive as doubles and every derived constant is formed in double, then rounded once -- as torch does with its
+  // Python floats (1 - beta2 formed in fp32 would be off by 5e-5 relative)
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const AdamC c{(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, (float)weight_decay, (float)(lr / bc1), (float)sqrt(bc2),
+                (float)grad_scale};
   const int vec_ok = (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
   const unsigned grid = (unsigned)((n + 1023) / 1024);
-  adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt,
-                                                     grad_scale, vec_ok);
+  adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(params, grads, exp_avg, exp_avg_sq, n, c, vec_ok);
   return i2sdf_hip_check(hipGetLastError(), "adam_step launch");
 }

@@ -23,6 +23,7 @@ extern "C" const char* i2sdf_strerror(int code) {
     case I2SDF_EHIP: return "HIP runtime error";
     case I2SDF_ESPHERE: return "ray misses the scene bounding sphere";
     case I2SDF_EWORKSPACE: return "workspace too small";
+    case I2SDF_ECOMM: return "RCCL error";
     default: return "unknown error";
   }
 }
@@ -376,6 +377,13 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     return I2SDF_OK;
   }
   return I2SDF_EINVAL;
+}
+
+extern "C" int i2sdf_plan_set_exchange(i2sdf_plan* p, const i2sdf_exchange* ex, int32_t flags) {
+  if (!p || (flags & ~I2SDF_DP_GLOBAL_SAMPLER) || (ex && !ex->allreduce)) return I2SDF_EINVAL;
+  p->exchange = ex ? *ex : i2sdf_exchange{nullptr, nullptr};
+  p->dp_flags = ex ? flags : 0;
+  return I2SDF_OK;
 }
 
 extern "C" int64_t i2sdf_plan_pack_floats(const i2sdf_plan* p) {

@@ -69,6 +69,8 @@ struct i2sdf_plan {
   int32_t train_fwd_bf16x3 = 0;      // I2SDF_OPT_TRAIN_FWD_BF16X3: SDF forward + d sdf/dx kernel in bf16x3 split arithmetic
   int32_t wgrad_bf16x3 = 0;          // I2SDF_OPT_WGRAD_BF16X3: full 256x256 weight-gradient blocks in bf16x3 split arithmetic
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
+  i2sdf_exchange exchange{nullptr, nullptr};   // i2sdf_plan_set_exchange: small data-parallel exchanges (copied)
+  int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
   int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones
   // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
   mutable hipStream_t side = nullptr;

@@ -448,11 +448,17 @@ __global__ __launch_bounds__(256) void error_bound_kernel(int64_t B, int n, cons
 }
 
 template <int E>
-void launch_iter(const SamplerArgs& a, hipStream_t st) {
+int launch_iter(const SamplerArgs& a, hipStream_t st, const i2sdf_exchange* ex) {
   const unsigned grid = (unsigned)((a.B + 3) / 4);
   sampler_beta_kernel<E><<<grid, 256, 0, st>>>(a);
+  // 1-GPU-equivalent data parallelism: `beta.max() > beta0` (ray_sampler.py:151) over the rays of ALL ranks
+  if (ex) {
+    const int rc = ex->allreduce(ex->ctx, a.state + ST_FLAG0 + a.it, 1, I2SDF_XCHG_I32, I2SDF_XCHG_MAX, (void*)st);
+    if (rc) return rc;
+  }
   sampler_resample_kernel<E><<<grid, 256, 0, st>>>(a);
   sampler_mark_kernel<<<1, 1, 0, st>>>(a.state, a.it, a.max_iters, a.force_iters);
+  return I2SDF_OK;
 }
 
 }  // namespace
@@ -514,6 +520,7 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
   int* state = (int*)w;
   const float near = sc->near, far = 2.0f * p->desc.scene_bounding_sphere;
   const unsigned grid = (unsigned)((B + 3) / 4);
+  const i2sdf_exchange* gcomm = (p->exchange.allreduce && (p->dp_flags & I2SDF_DP_GLOBAL_SAMPLER) && force_iters <= 0) ? &p->exchange : nullptr;
   sampler_init_kernel<<<grid, 256, 0, st>>>(B, sc->N_samples_eval, t_lin, training ? strat_u : nullptr, near, far, sc->eps, zA, samples, beta, state);
   // With a fixed iteration count the host knows where the loop ends; otherwise every iteration is enqueued and the ones after
   // convergence return immediately (device flag, no host synchronisation).
@@ -536,18 +543,20 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
     a.sdf_new = sdf_new; a.samples = samples; a.beta = beta;
     a.u_more = u_more; a.u_final = u_final; a.ldu_final = ldu_final;
     const int E = cdiv(a.n, 64);
+    int xrc = I2SDF_OK;
     switch (E) {
-      case 1: launch_iter<1>(a, st); break;
-      case 2: launch_iter<2>(a, st); break;
-      case 3: launch_iter<3>(a, st); break;
-      case 4: launch_iter<4>(a, st); break;
-      case 5: launch_iter<5>(a, st); break;
-      case 6: launch_iter<6>(a, st); break;
-      case 7: launch_iter<7>(a, st); break;
-      case 8: launch_iter<8>(a, st); break;
-      case 9: launch_iter<9>(a, st); break;
-      default: launch_iter<10>(a, st); break;
+      case 1: xrc = launch_iter<1>(a, st, gcomm); break;
+      case 2: xrc = launch_iter<2>(a, st, gcomm); break;
+      case 3: xrc = launch_iter<3>(a, st, gcomm); break;
+      case 4: xrc = launch_iter<4>(a, st, gcomm); break;
+      case 5: xrc = launch_iter<5>(a, st, gcomm); break;
+      case 6: xrc = launch_iter<6>(a, st, gcomm); break;
+      case 7: xrc = launch_iter<7>(a, st, gcomm); break;
+      case 8: xrc = launch_iter<8>(a, st, gcomm); break;
+      case 9: xrc = launch_iter<9>(a, st, gcomm); break;
+      default: xrc = launch_iter<10>(a, st, gcomm); break;
     }
+    if (xrc) return xrc;
   }
   sampler_final_kernel<<<grid, 256, 0, st>>>(B, state, sc->N_samples_eval, zA, zB, samples, sc->N_samples, sc->N_samples_extra,
                                              training ? (const int*)extra_idx : nullptr, (const int*)extra_tab, near, far, (const int*)eik_idx, z_out, ldz,

@@ -1,30 +1,174 @@
 """Data parallelism for the render core: one process per GPU, rays sharded, ONE collective per training step.
 
-The reference has no distributed code at all.  Rays are independent, so the only
-exchange step of the path is the parameter-gradient sum: the backward writes every gradient into one flat fp32 buffer
-(800 955 floats = 3.2 MB at synthetic.yml shapes) and this module all-reduces that buffer once -- RCCL over xGMI on
-MI355X (`backend="nccl"` is RCCL on ROCm), gloo on CPU for the tests.  Inference shards the pixel list; results are
-concatenated (no collective on the data path)."""
+The reference has no distributed code at all (main_recon.py:111-112 `strategy=None`).  Rays are
+independent, so the only exchange step of the path is the parameter-gradient mean: the backward writes every gradient into one
+flat fp32 buffer (800 955 floats = 3.2 MB at synthetic.yml shapes) and that buffer is all-reduced once -- by the library's own
+RCCL communicator (`i2sdf_allreduce_grads`, include/i2sdf.h) when the process group's backend is nccl (= RCCL on ROCm), through
+torch.distributed otherwise (gloo: CPU tests, or several ranks sharing one GPU).  Inference shards the pixel list; results are
+concatenated (no collective on the data path).
+
+`equivalent=True` additionally makes a sharded training step EQUAL to the single-GPU step on the concatenated batch (SURVEY.md
+8e): the sampler's batch-global convergence OR (ray_sampler.py:151) is reduced over all ranks on the device, the 32 extra
+`randperm` columns are shared (ray_sampler.py:223: one draw for all rays of a batch), and the loss uses global denominators for
+its (masked) means (model/network/__init__.py:320-336).  Throughput runs leave it off: per-rank flags, no extra exchanges."""
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+import contextlib
+import ctypes as C
+from typing import Dict, Tuple
 
 import torch
 import torch.distributed as dist
 
+from . import lib as L
 
-def attach_data_parallel(net, group=None):
-    """Make `net` (i2sdf_amd.I2SDFNetwork) average its flat gradient over the process group inside backward."""
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the library's RCCL communicator
+# ---------------------------------------------------------------------------------------------------------------------
+class RcclComm:
+    """`i2sdf_comm` of the C ABI: created collectively by all ranks of `group`; the 128-byte unique id travels through the
+    torch.distributed group (any backend).  The calling thread's current device must be this rank's GPU."""
+
+    def __init__(self, group=None):
+        self._lib = L.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        box = [None]
+        if self.rank == 0:
+            buf = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES)()
+            L.check(self._lib.i2sdf_comm_unique_id(buf, L.COMM_UNIQUE_ID_BYTES), "i2sdf_comm_unique_id")
+            box[0] = bytes(buf)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        dist.broadcast_object_list(box, src=src, group=group)
+        uid = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES).from_buffer_copy(box[0])
+        h = C.c_void_p()
+        L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
+        self._h = h
+        self._ex = L.Exchange()
+        L.check(self._lib.i2sdf_comm_as_exchange(self._h, C.byref(self._ex)), "i2sdf_comm_as_exchange")
+
+    def allreduce_mean(self, flat: torch.Tensor):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        with torch.cuda.device(flat.device):
+            L.check(self._lib.i2sdf_allreduce_grads(L.ptr(flat), flat.numel(), self._h, L.stream_ptr()), "i2sdf_allreduce_grads")
+
+    def broadcast(self, t: torch.Tensor, root: int = 0):
+        assert t.is_cuda and t.is_contiguous()
+        with torch.cuda.device(t.device):
+            L.check(self._lib.i2sdf_broadcast(L.ptr(t), t.numel() * t.element_size(), root, self._h, L.stream_ptr()), "i2sdf_broadcast")
+
+    def exchange(self) -> L.Exchange:
+        return self._ex
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.i2sdf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _DevView:
+    """A raw device pointer as a torch tensor (torch.as_tensor understands __cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TorchExchange:
+    """The `i2sdf_exchange` hook routed through torch.distributed (any backend): what the gloo tests and ranks that share one GPU
+    use for the small exchanges of `equivalent` mode.  Runs on torch's current stream -- the stream the entry points are given."""
+
+    def __init__(self, group=None):
+        self.group, self.world = group, dist.get_world_size(group)
+        self.calls = 0
+
+        def cb(ctx, buf, n, dtype, op, stream):
+            try:
+                t = torch.as_tensor(_DevView(buf, n, "<i4" if dtype == L.XCHG_I32 else "<f4"), device="cuda")
+                if op == L.XCHG_MAX:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+                    if op == L.XCHG_AVG:
+                        t.div_(self.world)
+                self.calls += 1
+                return 0
+            except Exception:      # never let an exception cross the C boundary
+                return -5
+
+        self._cb = L.EXCHANGE_FN(cb)              # keep the trampoline alive as long as the hook is installed
+        self._ex = L.Exchange(self._cb, None)
+
+    def exchange(self) -> L.Exchange:
+        return self._ex
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# module-level wiring
+# ---------------------------------------------------------------------------------------------------------------------
+class DataParallelState:
+    def __init__(self, group, world, comm, xchg, equivalent):
+        self.group, self.world, self.comm, self.xchg, self.equivalent = group, world, comm, xchg, equivalent
+        self.enabled = True
+
+
+def attach_data_parallel(net, group=None, equivalent: bool = False, native=None):
+    """Make `net` (i2sdf_amd.I2SDFNetwork) average its flat gradient over the process group inside backward.
+
+    native: use the library's own RCCL communicator for the collectives (default: when the group's backend is nccl); otherwise
+    torch.distributed carries them.  Do not ALSO wrap the module in torch DistributedDataParallel / a Lightning DDP strategy:
+    the gradients would be reduced twice -- this hook IS the data-parallel strategy of the module.  Under
+    gradient accumulation use `with no_sync(net):` for all but the last micro-batch, as with DDP."""
     world = dist.get_world_size(group)
+    if native is None:
+        native = dist.get_backend(group) == "nccl"
+    comm = RcclComm(group) if native else None
+    xchg = None
+    if equivalent:
+        xchg = comm if comm is not None else TorchExchange(group)
+    state = DataParallelState(group, world, comm, xchg, equivalent)
 
     def sync(flat_grad: torch.Tensor):
         # always through the collective once attached (a 1-rank group is a no-op for RCCL): the N=1 and N>1 code paths are the same
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
-        if world > 1:
-            flat_grad.mul_(1.0 / world)
+        if not state.enabled:
+            return
+        if comm is not None:
+            comm.allreduce_mean(flat_grad)
+        else:
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+            if world > 1:
+                flat_grad.mul_(1.0 / world)
 
     net.grad_sync = sync
+    net.dp_state = state
     return net
+
+
+@contextlib.contextmanager
+def no_sync(net):
+    """Skip the gradient all-reduce inside the block (gradient accumulation: all micro-batches but the last)."""
+    st = getattr(net, "dp_state", None)
+    if st is None:
+        yield
+        return
+    old, st.enabled = st.enabled, False
+    try:
+        yield
+    finally:
+        st.enabled = old
+
+
+def attach_loss(loss_fn, net):
+    """`equivalent` mode: the loss of this rank uses the global denominators (count-weighted masked means)."""
+    st = getattr(net, "dp_state", None)
+    loss_fn.exchange = st.xchg.exchange() if (st is not None and st.equivalent) else None
+    loss_fn._exchange_owner = st.xchg if st is not None else None
+    return loss_fn
 
 
 def broadcast_parameters(net, src: int = 0, group=None):
@@ -70,8 +214,8 @@ def gather_outputs(outputs: Dict[str, torch.Tensor], total: int, group=None) -> 
 
 
 def global_any(flag: torch.Tensor, group=None) -> torch.Tensor:
-    """MAX-reduce a small flag tensor (e.g. the sampler's `not converged`) when bit-identical 1-GPU-equivalent
-    sampling across shards is wanted; throughput runs use per-rank flags instead."""
+    """MAX-reduce a small flag tensor on the host side of the ABI (kept for callers that run their own loop; the module's
+    sampler uses the device-side exchange hook instead)."""
     if dist.get_world_size(group) > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     return flag

@@ -137,6 +137,12 @@ class RenderEngine:
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TAIL_OVERLAP, int(bool(on))), "i2sdf_plan_set_option")
         self.tail_overlap = bool(on)
 
+    def set_exchange(self, ex, flags: int = 0):
+        """Install (or with ex=None remove) the data-parallel exchange hook of the plan (include/i2sdf.h: i2sdf_plan_set_exchange);
+        flags: lib.DP_GLOBAL_SAMPLER = the sampler's convergence test is the OR over all ranks' rays."""
+        self._exchange = ex                       # keep the struct (and through it the callback) alive
+        L.check(self._lib.i2sdf_plan_set_exchange(self._plan, C.byref(ex) if ex is not None else None, int(flags)), "i2sdf_plan_set_exchange")
+
     def set_wgrad_bf16x3(self, on: bool):
         """Full 256x256 weight-gradient blocks in bf16x3 split arithmetic (I2SDF_OPT_WGRAD_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_WGRAD_BF16X3, int(bool(on))), "i2sdf_plan_set_option")

@@ -33,9 +33,23 @@ class SamplerCfg(C.Structure):
                 ("N_samples_extra", C.c_int32), ("beta_iters", C.c_int32), ("max_total_iters", C.c_int32)]
 
 
+# int allreduce(void* ctx, void* buf, int64_t n, int32_t dtype, int32_t op, void* stream)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+
+
+class Exchange(C.Structure):
+    _fields_ = [("allreduce", EXCHANGE_FN), ("ctx", C.c_void_p)]
+
+
 class LossCfg(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("eikonal_w", "smooth_w", "mask_w", "depth_w", "normal_w", "angular_w", "bubble_w", "light_w")] + \
-               [("smooth_on", C.c_int32)]
+               [("smooth_on", C.c_int32), ("reserved", C.c_int32), ("exchange", C.POINTER(Exchange))]
+
+
+XCHG_F32, XCHG_I32 = 0, 1
+XCHG_SUM, XCHG_AVG, XCHG_MAX = 0, 1, 2
+DP_GLOBAL_SAMPLER = 1
+COMM_UNIQUE_ID_BYTES = 128
 
 
 class RayTables(C.Structure):
@@ -64,7 +78,7 @@ class I2SDFError(RuntimeError):
 _lib = None
 
 # name -> (restype, argtypes).  Must list every symbol include/i2sdf.h declares (tests/test_cabi.py checks it).
-_P, _I64, _I32, _F = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+_P, _I64, _I32, _F, _D = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double
 SIGNATURES = {
     "i2sdf_version": (C.c_int, []),
     "i2sdf_strerror": (C.c_char_p, [C.c_int]),
@@ -87,7 +101,18 @@ SIGNATURES = {
     "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
     "i2sdf_wgrad_chunk_points": (_I64, []),
     "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
-    "i2sdf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I64, _F, _P]),
+    "i2sdf_comm_unique_id": (C.c_int, [_P, _I64]),
+    "i2sdf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
+    "i2sdf_comm_destroy": (None, [_P]),
+    "i2sdf_comm_size": (_I32, [_P]),
+    "i2sdf_comm_rank": (_I32, [_P]),
+    "i2sdf_last_comm_error": (C.c_char_p, []),
+    "i2sdf_allreduce_grads": (C.c_int, [_P, _I64, _P, _P]),
+    "i2sdf_allreduce_max_i32": (C.c_int, [_P, _I64, _P, _P]),
+    "i2sdf_broadcast": (C.c_int, [_P, _I64, _I32, _P, _P]),
+    "i2sdf_comm_as_exchange": (C.c_int, [_P, C.POINTER(Exchange)]),
+    "i2sdf_plan_set_exchange": (C.c_int, [_P, C.POINTER(Exchange), _I32]),
+    "i2sdf_adam_step": (C.c_int, [_P, _P, _P, _P, _I64, _D, _D, _D, _D, _D, _I64, _D, _P]),
     "i2sdf_error_bound": (C.c_int, [_P, _P, _I64, _I32, _P, _I64, _P, _P, _P, _P]),
     "i2sdf_sampler_workspace_floats": (_I64, [_I64]),
     # plan, packed, params, cfg, cam, dirs, B, training, t_lin, u_more, u_final, ldu_final, extra_tab, strat_u, extra_idx, eik_idx,
@@ -134,6 +159,8 @@ def check(rc: int, what: str = ""):
         msg = lib.i2sdf_strerror(rc).decode()
         if rc == -2:
             msg += ": " + lib.i2sdf_last_hip_error().decode()
+        if rc == -5:
+            msg += ": " + lib.i2sdf_last_comm_error().decode()
         raise I2SDFError(f"{what} failed ({rc}): {msg}")
 
 

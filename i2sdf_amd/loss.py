@@ -64,6 +64,7 @@ class I2SDFLoss(nn.Module):
         if self.bubble_weight > 0 and self.max_bubble_iter is not None and self.smooth_iter < self.max_bubble_iter:
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
+        self.exchange = None       # i2sdf_amd.dist.attach_loss: lib.Exchange hook -> global denominators (1-GPU-equivalent data parallelism)
 
     def _forward_fused(self, out, gt, current_step):
         from . import lib as L
@@ -71,6 +72,9 @@ class I2SDFLoss(nn.Module):
         cfg = L.LossCfg(eikonal_w=self.eikonal_weight, smooth_w=self.smooth_weight, mask_w=self.mask_weight, depth_w=self.depth_weight,
                         normal_w=self.normal_weight, angular_w=self.angular_weight, bubble_w=self.bubble_weight,
                         light_w=self.light_mask_weight, smooth_on=1 if smooth_on else 0)
+        import ctypes as C_
+        if self.exchange is not None:
+            cfg.exchange = C_.pointer(self.exchange)
         surf = out.get("surface_sdf")
         gtc = dict(gt)
         if not ("depth" in gt and self.depth_weight > 0):

@@ -213,7 +213,9 @@ class I2SDFNetwork(nn.Module):
         self.layout = ParamLayout(cfg)
         self.force_iters = 0            # >0: fixed sampler iteration count (benchmarks); 0: the reference's data-dependent loop
         self.grad_sync = None           # callable(flat_grad) for data-parallel training (i2sdf_amd.dist)
+        self.dp_state = None            # i2sdf_amd.dist.DataParallelState once attach_data_parallel() was called
         self.last_sampler_iters = None  # device int32 tensor of the last forward
+        self.last_extra_idx = None
         object.__setattr__(self, "_engines", {})
         object.__setattr__(self, "_flat", None)
         object.__setattr__(self, "_packed", set())
@@ -314,9 +316,24 @@ class I2SDFNetwork(nn.Module):
                     extra = keys.topk(sc.N_samples_extra, dim=1, largest=False).indices
                 elif extra is not None and extra.dim() == 1:
                     extra = extra.repeat(sc.max_total_iters, 1)
+                dp = self.dp_state
+                if dp is not None and dp.equivalent:
+                    # 1-GPU-equivalent data parallelism: the reference draws ONE randperm for all rays of a batch (ray_sampler.py:223),
+                    # so every rank must use rank 0's columns; and the convergence test is the OR over all ranks (device-side hook)
+                    if "extra_idx" not in draws and extra is not None:
+                        extra = extra.contiguous()
+                        if dp.comm is not None:
+                            dp.comm.broadcast(extra, 0)
+                        else:
+                            import torch.distributed as tdist
+                            tdist.broadcast(extra, src=tdist.get_global_rank(dp.group, 0) if dp.group is not None else 0, group=dp.group)
+                    if getattr(eng, "_exchange", None) is None:
+                        from . import lib as L_
+                        eng.set_exchange(dp.xchg.exchange(), L_.DP_GLOBAL_SAMPLER)
                 eik_idx = draws.get("eik_idx")
                 if eik_idx is None:
                     eik_idx = torch.randint(eng.n_z, (N,), device=dev)
+                self.last_extra_idx = extra          # (max_total_iters, N_extra) columns this forward used (shared by all rays / ranks)
                 z_all, z_eik, iters = eng.sample_rays(flat, cam, dirs, training=True, strat_u=strat_u, cdf_u=cdf_u, extra_idx=extra,
                                                       eik_idx=eik_idx, force_iters=self.force_iters)
             else:

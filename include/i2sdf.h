@@ -33,6 +33,7 @@ extern "C" {
 #define I2SDF_EHIP (-2)            /* HIP runtime error (see i2sdf_last_hip_error) */
 #define I2SDF_ESPHERE (-3)         /* ray does not hit the bounding sphere (rend_util.py:220 `exit()`) */
 #define I2SDF_EWORKSPACE (-4)      /* caller workspace too small */
+#define I2SDF_ECOMM (-5)           /* RCCL error or RCCL unavailable, see i2sdf_last_comm_error() */
 
 /* ------------------------------------------------------------------------------------------------
  * Network description.  Parameters live in ONE flat fp32 device buffer (`params`), laid out exactly in
@@ -280,13 +281,56 @@ int i2sdf_weight_grads(const i2sdf_plan* plan, const i2sdf_train_buffers* bufs, 
 
 
 /* ------------------------------------------------------------------------------------------------
+ * Data parallelism (the reference itself is single-GPU: main_recon.py:111-112).  One process per GPU; rays
+ * are sharded, parameters replicated, and the only exchange of a training step is the parameter-gradient mean over the flat
+ * buffer -- RCCL over xGMI.  RCCL is bound at run time (librccl.so.1); without it these calls return I2SDF_ECOMM.
+ *   i2sdf_comm_unique_id : rank 0 makes the 128-byte id, the caller distributes it (any side channel)
+ *   i2sdf_comm_init_rank : collective over all ranks; the calling thread's current HIP device is the rank's GPU
+ *   i2sdf_allreduce_grads: in place, stream ordered, every rank ends with the MEAN over ranks (DDP convention)
+ *   i2sdf_allreduce_max_i32 / i2sdf_broadcast: the small exchanges of 1-GPU-equivalent mode (below)
+ * 1-GPU-equivalent mode: besides the gradient mean, a sharded step needs two SMALL exchanges to equal the single-GPU step on
+ * the concatenated batch.  They go through an `i2sdf_exchange` hook (an in-place all-reduce of a few device words, enqueued on
+ * the stream, never synchronising the host): i2sdf_comm_as_exchange() gives the RCCL implementation; a caller may supply its
+ * own (i2sdf_amd/dist.py routes it through torch.distributed for gloo tests).
+ *   i2sdf_plan_set_exchange(plan, ex, I2SDF_DP_GLOBAL_SAMPLER): the sampler's convergence test becomes the batch-global OR over
+ *     ALL ranks' rays (ray_sampler.py:151: while any ray of the batch is unconverged every ray is up-sampled) -- one 4-byte MAX
+ *     all-reduce per iteration;
+ *   i2sdf_loss_cfg.exchange: every loss denominator (B, n_pc, masked-mean counts, model/network/__init__.py:320-336) becomes its
+ *     mean over the ranks, so that the mean over ranks of the per-rank gradients is the gradient on the concatenated batch.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct i2sdf_comm i2sdf_comm;
+#define I2SDF_COMM_UNIQUE_ID_BYTES 128
+#define I2SDF_DP_GLOBAL_SAMPLER 1
+#define I2SDF_XCHG_F32 0
+#define I2SDF_XCHG_I32 1
+#define I2SDF_XCHG_SUM 0
+#define I2SDF_XCHG_AVG 1
+#define I2SDF_XCHG_MAX 2
+typedef struct i2sdf_exchange {
+  /* in-place all-reduce of n elements at device pointer buf, ordered on `stream`; returns 0 or a negative error code */
+  int (*allreduce)(void* ctx, void* buf, int64_t n, int32_t dtype, int32_t op, void* stream);
+  void* ctx;
+} i2sdf_exchange;
+int i2sdf_comm_unique_id(void* out, int64_t out_bytes);
+int i2sdf_comm_init_rank(const void* unique_id, int32_t nranks, int32_t rank, i2sdf_comm** out);
+void i2sdf_comm_destroy(i2sdf_comm* comm);
+int32_t i2sdf_comm_size(const i2sdf_comm* comm);
+int32_t i2sdf_comm_rank(const i2sdf_comm* comm);
+const char* i2sdf_last_comm_error(void);
+int i2sdf_allreduce_grads(float* flat, int64_t n, const i2sdf_comm* comm, void* stream);
+int i2sdf_allreduce_max_i32(int32_t* flags, int64_t n, const i2sdf_comm* comm, void* stream);
+int i2sdf_broadcast(void* buf, int64_t bytes, int32_t root, const i2sdf_comm* comm, void* stream);
+int i2sdf_comm_as_exchange(const i2sdf_comm* comm, i2sdf_exchange* out);
+int i2sdf_plan_set_exchange(i2sdf_plan* plan, const i2sdf_exchange* ex, int32_t flags);   /* ex = NULL detaches; *ex is copied */
+
+/* ------------------------------------------------------------------------------------------------
  * Optimizer step over the flat parameter buffer -- torch.optim.Adam(model.get_param_groups(lr), eps=1e-15) of
  * model/trainer/recon.py:201-203 (same update rule and operation order, bias corrections in double on the host) as ONE
  * launch.  step = 1 for the first update.  grad_scale multiplies the gradient first (1/world for a summed all-reduce).
  *   params, grads, exp_avg, exp_avg_sq: (n) fp32, updated in place (grads is read-only)
  * ---------------------------------------------------------------------------------------------- */
-int i2sdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                    float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+int i2sdf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, int64_t step, double grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Error-bounded ray sampler -- ErrorBoundSampler.get_z_vals incl. UniformSampler and get_error_bound
@@ -348,6 +392,9 @@ int i2sdf_light_backward(const i2sdf_plan* plan, const float* packed, const floa
 typedef struct i2sdf_loss_cfg {
   float eikonal_w, smooth_w, mask_w, depth_w, normal_w, angular_w, bubble_w, light_w;
   int32_t smooth_on;
+  int32_t reserved;
+  const i2sdf_exchange* exchange;  /* NULL, or: every denominator (B, n_pc, mask counts) becomes its mean over the ranks, so that the
+                                      mean over ranks of the per-rank gradients is the gradient on the concatenated batch */
 } i2sdf_loss_cfg;
 
 int64_t i2sdf_loss_scratch_floats(void);

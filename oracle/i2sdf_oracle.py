@@ -343,7 +343,7 @@ def get_camera_params(uv: Tensor, pose: Tensor, intrinsics: Tensor) -> Tuple[Ten
     """uv (B,P,2), pose (B,4,4) cam->world or (B,7) [quaternion, translation], K (B,4,4)
     -> un-normalised ray dirs (B,P,3), cam_loc (B,3).  utils/rend_util.py:92-120."""
     if pose.dim() == 2 and pose.shape[1] == 7:                 # rend_util.py:93-98
-        p = torch.eye(4, dtype=pose.dtype).repeat(pose.shape[0], 1, 1)
+        p = torch.eye(4, dtype=pose.dtype, device=pose.device).repeat(pose.shape[0], 1, 1)
         p[:, :3, :3] = quat_to_rot(pose[:, :4])
         p[:, :3, 3] = pose[:, 4:]
         pose = p
@@ -405,7 +405,7 @@ def get_sphere_intersections(cam_loc: Tensor, dirs: Tensor, r: float) -> Tensor:
     under = dot ** 2 - (cam_loc.norm(2, 1, keepdim=True) ** 2 - r ** 2)
     if (under <= 0).any():
         raise ValueError("BOUNDING SPHERE PROBLEM")
-    t = torch.sqrt(under) * torch.tensor([-1.0, 1.0], dtype=dirs.dtype) - dot
+    t = torch.sqrt(under) * torch.tensor([-1.0, 1.0], dtype=dirs.dtype, device=dirs.device) - dot
     return t.clamp_min(0.0)
 
 
@@ -430,10 +430,10 @@ class Draws:
     nbr_off: Optional[Tensor] = None
 
 
-def uniform_z_vals(n_rays: int, cfg: NetCfg, training: bool, strat_u: Optional[Tensor], dtype) -> Tensor:
+def uniform_z_vals(n_rays: int, cfg: NetCfg, training: bool, strat_u: Optional[Tensor], dtype, device=None) -> Tensor:
     """UniformSampler.get_z_vals (ray_sampler.py:22-43), take_sphere_intersection=False."""
     near, far = cfg.sampler.near, 2.0 * cfg.scene_bounding_sphere
-    t = torch.linspace(0.0, 1.0, steps=cfg.sampler.N_samples_eval, dtype=dtype)
+    t = torch.linspace(0.0, 1.0, steps=cfg.sampler.N_samples_eval, dtype=dtype, device=device)
     z = (near * (1.0 - t) + far * t).unsqueeze(0).repeat(n_rays, 1)
     if training:
         mids = 0.5 * (z[:, 1:] + z[:, :-1])
@@ -499,11 +499,11 @@ def sample_z_vals(sd, cfg: NetCfg, dirs: Tensor, cam_loc: Tensor, training: bool
     by "exactly k evaluations of the loop body" -- used for fixed-work throughput runs only.
     """
     sc = cfg.sampler
-    B, dtype = dirs.shape[0], dirs.dtype
+    B, dtype, dev = dirs.shape[0], dirs.dtype, dirs.device
     draws = draws or Draws()
     with torch.no_grad():
         beta0 = get_beta(sd, cfg).detach().to(dtype)
-        z_vals = uniform_z_vals(B, cfg, training, draws.strat_u, dtype)
+        z_vals = uniform_z_vals(B, cfg, training, draws.strat_u, dtype, dirs.device)
         samples, samples_idx = z_vals, None
         dists = z_vals[:, 1:] - z_vals[:, :-1]
         bound = (1.0 / (4.0 * torch.log(torch.tensor(sc.eps + 1.0)))) * (dists ** 2.0).sum(-1)  # ray_sampler.py:76
@@ -533,9 +533,9 @@ def sample_z_vals(sd, cfg: NetCfg, dirs: Tensor, cam_loc: Tensor, training: bool
                 b_min = b_min * ok + b_mid * ~ok
             beta = b_max
             dens = laplace_density(d, beta.unsqueeze(-1))
-            dists_e = torch.cat([dists, torch.full([B, 1], 1e10, dtype=dtype)], -1)
+            dists_e = torch.cat([dists, torch.full([B, 1], 1e10, dtype=dtype, device=dev)], -1)
             fe = dists_e * dens
-            sfe = torch.cat([torch.zeros(B, 1, dtype=dtype), fe[:, :-1]], dim=-1)
+            sfe = torch.cat([torch.zeros(B, 1, dtype=dtype, device=dev), fe[:, :-1]], dim=-1)
             alpha = 1 - torch.exp(-fe)
             trans = torch.exp(-torch.cumsum(sfe, dim=-1))
             weights = alpha * trans
@@ -560,7 +560,7 @@ def sample_z_vals(sd, cfg: NetCfg, dirs: Tensor, cam_loc: Tensor, training: bool
             cdf = torch.cumsum(pdf, -1)
             cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
             if more or not training:
-                u = torch.linspace(0.0, 1.0, steps=N, dtype=dtype).unsqueeze(0).repeat(B, 1)
+                u = torch.linspace(0.0, 1.0, steps=N, dtype=dtype, device=dev).unsqueeze(0).repeat(B, 1)
             else:
                 u = draws.cdf_u
             samples = inverse_cdf(z_vals, cdf, u)
@@ -570,13 +570,13 @@ def sample_z_vals(sd, cfg: NetCfg, dirs: Tensor, cam_loc: Tensor, training: bool
                 z_vals, samples_idx = torch.sort(torch.cat([z_vals, samples], -1), -1)
         if trace is not None:
             trace.iters = total_iters
-        near = torch.full((B, 1), sc.near, dtype=dtype)
-        far = torch.full((B, 1), 2.0 * cfg.scene_bounding_sphere, dtype=dtype)
+        near = torch.full((B, 1), sc.near, dtype=dtype, device=dev)
+        far = torch.full((B, 1), 2.0 * cfg.scene_bounding_sphere, dtype=dtype, device=dev)
         if sc.N_samples_extra > 0:
             if training:
                 idx = draws.extra_idx.long()
             else:
-                idx = torch.linspace(0, z_vals.shape[1] - 1, sc.N_samples_extra).long()   # ray_sampler.py:225
+                idx = torch.linspace(0, z_vals.shape[1] - 1, sc.N_samples_extra).long().to(dev)   # ray_sampler.py:225
             extra = torch.cat([near, far, z_vals[:, idx]], -1)
         else:
             extra = torch.cat([near, far], -1)
@@ -882,7 +882,7 @@ def composite_backward(z_all, sdf, rgb, dnorm, beta, g_rgb, g_depth, g_wsum):
     dens = laplace_density(sdf, beta)
     delta = torch.cat([z[:, 1:] - z[:, :-1], (zmax - z[:, -1]).unsqueeze(-1)], -1)
     E = delta * dens
-    T = torch.exp(-torch.cumsum(torch.cat([torch.zeros(B, 1, dtype=z.dtype), E[:, :-1]], -1), -1))
+    T = torch.exp(-torch.cumsum(torch.cat([torch.zeros(B, 1, dtype=z.dtype, device=z.device), E[:, :-1]], -1), -1))
     w = (1 - torch.exp(-E)) * T
     wbar = (g_rgb.unsqueeze(1) * rgb).sum(-1) + g_depth.unsqueeze(-1) * z / dnorm.clamp(min=1e-6).unsqueeze(-1) + g_wsum
     rgb_bar = w.unsqueeze(-1) * g_rgb.unsqueeze(1)

@@ -24,14 +24,15 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
 from i2sdf_amd import dist as i2d
 
-def grads(attach):
+def grads(attach, equivalent=False, force_iters=2):
     torch.manual_seed(0)
     conf = synthetic_conf(); conf["use_normal"] = True
     net = I2SDFNetwork(conf).cuda()
-    net.train(); net.force_iters = 2
+    net.train(); net.force_iters = force_iters
     if attach:
         i2d.broadcast_parameters(net, src=0)          # before the flat buffer exists: per tensor
-        i2d.attach_data_parallel(net)
+        i2d.attach_data_parallel(net, equivalent=equivalent)     # backend nccl -> the library's own RCCL communicator (i2sdf_comm_*)
+        assert net.dp_state.comm is not None and net.dp_state.comm.world == 1
     g = torch.Generator().manual_seed(3)
     B = 96
     K = torch.eye(4); K[0, 0] = K[1, 1] = 600.0; K[0, 2] = 320.0; K[1, 2] = 240.0
@@ -43,6 +44,8 @@ def grads(attach):
           "normal": torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).cuda(),
           "normal_mask": torch.ones(B, dtype=torch.bool).cuda()}
     loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
+    if attach:
+        i2d.attach_loss(loss_fn, net)                  # equivalent mode: loss denominators through the RCCL exchange hook
     torch.manual_seed(7)                               # the module's own random draws
     out = net(inp)
     loss_fn(out, gt, 0)["loss"].backward()
@@ -58,6 +61,11 @@ dist.barrier()
 torch.cuda.synchronize()
 assert torch.isfinite(a).all() and float(a.abs().max()) > 0
 assert torch.equal(a, b), float((a - b).abs().max())
+# 1-GPU-equivalent mode, data-dependent sampler loop: the per-iteration flag MAX-reduce, the shared-column broadcast and the loss
+# denominators all go through RCCL (identity on one rank) -> bitwise the same step
+c, d = grads(False, force_iters=0), grads(True, equivalent=True, force_iters=0)
+torch.cuda.synchronize()
+assert torch.equal(c, d), float((c - d).abs().max())
 dist.destroy_process_group()
 print("RCCL_OK")
 """
