@@ -418,6 +418,23 @@ int i2sdf_eikonal_outputs_forward(const float* grad_all, int64_t B, float* grad_
 int i2sdf_eikonal_outputs_backward(const float* grad_all, const float* grad_theta_bar, const float* diff_norm_bar, int64_t B,
                                    float* grad_all_bar, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Full-image inference in one call -- the chunk loop of utils.split_input / model(chunk) /
+ * utils.merge_output (utils/__init__.py:35-84) as used by model/eval/recon.py:161-182 and the plotting callbacks: eval mode,
+ * `chunk` = split_n_pixels rays at a time, every chunk rendered exactly as the reference renders it (the sampler's convergence
+ * test is per chunk), outputs written straight into the (P, C) image-order tensors.  Enqueues all chunks on `stream` without
+ * allocating or synchronising; one chunk-sized workspace (i2sdf_render_image_workspace_floats) is reused by every chunk.
+ *   uv (P,2) pixel coordinates of ONE view; pose (4,4) or (7); intrinsics (4,4); tables as for i2sdf_sample_rays (eval)
+ *   -> o_rgb (P,3), o_depth (P), o_wsum (P), o_normal (P,3)|NULL = normal_map, o_lmask (P) (required iff the plan has a light
+ *      head), o_z (P, N_samples+N_extra+2)|NULL the depths used, o_iters (ceil(P/chunk)) device ints|NULL sampler iterations
+ * ---------------------------------------------------------------------------------------------- */
+int64_t i2sdf_render_image_workspace_floats(const i2sdf_plan* plan, const i2sdf_sampler_cfg* cfg, int64_t chunk);
+int i2sdf_render_image(const i2sdf_plan* plan, const float* packed, const float* params, const i2sdf_sampler_cfg* cfg,
+                       const float* uv, const float* pose, int32_t pose_is_quat, const float* intrinsics, int64_t P, int64_t chunk,
+                       const float* t_lin, const float* u_more, const float* u_final, const int32_t* extra_tab, float* workspace,
+                       float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* o_z, int32_t* o_iters,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -290,12 +290,32 @@ def sdf_gradient(sd, cfg: SdfCfg, x: Tensor, create_graph: bool = False) -> Tens
 # --------------------------------------------------------------------------------------
 # M5  radiance network ('nerf' mode) -- model/network/mlp.py:208-229
 # --------------------------------------------------------------------------------------
+# Test hook: `with relu_hook(fn):` routes every ReLU of the radiance net through fn(pre_activation, layer) -> activation.
+# Used by the parity tests to (a) record the pre-activations and (b) force the backward mask of units whose pre-activation is
+# zero within fp32 rounding -- there the reference's own mask is decided by rounding noise (tests/helpers.py: relu_flip_analysis).
+_RELU_HOOK = None
+
+
+class relu_hook:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __enter__(self):
+        global _RELU_HOOK
+        self.prev, _RELU_HOOK = _RELU_HOOK, self.fn
+        return self
+
+    def __exit__(self, *exc):
+        global _RELU_HOOK
+        _RELU_HOOK = self.prev
+
+
 def rgb_forward(sd, cfg: RgbCfg, view_dirs: Tensor, feat: Tensor, prefix: str = "rendering_network") -> Tensor:
     h = torch.cat([positional_encode(view_dirs, cfg.multires_view), feat], dim=-1)
     for l in range(cfg.n_lin):
         h = torch.nn.functional.linear(h, effective_weight(sd, f"{prefix}.lin{l}"), sd[f"{prefix}.lin{l}.bias"])
         if l < cfg.n_lin - 1:
-            h = torch.relu(h)
+            h = torch.relu(h) if _RELU_HOOK is None else _RELU_HOOK(h, l)
     return torch.sigmoid(h)
 
 

@@ -111,3 +111,94 @@ def assert_grad_digest(z, grads, tol, stride_key="grad_stride"):
         # the sum over the whole tensor guards the elements the sample skips (loose: cancellation)
         assert abs(float(g.sum()) - float(z["gsum." + n])) <= 50 * tol * gmax * max(1.0, g.numel() ** 0.5), f"grad {n}: sum"
     return worst
+
+
+def perturbed_weights(sd, rel=2e-7, seed=0):
+    """Another fp32 evaluation of the same network, emulated: every weight direction tensor times (1 + rel * N(0,1)).  rel is at
+    fp32 rounding level, so a quantity that moves by more than that under this perturbation is ill-conditioned IN THE REFERENCE
+    (e.g. a ReLU whose pre-activation is zero within rounding: its backward mask is then decided by rounding noise)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        out[k] = v * (1.0 + rel * torch.randn(v.shape, generator=g, dtype=v.dtype)) if k.endswith("weight_v") else v.clone()
+    return out
+
+
+def measured_spread(run, sd, n_perturbed=2, rel=2e-7):
+    """run(sd, dtype) -> dict name -> tensor (outputs / losses / gradients of the ORACLE).  Returns name -> the largest max-norm
+    relative deviation from the plain fp32 run among: the fp64 run and `n_perturbed` fp32 runs with rounding-level weight noise.
+    This is how far two correct evaluations of the reference algorithm are apart on this input: the conditioning of each quantity."""
+    base = run(sd, torch.float32)
+    members = [run({k: v.double() for k, v in sd.items()}, torch.float64)]
+    members += [run(perturbed_weights(sd, rel=rel, seed=100 + i), torch.float32) for i in range(n_perturbed)]
+    spread = {}
+    for k, b in base.items():
+        b64 = b.detach().double()
+        den = float(b64.abs().max())
+        if den == 0.0:
+            spread[k] = 0.0
+            continue
+        spread[k] = max(float((m[k].detach().double() - b64).abs().max()) / den for m in members)
+    return spread
+
+
+def network_of(name):
+    return name.split(".")[0]
+
+
+def relu_flip_analysis(grads_fn, tau=1e-6, max_candidates=64):
+    """ReLU units of the radiance net whose pre-activation is zero within fp32 rounding, and what flipping each one's BACKWARD
+    MASK does to the gradient.
+
+    grads_fn() -> {name: grad} runs the fp32 oracle's training step (bitwise the reference's arithmetic, see
+    test_oracle_vs_reference.py).  The derivative of relu at a pre-activation of +-1e-7 is 1 or 0 depending on the sign rounding
+    noise left behind, so two correct fp32 evaluations (the reference's and any other) can legitimately differ by exactly such
+    flips; each flip changes the gradient by a fixed, computable vector.  Returns (candidates, deltas): candidates = list of
+    (layer, point, unit, pre_activation); deltas[i] = {name: grad with candidate i's mask flipped  -  base grad}."""
+    rec = {}
+
+    def record(a, l):
+        rec[l] = a.detach()
+        return torch.relu(a)
+
+    with orc.relu_hook(record):
+        base = grads_fn()
+    cands = []
+    for l, a in rec.items():
+        idx = (a.abs() < tau).nonzero()
+        for m, u in idx.tolist():
+            cands.append((l, m, u, float(a[m, u])))
+    cands.sort(key=lambda c: abs(c[3]))
+    cands = cands[:max_candidates]
+    deltas = []
+    for (l, m, u, _) in cands:
+        def forced(a, layer, l=l, m=m, u=u):
+            mask = (a.detach() > 0)
+            if layer == l:
+                mask = mask.clone()
+                mask[m, u] = ~mask[m, u]
+            return a * mask.to(a.dtype)
+
+        with orc.relu_hook(forced):
+            g = grads_fn()
+        deltas.append({k: g[k] - base[k] for k in base})
+    return base, cands, deltas
+
+
+def explain_by_relu_flips(err, deltas, scale):
+    """err, deltas[i]: {name: 1-D tensor} (same sampling), scale: {name: max |reference grad|}.  Finds the 0/1 combination of
+    candidate flips that best explains err (least squares, rounded) and returns (chosen indices, residual {name: max-norm rel})."""
+    names = [n for n in err if scale[n] > 0]
+    e = torch.cat([err[n].double() / scale[n] for n in names])
+    if not deltas:
+        return [], {n: float(err[n].abs().max()) / scale[n] for n in names}
+    A = torch.stack([torch.cat([d[n].double() / scale[n] for n in names]) for d in deltas], 1)
+    x = torch.linalg.lstsq(A, e.unsqueeze(1)).solution.squeeze(1)
+    chosen = [i for i, v in enumerate(x.tolist()) if v > 0.5]
+    r = e - (A[:, chosen].sum(1) if chosen else 0.0)
+    res, off = {}, 0
+    for n in names:
+        k = err[n].numel()
+        res[n] = float(r[off:off + k].abs().max())
+        off += k
+    return chosen, res
