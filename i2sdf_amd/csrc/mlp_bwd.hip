@@ -401,7 +401,7 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
   if (p->H == 256 && p->F == 256) {
     a.n_fwd = sdf_fwd_hidden_stages(256, PE<6>::PEC, d.n_lin, has_skip);
     a.n_rev = sdf_rev_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
-    const int64_t bulk = split_bulk_points(M);
+    const int64_t bulk = split_bulk_points(M, p->n_cu);
     // full workgroups in bf16x3 split arithmetic (two launches); needs at least one plain hidden layer above the skip layer
     const bool x3 = p->sdf_bwd_bf16x3 != 0 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
     auto launch3 = [&](unsigned g) {
@@ -446,7 +446,7 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
-    const int64_t bulk = split_bulk_points(M);
+    const int64_t bulk = split_bulk_points(M, p->n_cu);
     auto full = [&](const RgbBwdArgs& x, unsigned g) {
       if (p->rgb_bf16x3) {
         RgbBwdArgs x3 = x;

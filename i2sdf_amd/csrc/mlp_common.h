@@ -26,7 +26,7 @@ inline void launch_lds(K kern, unsigned grid, hipStream_t st, A... args) { launc
 
 // Split of a launch over M points into full rounds of 128-point workgroups (one per CU) and a short tail that is run by
 // the split-K kernels (ksplit.h): returns the number of points of the bulk part (0 = no split).
-inline int64_t split_bulk_points(int64_t M, int n_cu = 256) {
+inline int64_t split_bulk_points(int64_t M, int n_cu) {
   const int64_t n_wg = (M + PTS_PER_WG - 1) / PTS_PER_WG;
   const int64_t full = (n_wg / n_cu) * n_cu, rem = n_wg - full;
   if (full == 0 || rem == 0 || rem * 4 > n_cu) return 0;      // nothing to gain, or the tail would not fit one round

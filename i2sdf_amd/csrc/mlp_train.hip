@@ -389,7 +389,7 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
   if (p->H == 256 && p->F == 256) {
-    const int64_t bulk = split_bulk_points(M);
+    const int64_t bulk = split_bulk_points(M, p->n_cu);
     if (bulk > 0 && feat != nullptr) {      // full rounds + the partial last round as split-K workgroups (ksplit.h)
       const int64_t M_all = a.M;
       const unsigned tg = (unsigned)((M_all - bulk + 31) / 32);
@@ -432,7 +432,7 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (d.hidden == 256 && p->F == 256) {
     a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
-    const int64_t bulk = split_bulk_points(M);
+    const int64_t bulk = split_bulk_points(M, p->n_cu);
     // full workgroups optionally in bf16x3 split arithmetic (mlp_x3.hip); the split-K tail keeps the fp32 MFMA kernel
     auto full = [&](const RgbFwdArgs& x, unsigned g) {
       if (p->rgb_bf16x3) {

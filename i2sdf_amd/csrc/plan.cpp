@@ -308,6 +308,11 @@ extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
     p->d_segs = nullptr;
     (void)hipGetLastError();
   }
+  {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) p->n_cu = n;
+    else (void)hipGetLastError();
+  }
   *out = p;
   return I2SDF_OK;
 }

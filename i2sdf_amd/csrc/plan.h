@@ -64,6 +64,7 @@ struct i2sdf_plan {
   int64_t total_chunks = 0;          // chunks after the scale region (+1 stage of slack for the DMA look-ahead)
   int64_t wgrad_floats = 0;
   int32_t H = 0, F = 0;              // sdf hidden width / feature size
+  int32_t n_cu = 256;                // compute units of the device the plan was created on (hipDeviceProp; 256 on MI355X)
   int32_t rgb_bf16x3 = 0;            // I2SDF_OPT_RGB_BF16X3: radiance forward / backward (full workgroups) in bf16x3 split arithmetic
   int32_t sdf_bwd_bf16x3 = 0;        // I2SDF_OPT_SDF_BWD_BF16X3: SDF backward sweeps (full workgroups) in bf16x3 split arithmetic
   int32_t train_fwd_bf16x3 = 0;      // I2SDF_OPT_TRAIN_FWD_BF16X3: SDF forward + d sdf/dx kernel in bf16x3 split arithmetic

@@ -213,6 +213,27 @@ def gather_outputs(outputs: Dict[str, torch.Tensor], total: int, group=None) -> 
     return merged
 
 
+def render_image(net, model_input: Dict[str, torch.Tensor], split_n_pixels: int = 12000, group=None) -> Dict[str, torch.Tensor]:
+    """Multi-GPU full-image inference (BASELINE config 4): whole chunks of the view are dealt to the ranks in contiguous runs,
+    every rank renders its run with ONE library call, and the rows are all-gathered into image order (32 B/ray).  Identical
+    to the single-GPU image because the chunk composition does not change."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    P = model_input["uv"].shape[1]
+    mine = net.render_image(model_input, split_n_pixels, rank=rank, world_size=world)
+    if world == 1:
+        return mine
+    n_chunks = (P + split_n_pixels - 1) // split_n_pixels
+    per = (n_chunks + world - 1) // world * split_n_pixels           # rows per rank (last ranks may hold fewer / none)
+    merged = {}
+    for k, v in mine.items():
+        pad = torch.zeros((per,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device)
+        pad[: v.shape[0]] = v
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        merged[k] = torch.cat(parts, 0)[:P]
+    return merged
+
+
 def global_any(flag: torch.Tensor, group=None) -> torch.Tensor:
     """MAX-reduce a small flag tensor on the host side of the ABI (kept for callers that run their own loop; the module's
     sampler uses the device-side exchange hook instead)."""

@@ -350,6 +350,34 @@ class RenderEngine:
                                             L.ptr(ds_out), L.ptr(bound), L.stream_ptr()), "i2sdf_error_bound")
         return (bound, ds_out) if want_d_star else bound
 
+    # -- full-image inference (N3) ---------------------------------------------------------------
+    def render_image(self, flat_params, uv, pose, intrinsics, chunk, want_normal=True, want_z=False):
+        """All chunks of one view in ONE library call (include/i2sdf.h: i2sdf_render_image).  uv (P,2); pose (4,4)|(7); K (4,4).
+        Returns dict(rgb (P,3), depth (P), wsum (P,1), normal (P,3)|None, lmask (P,1)|None, z (P,n_z)|None, iters (n_chunks) int32)."""
+        uv = uv.detach().to(torch.float32).reshape(-1, 2).contiguous()
+        pose = pose.detach().to(torch.float32).contiguous()
+        intrinsics = intrinsics.detach().to(torch.float32).reshape(4, 4).contiguous()
+        quat = pose.numel() == 7
+        if not quat and pose.numel() != 16:
+            raise ValueError(f"one view: pose must be (4,4) or (7,), got {tuple(pose.shape)}")
+        P, dev = uv.shape[0], uv.device
+        chunk = int(max(1, min(chunk, max(P, 1))))
+        n_ws = int(self._lib.i2sdf_render_image_workspace_floats(self._plan, C.byref(self._scfg), chunk))
+        ws = getattr(self, "_img_ws", None)
+        if ws is None or ws.numel() < n_ws or ws.device != dev:
+            ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            self._img_ws = ws                                  # kept: a video / test set renders many views at the same chunk size
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        o = {"rgb": e(P, 3), "depth": e(P), "wsum": e(P, 1), "normal": e(P, 3) if want_normal else None,
+             "lmask": e(P, 1) if self.cfg.light is not None else None, "z": e(P, self.n_z) if want_z else None,
+             "iters": torch.zeros((P + chunk - 1) // chunk, dtype=torch.int32, device=dev)}
+        L.check(self._lib.i2sdf_render_image(self._plan, L.ptr(self.packed), L.ptr(flat_params), C.byref(self._scfg), L.ptr(uv), L.ptr(pose),
+                                             int(quat), L.ptr(intrinsics), P, chunk, L.ptr(self.t_lin), L.ptr(self.u_more), L.ptr(self.u_final),
+                                             L.ptr(self.extra_tab), L.ptr(ws), L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["wsum"]),
+                                             L.ptr(o["normal"]), L.ptr(o["lmask"]), L.ptr(o["z"]), L.ptr(o["iters"]), L.stream_ptr()),
+                "i2sdf_render_image")
+        return o
+
     # -- light-mask head ---------------------------------------------------------------------------
     def light_forward(self, feat, M, save=True):
         Mp, dev = feat.shape[0], feat.device

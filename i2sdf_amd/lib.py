@@ -119,6 +119,10 @@ SIGNATURES = {
     # force_iters, workspace, z_out, ldz, z_eik, iters_out, stream
     "i2sdf_sample_rays": (C.c_int, [_P, _P, _P, C.POINTER(SamplerCfg), _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _P, _P, _P, _I32, _P, _P,
                                     _I64, _P, _P, _P]),
+    "i2sdf_render_image_workspace_floats": (_I64, [_P, C.POINTER(SamplerCfg), _I64]),
+    # plan, packed, params, cfg, uv, pose, pose_is_quat, intrinsics, P, chunk, t_lin, u_more, u_final, extra_tab, workspace,
+    # o_rgb, o_depth, o_wsum, o_normal, o_lmask, o_z, o_iters, stream
+    "i2sdf_render_image": (C.c_int, [_P, _P, _P, C.POINTER(SamplerCfg), _P, _P, _I32, _P, _I64, _I64] + [_P] * 13),
     "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_loss_scratch_floats": (_I64, []),

@@ -387,19 +387,33 @@ class I2SDFNetwork(nn.Module):
     # ------------------------------------------------------------------------------------------
     # "next" rows N3 / N4 of SURVEY.md section 8(f): the callers' chunk loops, kept on the device
     @torch.no_grad()
-    def render_image(self, input: Dict[str, torch.Tensor], split_n_pixels: int = 12000) -> Dict[str, torch.Tensor]:
+    def render_image(self, input: Dict[str, torch.Tensor], split_n_pixels: int = 12000, rank: int = 0, world_size: int = 1,
+                     return_depths: bool = False) -> Dict[str, torch.Tensor]:
         """Full-image inference: utils.split_input -> self(chunk) -> utils.merge_output (utils/__init__.py:35-84,
-        model/eval/recon.py:161-182) in one call; input['uv'] is (1, P, 2).  Outputs are (P, C) / (P,) in pixel order.
-        Chunks are rendered exactly as the reference renders them (the sampler's convergence test is per chunk)."""
+        model/eval/recon.py:161-182) as ONE library call (i2sdf_render_image): every chunk of `split_n_pixels` rays is rendered
+        exactly as the reference renders it (eval mode, the sampler's convergence test is per chunk) and written straight into
+        the (P, C) outputs in pixel order.  input['uv'] is (1, P, 2) -- one view.
+
+        world_size > 1: this rank renders only ITS chunks (whole chunks, contiguous: the chunk composition -- and with it every
+        pixel -- is the same as on one GPU) and returns its rows; i2sdf_amd.dist.render_image gathers the image."""
         uv = input["uv"]
-        assert uv.shape[0] == 1, "eval layout: uv is (1, P, 2)"
+        assert uv.dim() == 3 and uv.shape[0] == 1, "eval layout: uv is (1, P, 2), one view"
         P = uv.shape[1]
-        outs = []
-        for lo in range(0, P, split_n_pixels):
-            d = dict(input)
-            d["uv"] = uv[:, lo:lo + split_n_pixels].contiguous()
-            outs.append(self(d))
-        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
+        eng = self._engine_for(uv.device)
+        n_chunks = (P + split_n_pixels - 1) // split_n_pixels
+        per = (n_chunks + world_size - 1) // world_size
+        lo = min(rank * per, n_chunks) * split_n_pixels
+        hi = min(min((rank + 1) * per, n_chunks) * split_n_pixels, P)
+        with torch.cuda.device(uv.device):
+            o = eng.render_image(self._flat, uv[0, lo:hi], input["pose"][0], input["intrinsics"][0], split_n_pixels, want_z=return_depths)
+        self.last_sampler_iters = o["iters"]                  # one count per chunk
+        out = {"rgb_values": o["rgb"], "depth_values": o["depth"], "weight_sum": o["wsum"]}
+        if self.use_light:
+            out["light_mask"] = o["lmask"]
+        out["normal_map"] = o["normal"]
+        if return_depths:
+            out["z_vals"] = o["z"]
+        return out
 
     @torch.no_grad()
     def sdf_grid(self, points: torch.Tensor, chunk: int = 1 << 20) -> torch.Tensor:

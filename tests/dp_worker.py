@@ -95,6 +95,20 @@ def worker(rank, world, port, Bh, result_path):
             den = float(q.grad.abs().max())
             res["grad_err"][n] = float((p.grad - q.grad).abs().max()) / den if den > 0 else float(p.grad.abs().max())
         torch.save(res, result_path)
+    # ---- multi-GPU full-image inference (N3): whole chunks dealt to the ranks, rows all-gathered into image order
+    ev = make_net().eval()
+    Wi, Hi, chunk = 32, 24, 100
+    K = torch.eye(4); K[0, 0] = K[1, 1] = 30.0; K[0, 2], K[1, 2] = Wi / 2, Hi / 2
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
+    ys, xs = torch.meshgrid(torch.arange(Hi), torch.arange(Wi), indexing="ij")
+    img = {"uv": torch.stack([xs, ys], -1).float().reshape(1, -1, 2).cuda(), "intrinsics": K.unsqueeze(0).cuda(), "pose": pose.unsqueeze(0).cuda()}
+    merged = i2dist.render_image(ev, img, chunk)
+    if rank == 0:
+        single = ev.render_image(img, chunk)
+        res = torch.load(result_path)
+        res["image_equal"] = all(bool(torch.equal(merged[k], single[k])) for k in single)
+        res["image_rows"] = int(merged["rgb_values"].shape[0])
+        torch.save(res, result_path)
     dist.barrier()
     dist.destroy_process_group()
 

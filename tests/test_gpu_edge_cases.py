@@ -80,7 +80,7 @@ def test_render_image_equals_manual_chunk_loop_and_grid_sdf():
             parts.append(net(d))
     for k in full:
         assert full[k].shape[0] == P
-        assert torch.equal(full[k], torch.cat([p[k] for p in parts], 0)), k
+        assert torch.equal(full[k].reshape(P, -1), torch.cat([p[k] for p in parts], 0).reshape(P, -1)), k
     pts = (torch.rand(5000, 3) * 2 - 1) * 1.5
     got = net.sdf_grid(pts.cuda(), chunk=1024)
     assert_close(got.cpu(), orc.sdf_forward(sd, ocfg.sdf, pts)[:, 0], 2e-5, "sdf_grid")
