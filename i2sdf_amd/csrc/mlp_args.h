@@ -55,7 +55,11 @@ struct RgbBwdArgs {
 };
 
 // bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points
-void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st);
-void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
+// `ring`: the kernels that re-read saved tensors take them through the per-wave LDS ring (x3r.h, mlp_x3r.hip)
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st, bool ring);
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st, bool ring);
 void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st, bool ring);
+void i2sdf_launch_igrad3r(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_sdf_bwd3r(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_bwd3r(const RgbBwdArgs& a, unsigned grid, hipStream_t st);

@@ -385,7 +385,7 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     a3.rev = base + p->sdf.rev3_wsdf_chunk * CHUNK_FLOATS;                                               \
     a3.n_fwd = sdf_fwd3_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);      \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
-    i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st);                                            \
+    i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st, p->src_ring != 0);                                            \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
   if (p->H == 256 && p->F == 256) {

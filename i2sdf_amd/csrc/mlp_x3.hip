@@ -378,13 +378,20 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
 
 }  // namespace
 
-void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st) {
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st, bool ring) {
   launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, grid, st, a);
-  if (grad) launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a);
+  if (grad) {
+    if (ring) i2sdf_launch_igrad3r(a, grid, st);
+    else launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a);
+  }
 }
-void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st, bool ring) {
+  if (ring) { i2sdf_launch_sdf_bwd3r(a, grid, st); return; }
   launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
   launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);
 }
 void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(rgb_fwd3_kernel<256, 256, 4>, grid, st, a); }
-void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(rgb_bwd3_kernel<256, 256>, grid, st, a); }
+void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st, bool ring) {
+  if (ring) i2sdf_launch_rgb_bwd3r(a, grid, st);
+  else launch_lds(rgb_bwd3_kernel<256, 256>, grid, st, a);
+}

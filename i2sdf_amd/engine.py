@@ -42,6 +42,9 @@ class RenderEngine:
                 self.set_sdf_backward_bf16x3(True)
             if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
                 self.set_rgb_bf16x3(True)
+        self.src_ring = False
+        if cfg.bf16x3 and os.environ.get("I2SDF_SRC_RING", "1") != "0":       # on by default; I2SDF_SRC_RING=0 for A/B runs
+            self.set_src_ring(True)
         self.tail_overlap = False
         if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
             self.set_tail_overlap(True)
@@ -131,6 +134,11 @@ class RenderEngine:
         """Radiance forward / backward (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_RGB_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.rgb_bf16x3 = bool(on)
+
+    def set_src_ring(self, on: bool):
+        """Saved-tensor reads of the bf16x3 kernels through the per-wave LDS DMA ring (I2SDF_OPT_SRC_RING, csrc/x3r.h)."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SRC_RING, int(bool(on))), "i2sdf_plan_set_option")
+        self.src_ring = bool(on)
 
     def set_tail_overlap(self, on: bool):
         """Split-K tail workgroups on the plan's side stream, concurrent with the full workgroups (I2SDF_OPT_TAIL_OVERLAP)."""

@@ -69,6 +69,7 @@ OPT_TRAIN_FWD_BF16X3 = 4
 OPT_SDF_BWD_BF16X3 = 8
 OPT_RGB_BF16X3 = 16
 OPT_TAIL_OVERLAP = 32
+OPT_SRC_RING = 64
 
 
 class I2SDFError(RuntimeError):

@@ -97,6 +97,10 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   concurrently with the full workgroups / the 256x256 blocks; the entry point still returns stream-ordered on the
  *   caller's stream (fork/join with events; capturable in a hipGraph). */
 #define I2SDF_OPT_TAIL_OVERLAP 32
+/*   I2SDF_OPT_SRC_RING: the bf16x3 kernels that re-read saved tensors (backward sweeps, d sdf/dx chain, radiance backward) take
+ *   them through a per-wave LDS ring filled by DMA, several k-chunks ahead, with counted vmcnt waits (csrc/x3r.h): memory time
+ *   overlaps matrix time instead of adding to it.  Same arithmetic, bitwise the same results.  Default 0. */
+#define I2SDF_OPT_SRC_RING 64
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
