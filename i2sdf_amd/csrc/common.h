@@ -418,20 +418,22 @@ __device__ __forceinline__ void store_tile(float* __restrict__ row, int hi, bool
       *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q + 4 * hi) = v;
     }
 }
+// `kcs` = floats between consecutive 16-wide k-chunks of the row: 16 in the point-major layout, 512 in the blocked layout of the
+// saved tensors (mlp_common.h: save_row_off)
 template <int NC>
-__device__ __forceinline__ void store_regs(float* __restrict__ row, int hi, bool valid, const float (&r)[NC * 4]) {
+__device__ __forceinline__ void store_regs(float* __restrict__ row, int hi, bool valid, const float (&r)[NC * 4], int kcs = 16) {
   if (!valid) return;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     f32x4 v = {r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]};
-    *reinterpret_cast<f32x4*>(row + 8 * c + 4 * hi) = v;
+    *reinterpret_cast<f32x4*>(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi) = v;
   }
 }
 template <int NC>
-__device__ __forceinline__ void load_regs(const float* __restrict__ row, int hi, float (&r)[NC * 4]) {
+__device__ __forceinline__ void load_regs(const float* __restrict__ row, int hi, float (&r)[NC * 4], int kcs = 16) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(row + 8 * c + 4 * hi);
+    f32x4 v = *reinterpret_cast<const f32x4*>(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi);
     r[4 * c] = v.x; r[4 * c + 1] = v.y; r[4 * c + 2] = v.z; r[4 * c + 3] = v.w;
   }
 }

@@ -14,6 +14,7 @@ struct SdfTrainFwdArgs {
   float* hs;                            // (L-1, Mp, H)  h_1..h_{L-1}   or nullptr (no saves: eval)
   float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
   float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
+  int kcs = 16;                         // layout of hs / abars for the points of THIS launch: 16 point-major, 512 blocked (mlp_common.h)
 };
 
 struct SdfBwdArgs {
@@ -31,6 +32,7 @@ struct SdfBwdArgs {
   float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (holds G2(a_l) between the sweeps)
   float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
   float* ones4;                         // (Mp,4) {1,0,0,0}
+  int kcs = 16;                         // layout of hs / abars / gus / gas for the points of this launch
 };
 
 struct RgbFwdArgs {
@@ -41,6 +43,7 @@ struct RgbFwdArgs {
   float* rgb;                           // (M,3)
   float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
   float* pev_save;                      // (Mp, PECV*8) PE(view dir), or nullptr
+  int kcs = 16;                         // layout of rs for the points of this launch
 };
 
 struct RgbBwdArgs {
@@ -52,6 +55,7 @@ struct RgbBwdArgs {
   float* gar;               // (L-1, Mp, H)  G(a_l), l = 0..L-2
   float* ga_last;           // (Mp, 4)       G(a_{L-1}) (3 used)
   float* fbar;              // (Mp, F)
+  int kcs = 16;             // layout of rs / gar for the points of this launch
 };
 
 // bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points

@@ -410,6 +410,7 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       a3.rev = base + p->sdf.rev3_chunk0 * CHUNK_FLOATS;
       a3.n_fwd = sdf_fwd3_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
       a3.n_rev = sdf_rev3_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
+      a3.kcs = sdf_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
       i2sdf_launch_sdf_bwd3(a3, g, st, p->src_ring != 0);
     };
     if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
@@ -452,6 +453,7 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
         RgbBwdArgs x3 = x;
         x3.rev = packed + p->scale_floats + p->rgb.rev3_chunk0 * CHUNK_FLOATS;
         x3.n_rev = rgb_rev3_stages(256, 256, d.n_lin);
+        x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
         i2sdf_launch_rgb_bwd3(x3, g, st, p->src_ring != 0);
       } else {
         launch_lds(rgb_bwd_kernel<256, 256>, g, st, x);

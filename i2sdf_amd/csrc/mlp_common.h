@@ -33,6 +33,33 @@ inline int64_t split_bulk_points(int64_t M, int n_cu) {
   return full * PTS_PER_WG;
 }
 
+// ---- layouts of the saved per-point tensors of width 256 (hs, abars, gus, gas; rs, gar) ------------------------------
+//   point-major  [Mp][256]                          row of point m at m*256, k-chunk kc (16 floats) at +16*kc
+//   blocked      [Mp/32][16 k-chunks][32 points][16] row of point m at (m/32)*8192 + (m%32)*16, k-chunk kc at +512*kc
+// The K-outer bf16x3 kernels touch 16 floats of every point per k-chunk: in the point-major layout a wave instruction
+// (16 B per lane) lands in 32 different 1 KB rows, in the blocked layout in one contiguous 2 KB run -- 3.9 vs 5.0 TB/s at the
+// occupancy of these kernels (scripts/dev/layout_bench2.hip).  I2SDF_OPT_BLOCKED_SAVES stores the points handled by the bf16x3
+// full workgroups blocked; the fp32 split-K tail workgroups (the points behind them) and the fp32 kernels keep point-major rows.
+// Both ranges are tile aligned, so one tensor holds both; every producer / consumer derives the blocked prefix from (plan, M).
+constexpr int KCS_PM = 16, KCS_BLK = 512;
+__host__ __device__ inline int64_t save_row_off(int64_t m, int kcs) { return kcs == KCS_PM ? m * 256 : (m >> 5) * 8192 + (m & 31) * 16; }
+
+inline bool sdf_x3_path(const i2sdf_plan* p) {
+  const i2sdf_mlp_desc& d = p->sdf.d;
+  return p->train_fwd_bf16x3 != 0 && p->sdf_bwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
+}
+// leading points of a batch of M points whose saved SDF tensors are in the blocked layout (0 = none)
+inline int64_t sdf_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp, bool has_feat = true) {
+  if (!p->blocked_saves || !sdf_x3_path(p)) return 0;
+  const int64_t bulk = split_bulk_points(M, p->n_cu);
+  return (bulk > 0 && has_feat) ? bulk : Mp;
+}
+inline int64_t rgb_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp) {
+  if (!p->blocked_saves || !p->rgb_bf16x3 || p->rgb.d.hidden != 256 || p->F != 256) return 0;
+  const int64_t bulk = split_bulk_points(M, p->n_cu);
+  return bulk > 0 ? bulk : Mp;
+}
+
 constexpr float RS2 = 0.70710678118654752440f;
 
 template <int N>

@@ -346,6 +346,13 @@ __global__ __launch_bounds__(256) void rgb_fwd_split_kernel(RgbFwdArgs a, int64_
 
 }  // namespace
 
+// leading points of a batch whose saved 256-wide tensors are in the blocked layout (I2SDF_OPT_BLOCKED_SAVES): which = 0 the SDF
+// tensors (hs, abars, gus, gas) of a batch of M points, 1 the radiance tensors (rs, gar)
+extern "C" int64_t i2sdf_blocked_points(const i2sdf_plan* p, int32_t which, int64_t M, int64_t Mp, int32_t has_feat) {
+  if (!p || M <= 0) return 0;
+  return which == 0 ? sdf_blocked_points(p, M, Mp, has_feat != 0) : rgb_blocked_points(p, M, Mp);
+}
+
 // =============================================================================================================
 extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, const float* points, const float* cam,
                                       const float* dirs, const float* z, int64_t ldz, int32_t n_per_ray, int64_t n_ray_pts, int64_t M,
@@ -385,6 +392,7 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     a3.rev = base + p->sdf.rev3_wsdf_chunk * CHUNK_FLOATS;                                               \
     a3.n_fwd = sdf_fwd3_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);      \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
+    a3.kcs = sdf_blocked_points(p, M, Mp, feat != nullptr) > 0 ? KCS_BLK : KCS_PM;                   \
     i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st, p->src_ring != 0);                                            \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
@@ -438,6 +446,7 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
       if (p->rgb_bf16x3) {
         RgbFwdArgs x3 = x;
         x3.fwd = packed + p->scale_floats + p->rgb.fwd3_chunk0 * CHUNK_FLOATS;
+        x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
         x3.n_fwd = rgb_fwd3_stages(256, 256, PE<4>::DIM, d.n_lin);
         i2sdf_launch_rgb_fwd3(x3, g, st);
       } else {

@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) 
     x3_select_pe<PE16>(pad, pe, hi);
   }
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   WStream ws;
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 accA[NT], accB[NT];
@@ -41,12 +43,12 @@ __global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) 
   }
   // hidden layers: layer l reads accA (pre-activations of layer l-1, whose softplus is h_l -> hs[l-1]) and writes accB
   for (int l = 1; l < a.L - 1; ++l) {
-    float* hrow = a.hs ? a.hs + (l - 1) * lstride + m * H : nullptr;
+    float* hrow = a.hs ? a.hs + (l - 1) * lstride + mrow : nullptr;
     if (l == a.skip) {
-      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
+      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid, kcs};
       dense_x3g<NT, KH16 + PE16, 1>(ws, src, accB, tid);
     } else {
-      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid};
+      X3FwdSrc<NT, KH16, NPE> src{accA, pe, hrow, hi, valid, kcs};
       dense_x3g<NT, KH16, 1>(ws, src, accB, tid);
     }
 #pragma unroll
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) 
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accA[nt][r]);
-  if (a.hs) store_regs<KC>(a.hs + (a.L - 2) * lstride + m * H, hi, valid, h);
+  if (a.hs) store_regs<KC>(a.hs + (a.L - 2) * lstride + mrow, hi, valid, h, kcs);
   {
     float s[1];
     rowvec_op<1, KC>(ws, h, s, tid);
@@ -81,11 +83,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float px, py, pz;
   fetch_point(a.pts, mc, px, py, pz);
   f32x16 accA[NT], accB[NT];
   float h[KC * 4];
-  load_regs<KC>(a.hs + (a.L - 2) * lstride + mc * H, hi, h);
+  load_regs<KC>(a.hs + (a.L - 2) * lstride + mcrow, hi, h, kcs);
   WStream ws;
   ws.begin(a.rev, lds, a.n_rev, tid);
   {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < KC * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
   }
-  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + m * H, hi, valid, h);
+  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + mrow, hi, valid, h, kcs);
   f32x16 pt[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i)
@@ -116,19 +120,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     dense_x3g<NT, KH16, 0>(ws, src, accA, tid);       // l = L-2 (never the skip layer, checked by the host)
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    const float* hrow = a.hs + l * lstride + mc * H;
-    X3RevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + m * H : nullptr, hi, valid};
+    const float* hrow = a.hs + l * lstride + mcrow;
+    X3RevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + mrow : nullptr, hi, valid, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) {
-      X3RevSrc<NT> src2{accA, hrow, nullptr, hi, valid};
+      X3RevSrc<NT> src2{accA, hrow, nullptr, hi, valid, kcs};
       dense_x3g<PT, KH16, 0>(ws, src2, pt, tid);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3RevSrc<NT> src{accA, a.hs + mc * H, a.abars ? a.abars + m * H : nullptr, hi, valid};     // abar_0 = (.) * sigma(h_1)
+    X3RevSrc<NT> src{accA, a.hs + mcrow, a.abars ? a.abars + mrow : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
     dense_x3g<PT, KH16, 0>(ws, src, pt, tid);       // pbar += W_0^T abar_0
   }
   {
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float gpx[NGP];                       // G(pbar) in the fp32 kernels' B layout, zero padded to whole 16-chunks
   {
     float gp[PEC * 4];
@@ -176,8 +182,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   }
   for (int l = 1; l < a.L - 1; ++l) {
     // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l], G2(a_{l-1}) -> gas[l-1]
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
-                                   a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
+                                   a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, hi, valid, kcs};
     if (l == a.skip) dense_x3g<NT, KH16 + PE16, 2>(ws, src, accB, tid);
     else dense_x3g<NT, KH16, 2>(ws, src, accB, tid);
 #pragma unroll
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   }
   {
     const int l = a.L - 1;
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
-                                   a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
+                                   a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, hi, valid, kcs};
     x3_drain<KH16>(src);
   }
 }
@@ -200,6 +206,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   const float sb = a.sbar ? a.sbar[mc] : 0.f;
   if (valid && hi == 0) {
     *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
@@ -223,16 +231,16 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   ws.skip(rowvec_chunks(KC, 1) / SC, tid);            // the d sdf/dx chain's copy of w_sdf
   {
     const int l = a.L - 2;                            // G(a_{L-2}) = (W_feat^T fbar + sbar w_sdf) sigma + G2, then W_{L-2}^T G(a_{L-2})
-    X3Sweep2Src<NT, true> src{accA, a.hs + l * lstride + mc * H, a.gas + l * lstride + mc * H, a.gas + l * lstride + m * H, hi, valid,
-                              sb, a.rev + lane * 4};
+    X3Sweep2Src<NT, true> src{accA, a.hs + l * lstride + mcrow, a.gas + l * lstride + mcrow, a.gas + l * lstride + mrow, hi, valid,
+                              sb, a.rev + lane * 4, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    X3Sweep2Src<NT, false> src{accA, a.hs + l * lstride + mc * H, a.gas + l * lstride + mc * H, a.gas + l * lstride + m * H, hi, valid,
-                               0.f, nullptr};
+    X3Sweep2Src<NT, false> src{accA, a.hs + l * lstride + mcrow, a.gas + l * lstride + mcrow, a.gas + l * lstride + mrow, hi, valid,
+                               0.f, nullptr, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) ws.skip(x3_bwd_chunks(PT, KH16) / SC, tid);      // the PE rows of W_skip^T are not needed here
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3Sweep2Src<NT, false> src{accA, a.hs + mc * H, a.gas + mc * H, a.gas + m * H, hi, valid, 0.f, nullptr};     // G(a_0)
+    X3Sweep2Src<NT, false> src{accA, a.hs + mcrow, a.gas + mcrow, a.gas + mrow, hi, valid, 0.f, nullptr, kcs};     // G(a_0)
     x3_drain<KH16>(src);
   }
 }
@@ -269,6 +277,8 @@ __global__ __launch_bounds__(256) void rgb_fwd3_kernel(RgbFwdArgs a) {
     x3_select_pe<PV16>(pad, pev, hi);
   }
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   WStream ws;
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 accA[NT], accB[NT];
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256) void rgb_fwd3_kernel(RgbFwdArgs a) {
     dense_x3g<NT, PV16 + F / 16, 1>(ws, src, accA, tid);
   }
   for (int l = 1; l < a.L - 1; ++l) {
-    X3ReluSrc<NT> src{accA, a.rs ? a.rs + (l - 1) * lstride + m * H : nullptr, hi, valid};
+    X3ReluSrc<NT> src{accA, a.rs ? a.rs + (l - 1) * lstride + mrow : nullptr, hi, valid, kcs};
     dense_x3g<NT, KH16, 1>(ws, src, accB, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(256) void rgb_fwd3_kernel(RgbFwdArgs a) {
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int q = 0; q < 16; ++q) r[nt * 16 + q] = fmaxf(accA[nt][q], 0.f);
-  if (a.rs) store_regs<KC>(a.rs + (a.L - 2) * lstride + m * H, hi, valid, r);
+  if (a.rs) store_regs<KC>(a.rs + (a.L - 2) * lstride + mrow, hi, valid, r, kcs);
   float o[3];
   rowvec_op<3, KC>(ws, r, o, tid);
   if (valid && hi == 0) {
@@ -306,6 +316,8 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float g3[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -338,15 +350,15 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
       }
     }
     const int l = a.L - 2;
-    const float* rrow = a.rs + l * lstride + mc * H;
-    float* grow = a.gar + l * lstride + m * H;
+    const float* rrow = a.rs + l * lstride + mcrow;
+    float* grow = a.gar + l * lstride + mrow;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(rrow + 8 * c + 4 * hi);
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(rrow + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi);
       f32x4 o;
 #pragma unroll
       for (int t = 0; t < 4; ++t) { o[t] = rv[t] > 0.f ? ga[c * 4 + t] : 0.f; ga[c * 4 + t] = o[t]; }
-      if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
+      if (valid) *reinterpret_cast<f32x4*>(grow + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi) = o;
     }
   }
   f32x16 accA[NT], accB[NT];
@@ -362,14 +374,14 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
     dense_x3g<NT, KH16, 0>(ws, src, accA, tid);            // W_{L-2}^T G(a_{L-2})
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    X3MaskSrc<NT> src{accA, a.rs + l * lstride + mc * H, a.gar + l * lstride + m * H, hi, valid};
+    X3MaskSrc<NT> src{accA, a.rs + l * lstride + mcrow, a.gar + l * lstride + mrow, hi, valid, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3MaskSrc<NT> src{accA, a.rs + mc * H, a.gar + m * H, hi, valid};     // G(a_0), then the feature rows of W_0^T
+    X3MaskSrc<NT> src{accA, a.rs + mcrow, a.gar + mrow, hi, valid, kcs};     // G(a_0), then the feature rows of W_0^T
     zero(accB);
     dense_x3g<FT, KH16, 0>(ws, src, accB, tid);
     store_tile<FT>(a.fbar + mc * F, hi, valid, accB);

@@ -29,11 +29,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float px, py, pz;
   fetch_point(a.pts, mc, px, py, pz);
   f32x16 accA[NT], accB[NT];
   float h[KC * 4];
-  load_regs<KC>(a.hs + (a.L - 2) * lstride + mc * H, hi, h);
+  load_regs<KC>(a.hs + (a.L - 2) * lstride + mcrow, hi, h, kcs);
   WStream ws;
   ws.begin(a.rev, lds, a.n_rev, tid);
   {
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < KC * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
   }
-  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + m * H, hi, valid, h);
+  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + mrow, hi, valid, h, kcs);
   f32x16 pt[PT];
   zero_tiles<PT>(pt);
   {
@@ -52,19 +54,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     dense_x3r<NT, KH16, 0>(ws, src, accA, ring, tid);       // l = L-2 (never the skip layer, checked by the host)
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    const float* hrow = a.hs + l * lstride + mc * H;
-    X3rRevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + m * H : nullptr, hi, valid};
+    const float* hrow = a.hs + l * lstride + mcrow;
+    X3rRevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + mrow : nullptr, hi, valid, kcs};
     zero_tiles<NT>(accB);
     dense_x3r<NT, KH16, 0>(ws, src, accB, ring, tid);
     if (l == a.skip) {
-      X3rRevSrc<NT> src2{accA, hrow, nullptr, hi, valid};
+      X3rRevSrc<NT> src2{accA, hrow, nullptr, hi, valid, kcs};
       dense_x3r<PT, KH16, 0>(ws, src2, pt, ring, tid);
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3rRevSrc<NT> src{accA, a.hs + mc * H, a.abars ? a.abars + m * H : nullptr, hi, valid};     // abar_0 = (.) * sigma(h_1)
+    X3rRevSrc<NT> src{accA, a.hs + mcrow, a.abars ? a.abars + mrow : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
     dense_x3r<PT, KH16, 0>(ws, src, pt, ring, tid);       // pbar += W_0^T abar_0
   }
   {
@@ -87,6 +89,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep1_kernel(SdfBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float gpx[NGP];                       // G(pbar) in the fp32 kernels' B layout, zero padded to whole 16-chunks
   {
     float gp[PEC * 4];
@@ -109,8 +113,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep1_kernel(SdfBwdArgs a) {
   }
   for (int l = 1; l < a.L - 1; ++l) {
     // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l], G2(a_{l-1}) -> gas[l-1]
-    X3rSweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
-                                    a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    X3rSweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
+                                    a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, hi, valid, kcs};
     if (l == a.skip) dense_x3r<NT, KH16 + PE16, 2>(ws, src, accB, ring, tid);
     else dense_x3r<NT, KH16, 2>(ws, src, accB, ring, tid);
 #pragma unroll
@@ -118,8 +122,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep1_kernel(SdfBwdArgs a) {
   }
   {
     const int l = a.L - 1;
-    X3rSweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mc * H, a.abars + (l - 1) * lstride + mc * H,
-                                    a.gas + (l - 1) * lstride + m * H, a.gus + l * lstride + m * H, hi, valid};
+    X3rSweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
+                                    a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, hi, valid, kcs};
     x3r_drain<KH16>(src, ring, tid);
   }
 }
@@ -135,6 +139,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep2_kernel(SdfBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   const float sb = a.sbar ? a.sbar[mc] : 0.f;
   if (valid && hi == 0) {
     *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
@@ -162,8 +168,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep2_kernel(SdfBwdArgs a) {
   }
   for (int l = a.L - 2; l >= 1; --l) {
     // G(a_l) = upstream * sigma_l + G2(a_l), then W_l^T G(a_l)
-    X3rSweep2Src<NT, false> src{accA, a.hs + l * lstride + mc * H, a.gas + l * lstride + mc * H, a.gas + l * lstride + m * H, hi, valid,
-                                0.f, nullptr};
+    X3rSweep2Src<NT, false> src{accA, a.hs + l * lstride + mcrow, a.gas + l * lstride + mcrow, a.gas + l * lstride + mrow, hi, valid,
+                                0.f, nullptr, kcs};
     zero_tiles<NT>(accB);
     dense_x3r<NT, KH16, 0>(ws, src, accB, ring, tid);
     if (l == a.skip) ws.skip(x3_bwd_chunks(PT, KH16) / SC, tid);      // the PE rows of W_skip^T are not needed here
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep2_kernel(SdfBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3rSweep2Src<NT, false> src{accA, a.hs + mc * H, a.gas + mc * H, a.gas + m * H, hi, valid, 0.f, nullptr};     // G(a_0)
+    X3rSweep2Src<NT, false> src{accA, a.hs + mcrow, a.gas + mcrow, a.gas + mrow, hi, valid, 0.f, nullptr, kcs};     // G(a_0)
     x3r_drain<KH16>(src, ring, tid);
   }
 }
@@ -188,6 +194,8 @@ __global__ __launch_bounds__(256) void rgb_bwd3r_kernel(RgbBwdArgs a) {
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
+  const int kcs = a.kcs;
+  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
   float g3[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -199,8 +207,8 @@ __global__ __launch_bounds__(256) void rgb_bwd3r_kernel(RgbBwdArgs a) {
   {
     // top mask operand r_{L-1}: loaded before the weight stream starts (ordinary loads must not follow a DMA in flight)
     const int l = a.L - 2;
-    const float* rrow = a.rs + l * lstride + mc * H;
-    load_regs<KC>(rrow, hi, ga);
+    const float* rrow = a.rs + l * lstride + mcrow;
+    load_regs<KC>(rrow, hi, ga, kcs);
   }
   WStream ws;
   ws.begin(a.rev, lds, a.n_rev, tid);
@@ -227,13 +235,13 @@ __global__ __launch_bounds__(256) void rgb_bwd3r_kernel(RgbBwdArgs a) {
       }
     }
     const int l = a.L - 2;
-    float* grow = a.gar + l * lstride + m * H;
+    float* grow = a.gar + l * lstride + mrow;
 #pragma unroll
     for (int c = 0; c < KC; ++c) {
       f32x4 o;
 #pragma unroll
       for (int t = 0; t < 4; ++t) { o[t] = ga[c * 4 + t] > 0.f ? acc1[c * 4 + t] : 0.f; ga[c * 4 + t] = o[t]; }
-      if (valid) *reinterpret_cast<f32x4*>(grow + 8 * c + 4 * hi) = o;
+      if (valid) *reinterpret_cast<f32x4*>(grow + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi) = o;
     }
   }
   f32x16 accA[NT], accB[NT];
@@ -243,14 +251,14 @@ __global__ __launch_bounds__(256) void rgb_bwd3r_kernel(RgbBwdArgs a) {
     dense_x3r<NT, KH16, 0>(ws, src, accA, ring, tid);            // W_{L-2}^T G(a_{L-2})
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    X3rMaskSrc<NT> src{accA, a.rs + l * lstride + mc * H, a.gar + l * lstride + m * H, hi, valid};
+    X3rMaskSrc<NT> src{accA, a.rs + l * lstride + mcrow, a.gar + l * lstride + mrow, hi, valid, kcs};
     zero_tiles<NT>(accB);
     dense_x3r<NT, KH16, 0>(ws, src, accB, ring, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3rMaskSrc<NT> src{accA, a.rs + mc * H, a.gar + m * H, hi, valid};     // G(a_0), then the feature rows of W_0^T
+    X3rMaskSrc<NT> src{accA, a.rs + mcrow, a.gar + mrow, hi, valid, kcs};     // G(a_0), then the feature rows of W_0^T
     zero_tiles<NT>(accB);
     dense_x3r<FT, KH16, 0>(ws, src, accB, ring, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -16,7 +16,9 @@ constexpr int WG_CH = 1024;          // points per split-M chunk
 constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
 
-struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; };
+// A / B point at column a_c0 / b_c0 of the operand's first row in the POINT-MAJOR sense; a_blk / b_blk = leading points of the
+// operand tensor stored in the blocked layout (mlp_common.h; only 256-wide tensors, accessed as 128-column tiles, are ever blocked)
+struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; int64_t a_blk, b_blk; int32_t a_c0, b_c0; };
 struct WgTask {
   WgJob j[2];
   int32_t njobs, relu_b, has_bias, rows_store, cols_store, ldo;
@@ -66,6 +68,20 @@ __device__ __forceinline__ void wgrad_accumulate(const WgTask& t, int64_t lo, in
       b_off[0] = (4 * i32 < job.b_w) ? (unsigned)((hi * job.ldb + 4 * i32) * 4) : OOB;
     }
     const unsigned a_step = 2u * job.lda * 4u, b_step = 2u * job.ldb * 4u;
+    // The 16-B-per-lane operands (128-column tiles of 256-wide tensors) may be stored blocked (mlp_common.h).  Chunks start on a
+    // tile boundary, so the chunk's base address is the same in both layouts: point r of the chunk sits at (r/32)*8192 + (r%32)*16
+    // floats, column c at (c/16)*512 + c%16 (blocked) or at r*ld + c (point-major).  One descriptor over the chunk serves both;
+    // the offset is SELECTED (no branch in the load groups), rows beyond the job and columns beyond the width read as 0 (OOB).
+    const bool ablk = !AM && m_lo < job.a_blk, bblk = !BM && m_lo < job.b_blk;
+    const unsigned a_cb = ablk ? (unsigned)((((job.a_c0 + 4 * i32) >> 4) * 512 + ((4 * i32) & 15)) * 4) : (unsigned)((job.a_c0 + 4 * i32) * 4);
+    const unsigned b_cb = bblk ? (unsigned)((((job.b_c0 + 4 * i32) >> 4) * 512 + ((4 * i32) & 15)) * 4) : (unsigned)((job.b_c0 + 4 * i32) * 4);
+    const __amdgpu_buffer_rsrc_t ra_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A - job.a_c0 + m_lo * job.lda), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.B - job.b_c0 + m_lo * job.ldb), 0, 0x7ffffff0, 0x00020000);
+    auto off16 = [&](unsigned cb, bool is_blk, unsigned ld, unsigned pn, bool col_ok) -> unsigned {
+      const unsigned r = 2u * pn + (unsigned)hi;
+      const unsigned ro = is_blk ? ((r >> 5) * 8192u + (r & 31u) * 16u) * 4u : r * ld * 4u;
+      return (col_ok && (int)r < rows) ? cb + ro : OOB;
+    };
     const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;           // branch-free optional ReLU on the B operand
     const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;       // branch-free optional column sums of A
     // Group double buffering: while the MFMAs of one group of point pairs run, the loads of the NEXT group are in flight.
@@ -79,7 +95,7 @@ __device__ __forceinline__ void wgrad_accumulate(const WgTask& t, int64_t lo, in
         const unsigned pn = pbase + u;
         if (AM) A[u][0] = ldw(ra, a_off, pn * a_step);
         else {
-          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_off == OOB ? OOB : a_off + pn * a_step, 0, 0));
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_b, off16(a_cb, ablk, (unsigned)job.lda, pn, a_off != OOB), 0, 0));
 #pragma unroll
           for (int q = 0; q < TA; ++q) A[u][q] = x[q];
         }
@@ -87,7 +103,7 @@ __device__ __forceinline__ void wgrad_accumulate(const WgTask& t, int64_t lo, in
 #pragma unroll
           for (int tb = 0; tb < TB; ++tb) Bv[u][tb] = ldw(rb, b_off[tb < (BM ? BM : 1) ? tb : 0], pn * b_step);
         } else {
-          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[0] == OOB ? OOB : b_off[0] + pn * b_step, 0, 0));
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb_b, off16(b_cb, bblk, (unsigned)job.ldb, pn, b_off[0] != OOB), 0, 0));
 #pragma unroll
           for (int q = 0; q < TB; ++q) Bv[u][q] = x[q];
         }
@@ -270,24 +286,50 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     const int nst = (rows + W3_PTS - 1) / W3_PTS;
     const float* dbase = (opB ? job.B : job.A) + m_lo * (opB ? job.ldb : job.lda) + 128 * (w & 1) + 4 * i32;
     const int dld = opB ? job.ldb : job.lda;
+    // Blocked operand (mlp_common.h): a 16-point stage x one 16-wide k-chunk is ONE contiguous 1 KB run, i.e. one DMA piece.
+    // Piece j of this wave's quarter = k-chunk 8*(w&1)+j; lane L fetches column quad L&3 of point
+    // 4*(L>>4) + 2*(((L>>3)&1) ^ (j&1)) + (((L>>2)&1) ^ ((j>>1)&1)): every aligned group of 8 lanes still fetches one whole 128 B line
+    // (two neighbouring points), and the swap pattern puts the four k-chunks a 16-lane group reads later into different LDS
+    // banks (conflict-free ds_read_b128).
+    const bool blk = m_lo < (opB ? job.b_blk : job.a_blk);
+    const float* bbase = (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * (w & 1)) * 512 + 4 * (lane & 3);
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    // raw rows of stage s: 8 DMA pieces of this wave's quarter (clamped rows are masked when they are split)
+    // raw rows of stage s: 8 DMA pieces of this wave's quarter (clamped rows are masked when they are split).  Branch-free in
+    // `blk` (a scalar branch inside the stage loop would cut the MFMA / split interleave into basic blocks): per piece j the lane's
+    // point of the stage is rj[j], and the row's float offset is selected from the two layouts
+    int rj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      rj[j] = blk ? 4 * (lane >> 4) + 2 * (((lane >> 3) & 1) ^ (j & 1)) + (((lane >> 2) & 1) ^ ((j >> 1) & 1)) : 8 * kg + j;
+    const float* fbase = blk ? bbase : dbase;
+    const int pstep = blk ? 512 : 0;              // blocked: piece j is k-chunk j of the quarter
     auto issue = [&](int s) __attribute__((always_inline)) {
       float* dst = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        int row = s * W3_PTS + 8 * kg + j;
+        int row = s * W3_PTS + rj[j];
         row = row < rows ? row : rows - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dbase + (int64_t)row * dld),
+        const int64_t off = blk ? (int64_t)((row >> 5) * 8192 + (row & 31) * 16) : (int64_t)row * dld;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fbase + off + j * pstep),
                                          (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
       }
     };
+    // LDS float offsets (inside this wave's 8 pieces) of the two points of pair i for this lane
+    int olo[4], ohi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = i32 >> 2, q = i32 & 3, pt = 8 * kg + 2 * i;
+      // position of (point pt, quad q) inside piece j as the fetch laid it out (pt is even: pt + 1 only flips the lowest bit)
+      const int pos = 16 * (pt >> 2) + 8 * (((pt >> 1) & 1) ^ (j & 1)) + 4 * ((j >> 1) & 1) + q;
+      olo[i] = blk ? j * 256 + pos * 4 : (2 * i) * 256 + lane * 4;
+      ohi[i] = blk ? j * 256 + (pos ^ 4) * 4 : (2 * i + 1) * 256 + lane * 4;
+    }
     unsigned pl[4][3][4];                 // planes of the quarter being split: [tile][plane][point pair]
     // point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: read raw, mask / relu / bias sums, split
     auto split_pair = [&](int s, int i) __attribute__((always_inline)) {
-      const float* src = rawb + (s & 1) * W3P_RAW + (w * 8 + 2 * i) * 256 + lane * 4;
-      f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi_ = *reinterpret_cast<const f32x4*>(src + 256);
+      const float* src = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(src + olo[i]), hi_ = *reinterpret_cast<const f32x4*>(src + ohi[i]);
       const int p0 = s * W3_PTS + 8 * kg + 2 * i;
       const float k0 = p0 < rows ? 1.f : 0.f, k1 = p0 + 1 < rows ? 1.f : 0.f;
 #pragma unroll
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct Src { const float* p; int ld; int w; };     // a [Mp][ld] matrix and the width used from it
+struct Src { const float* p; int ld; int w; int64_t blk = 0; };     // a [Mp][ld] matrix, the width used from it, blocked-prefix points
 
 struct TaskList {
   std::vector<WgTask> tasks;
@@ -461,10 +503,10 @@ struct TaskList {
         for (size_t i = 0; i < A0.size(); ++i) {
           if (A0[i].w != 256) continue;
           WgTask t{};
-          t.j[0] = WgJob{A0[i].p, B0[k].p, A0[i].ld, B0[k].ld, 256, 256, mA0[i]};
+          t.j[0] = WgJob{A0[i].p, B0[k].p, A0[i].ld, B0[k].ld, 256, 256, mA0[i], A0[i].blk, B0[k].blk, 0, 0};
           t.njobs = 1;
           if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
-            t.j[1] = WgJob{A1[i].p, B1[k].p, A1[i].ld, B1[k].ld, 256, 256, m1};
+            t.j[1] = WgJob{A1[i].p, B1[k].p, A1[i].ld, B1[k].ld, 256, 256, m1, A1[i].blk, B1[k].blk, 0, 0};
             t.njobs = 2;
           }
           t.relu_b = relu_b ? 1 : 0;
@@ -481,10 +523,10 @@ struct TaskList {
           for (int rt = 0; rt * 128 < A0[i].w; ++rt) {
             WgTask t{};
             const int aw = std::min(128, A0[i].w - rt * 128), bw = std::min(128, B0[k].w - ct * 128);
-            t.j[0] = WgJob{A0[i].p + rt * 128, B0[k].p + ct * 128, A0[i].ld, B0[k].ld, aw, bw, mA0[i]};
+            t.j[0] = WgJob{A0[i].p + rt * 128, B0[k].p + ct * 128, A0[i].ld, B0[k].ld, aw, bw, mA0[i], A0[i].blk, B0[k].blk, rt * 128, ct * 128};
             t.njobs = 1;
             if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
-              t.j[1] = WgJob{A1[i].p + rt * 128, B1[k].p + ct * 128, A1[i].ld, B1[k].ld, aw, bw, m1};
+              t.j[1] = WgJob{A1[i].p + rt * 128, B1[k].p + ct * 128, A1[i].ld, B1[k].ld, aw, bw, m1, A1[i].blk, B1[k].blk, rt * 128, ct * 128};
               t.njobs = 2;
             }
             t.relu_b = relu_b ? 1 : 0;
@@ -542,15 +584,16 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     const i2sdf_mlp_desc& d = np.d;
     const int L = d.n_lin, H = d.hidden, F = p->F, PEC8 = cdiv(d.in0, 8) * 8;
     const int64_t ls = Mp * H;
+    const int64_t bs = (H == 256) ? sdf_blocked_points(p, Ms, Mp) : 0;      // leading points of hs / abars / gus / gas in the blocked layout
     for (int l = 0; l < L - 1; ++l) {
       std::vector<Src> B0, B1;
       if (l == 0) { B0 = {{tb->pe, PEC8, PEC8}}; B1 = {{tb->gpbar, PEC8, PEC8}}; }
       else {
-        B0 = {{tb->hs + (l - 1) * ls, H, H}}; B1 = {{tb->gus + l * ls, H, H}};
+        B0 = {{tb->hs + (l - 1) * ls, H, H, bs}}; B1 = {{tb->gus + l * ls, H, H, bs}};
         if (l == d.skip_layer) { B0.push_back({tb->pe, PEC8, PEC8}); B1.push_back({tb->gpbar, PEC8, PEC8}); }
       }
       tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l],
-                   {{tb->gas + l * ls, H, H}}, {{tb->abars + l * ls, H, H}}, {0}, {Ms}, B0, B1, Ms, false);
+                   {{tb->gas + l * ls, H, H, bs}}, {{tb->abars + l * ls, H, H, bs}}, {0}, {Ms}, B0, B1, Ms, false);
     }
     {
       const int l = L - 1;
@@ -559,7 +602,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       std::vector<int64_t> mA0 = {Ms};
       if (F > 0 && Mm > 0 && tb->fbar) { A0.push_back({tb->fbar, F, F}); A1.push_back({nullptr, 0, 0}); row0.push_back(32); mA0.push_back(Mm); }
       tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l], A0, A1, row0, mA0,
-                   {{tb->hs + (L - 2) * ls, H, H}}, {{tb->gus + (L - 1) * ls, H, H}}, Ms, false);
+                   {{tb->hs + (L - 2) * ls, H, H, bs}}, {{tb->gus + (L - 1) * ls, H, H, bs}}, Ms, false);
     }
   }
   if (Mm > 0 && tb->gar) {  // ---- radiance net
@@ -567,12 +610,13 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     const i2sdf_mlp_desc& d = np.d;
     const int L = d.n_lin, H = d.hidden, F = p->F, PV8 = cdiv(d.in0 - F, 8) * 8;
     const int64_t ls = Mp * H;
+    const int64_t br = (H == 256) ? rgb_blocked_points(p, Mm, Mp) : 0;     // leading points of rs / gar in the blocked layout
     for (int l = 0; l < L; ++l) {
       std::vector<Src> B0;
       if (l == 0) B0 = {{tb->pev, PV8, PV8}, {tb->feat, F, F}};
-      else B0 = {{tb->rs + (l - 1) * ls, H, H}};
+      else B0 = {{tb->rs + (l - 1) * ls, H, H, br}};
       std::vector<Src> A0;
-      if (l < L - 1) A0 = {{tb->gar + l * ls, H, H}};
+      if (l < L - 1) A0 = {{tb->gar + l * ls, H, H, br}};
       else A0 = {{tb->ga_last_rgb, 4, 4}};
       tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l], A0, {}, {0}, {Mm}, B0, {}, 0,
                    false);

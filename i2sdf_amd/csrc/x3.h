@@ -208,7 +208,7 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
-  const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc < KACC) return softplus100(accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u]);
@@ -216,8 +216,8 @@ struct X3FwdSrc {
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (kc < KACC && hrow != nullptr && valid) {
-      *reinterpret_cast<f32x4*>(hrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(hrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(hrow + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(hrow + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
 };
@@ -234,33 +234,34 @@ struct X3RegSrc {
 template <int NT>
 struct X3RevSrc {
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    hq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 4 * hi);
-    hq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(hrow + 16 * kc + 8 + 4 * hi);
+    hq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(hrow + kcs * kc + 4 * hi);
+    hq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(hrow + kcs * kc + 8 + 4 * hi);
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (abrow != nullptr && valid) {
-      *reinterpret_cast<f32x4*>(abrow + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(abrow + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(abrow + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(abrow + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
     }
   }
 };
 
 
 // ---- sources of the backward sweeps (appendix A.3) ------------------------------------------------------------------
-// two f32x4 of a point-major row covering this lane's 8 reduction indices of k-chunk kc
-__device__ __forceinline__ void x3_load8(const float* row, int kc, int hi, f32x4 (&q)[2]) {
-  q[0] = *reinterpret_cast<const f32x4*>(row + 16 * kc + 4 * hi);
-  q[1] = *reinterpret_cast<const f32x4*>(row + 16 * kc + 8 + 4 * hi);
+// two f32x4 of a row covering this lane's 8 reduction indices of k-chunk kc; kcs = floats between consecutive k-chunks of the
+// row (16: point-major [M][256]; 512: blocked [M/32][16][32][16], mlp_common.h save_row_off)
+__device__ __forceinline__ void x3_load8(const float* row, int kc, int hi, f32x4 (&q)[2], int kcs = 16) {
+  q[0] = *reinterpret_cast<const f32x4*>(row + kcs * kc + 4 * hi);
+  q[1] = *reinterpret_cast<const f32x4*>(row + kcs * kc + 8 + 4 * hi);
 }
-__device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const float (&v)[8]) {
-  *reinterpret_cast<f32x4*>(row + 16 * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(row + 16 * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+__device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const float (&v)[8], int kcs = 16) {
+  *reinterpret_cast<f32x4*>(row + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(row + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
 }
 // sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
 //                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
@@ -268,10 +269,10 @@ template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
-  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
+  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2], aq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc % X3_RING]); x3_load8(arow, kc, hi, aq[kc % X3_RING]); }
+    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(arow, kc, hi, aq[kc % X3_RING], kcs); }
   }
   __device__ __forceinline__ float value(int kc, int u, float& g2) {
     g2 = 0.f;
@@ -282,7 +283,7 @@ struct X3Sweep1Src {
     return ga * sg;
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
-    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v); x3_store8(g2row, kc, hi, g2); }
+    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v, kcs); x3_store8(g2row, kc, hi, g2, kcs); }
   }
 };
 // sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
@@ -291,9 +292,10 @@ struct X3Sweep2Src {
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
+  int kcs = 16;
   f32x4 hq[X3_RING][2], gq[X3_RING][2], wq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    x3_load8(hrow, kc, hi, hq[kc % X3_RING]); x3_load8(g2row, kc, hi, gq[kc % X3_RING]);
+    x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(g2row, kc, hi, gq[kc % X3_RING], kcs);
     if (TOP) {
       wq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
       wq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
@@ -305,7 +307,7 @@ struct X3Sweep2Src {
     return fmaf(x, sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]), gq[kc % X3_RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v);
+    if (valid) x3_store8(grow, kc, hi, v, kcs);
   }
 };
 // a point-major row in global memory (or zeros) as B operand
@@ -326,11 +328,11 @@ struct X3RowSrc {
 template <int NT>
 struct X3ReluSrc {
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; float* rrow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; float* rrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) { return fmaxf(accP[kc >> 1][8 * (kc & 1) + u], 0.f); }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (rrow != nullptr && valid) x3_store8(rrow, kc, hi, v);
+    if (rrow != nullptr && valid) x3_store8(rrow, kc, hi, v, kcs);
   }
 };
 // layer-0 input of the radiance net: NPV k-chunks of PE(view dir) held in registers, then the feature row from global memory
@@ -349,14 +351,14 @@ struct X3PeRowSrc {
 template <int NT>
 struct X3MaskSrc {
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid; int kcs = 16;
   f32x4 q[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { x3_load8(rrow, kc, hi, q[kc % X3_RING]); }
+  __device__ __forceinline__ void ahead(int kc) { x3_load8(rrow, kc, hi, q[kc % X3_RING], kcs); }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     return q[kc % X3_RING][u >> 2][u & 3] > 0.f ? accP[kc >> 1][8 * (kc & 1) + u] : 0.f;
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v);
+    if (valid) x3_store8(grow, kc, hi, v, kcs);
   }
 };
 

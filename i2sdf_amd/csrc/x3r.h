@@ -47,9 +47,9 @@ __device__ __forceinline__ void x3r_dma16(const float* src, float* dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
 }
 // the two pieces of a point-major row that cover this lane's 8 reduction indices of k-chunk kc (x3_load8's addresses)
-__device__ __forceinline__ void x3r_issue8(const float* row, int kc, int hi, float* slot, int piece) {
-  x3r_dma16(row + 16 * kc + 4 * hi, slot + piece * 256);
-  x3r_dma16(row + 16 * kc + 8 + 4 * hi, slot + (piece + 1) * 256);
+__device__ __forceinline__ void x3r_issue8(const float* row, int kc, int hi, float* slot, int piece, int kcs = 16) {
+  x3r_dma16(row + kcs * kc + 4 * hi, slot + piece * 256);
+  x3r_dma16(row + kcs * kc + 8 + 4 * hi, slot + (piece + 1) * 256);
 }
 __device__ __forceinline__ void x3r_fetch8(const float* slot, int piece, int lane, f32x4 (&q)[2]) {
   q[0] = *reinterpret_cast<const f32x4*>(slot + piece * 256 + lane * 4);
@@ -253,13 +253,13 @@ template <int NT>
 struct X3rRevSrc {
   static constexpr int NLD = 2;
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[2];
-  __device__ __forceinline__ void issue(int kc, float* slot) { x3r_issue8(hrow, kc, hi, slot, 0); }
+  __device__ __forceinline__ void issue(int kc, float* slot) { x3r_issue8(hrow, kc, hi, slot, 0, kcs); }
   __device__ __forceinline__ void fetch(int, const float* slot, int lane) { x3r_fetch8(slot, 0, lane, hq); }
   __device__ __forceinline__ float value(int kc, int u, float&) { return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[u >> 2][u & 3]); }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (abrow != nullptr && valid) x3_store8(abrow, kc, hi, v);
+    if (abrow != nullptr && valid) x3_store8(abrow, kc, hi, v, kcs);
   }
 };
 // backward sweep 1 (see X3Sweep1Src)
@@ -268,13 +268,13 @@ struct X3rSweep1Src {
   static constexpr int NLD = KACC > 0 ? 4 : 0;
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];
-  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid;
+  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[2], aq[2];
   __device__ __forceinline__ void issue(int kc, float* slot) {
     // k-chunks >= KACC come from registers; their (unused) pieces re-read the last row chunk so that every k-chunk issues NLD reads
     const int kk = kc < KACC ? kc : KACC - 1;
-    x3r_issue8(hrow, kk, hi, slot, 0);
-    x3r_issue8(arow, kk, hi, slot, 2);
+    x3r_issue8(hrow, kk, hi, slot, 0, kcs);
+    x3r_issue8(arow, kk, hi, slot, 2, kcs);
   }
   __device__ __forceinline__ void fetch(int kc, const float* slot, int lane) {
     if (kc < KACC) { x3r_fetch8(slot, 0, lane, hq); x3r_fetch8(slot, 2, lane, aq); }
@@ -288,20 +288,21 @@ struct X3rSweep1Src {
     return ga * sg;
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
-    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v); x3_store8(g2row, kc, hi, g2); }
+    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v, kcs); x3_store8(g2row, kc, hi, g2, kcs); }
   }
 };
 // backward sweep 2 (see X3Sweep2Src); TOP: + sbar * w_sdf, w_sdf read from the packed buffer (third DMA pair)
 template <int NT, bool TOP>
 struct X3rSweep2Src {
-  static constexpr int NLD = TOP ? 6 : 4;
+  static constexpr int NLD = 4;
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
-  float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
+  float sb; const float* wsdf;        // (TOP form unused by the ring kernels: sbar w_sdf is added to the upstream before the op)
+  int kcs = 16;
   f32x4 hq[2], gq[2], wq[2];
   __device__ __forceinline__ void issue(int kc, float* slot) {
-    x3r_issue8(hrow, kc, hi, slot, 0);
-    x3r_issue8(g2row, kc, hi, slot, 2);
+    x3r_issue8(hrow, kc, hi, slot, 0, kcs);
+    x3r_issue8(g2row, kc, hi, slot, 2, kcs);
   }
   __device__ __forceinline__ void fetch(int kc, const float* slot, int lane) {
     x3r_fetch8(slot, 0, lane, hq); x3r_fetch8(slot, 2, lane, gq);
@@ -312,7 +313,7 @@ struct X3rSweep2Src {
     return fmaf(x, sp_sigma_from_h(hq[u >> 2][u & 3]), gq[u >> 2][u & 3]);
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v);
+    if (valid) x3_store8(grow, kc, hi, v, kcs);
   }
 };
 // a point-major row in global memory (or zeros) as B operand
@@ -334,13 +335,13 @@ template <int NT>
 struct X3rMaskSrc {
   static constexpr int NLD = 2;
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid; int kcs = 16;
   f32x4 q[2];
-  __device__ __forceinline__ void issue(int kc, float* slot) { x3r_issue8(rrow, kc, hi, slot, 0); }
+  __device__ __forceinline__ void issue(int kc, float* slot) { x3r_issue8(rrow, kc, hi, slot, 0, kcs); }
   __device__ __forceinline__ void fetch(int, const float* slot, int lane) { x3r_fetch8(slot, 0, lane, q); }
   __device__ __forceinline__ float value(int kc, int u, float&) { return q[u >> 2][u & 3] > 0.f ? accP[kc >> 1][8 * (kc & 1) + u] : 0.f; }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v);
+    if (valid) x3_store8(grow, kc, hi, v, kcs);
   }
 };
 

@@ -43,8 +43,11 @@ class RenderEngine:
             if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
                 self.set_rgb_bf16x3(True)
         self.src_ring = False
-        if cfg.bf16x3 and os.environ.get("I2SDF_SRC_RING", "1") != "0":       # on by default; I2SDF_SRC_RING=0 for A/B runs
+        if cfg.bf16x3 and os.environ.get("I2SDF_SRC_RING", "0") != "0":       # off by default (no gain measured); I2SDF_SRC_RING=1 for A/B runs
             self.set_src_ring(True)
+        self.blocked_saves = False
+        if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
+            self.set_blocked_saves(True)
         self.tail_overlap = False
         if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
             self.set_tail_overlap(True)
@@ -135,6 +138,27 @@ class RenderEngine:
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.rgb_bf16x3 = bool(on)
 
+    def set_blocked_saves(self, on: bool):
+        """Saved 256-wide tensors of the bf16x3 full workgroups in the blocked layout (I2SDF_OPT_BLOCKED_SAVES, csrc/mlp_common.h).
+        Change it only between training steps: forward, backward and weight gradients of one step must agree."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_BLOCKED_SAVES, int(bool(on))), "i2sdf_plan_set_option")
+        self.blocked_saves = bool(on)
+
+    def blocked_points(self, which: int, M: int, Mp: int, has_feat: bool = True) -> int:
+        return int(self._lib.i2sdf_blocked_points(self._plan, which, M, Mp, int(has_feat)))
+
+    @staticmethod
+    def saved_to_point_major(t: torch.Tensor, n_blocked: int) -> torch.Tensor:
+        """A copy of a saved (layers, Mp, 256) tensor with ordinary rows (inspection / tests): the first n_blocked points are stored
+        [Mp/32][16 k-chunks][32 points][16 floats] (include/i2sdf.h: i2sdf_blocked_points)."""
+        if n_blocked <= 0:
+            return t.clone()
+        Lr, Mp, H = t.shape
+        assert H == 256 and n_blocked % 32 == 0
+        out = t.clone()
+        out[:, :n_blocked] = t[:, :n_blocked].reshape(Lr, n_blocked // 32, 16, 32, 16).permute(0, 1, 3, 2, 4).reshape(Lr, n_blocked, 256)
+        return out
+
     def set_src_ring(self, on: bool):
         """Saved-tensor reads of the bf16x3 kernels through the per-wave LDS DMA ring (I2SDF_OPT_SRC_RING, csrc/x3r.h)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SRC_RING, int(bool(on))), "i2sdf_plan_set_option")
@@ -189,7 +213,8 @@ class RenderEngine:
             dev = pts.device
         M = n_ray + (pts.shape[0] if pts is not None else 0)
         Mp = self.pad_rows(M)
-        out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z, npr), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev)}
+        out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z, npr), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev),
+               "blk": self.blocked_points(0, M, Mp, want_feat)}         # leading points of hs / abars in the blocked layout
         out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
         out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
         out["hs"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None

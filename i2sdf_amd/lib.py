@@ -70,6 +70,7 @@ OPT_SDF_BWD_BF16X3 = 8
 OPT_RGB_BF16X3 = 16
 OPT_TAIL_OVERLAP = 32
 OPT_SRC_RING = 64
+OPT_BLOCKED_SAVES = 128
 
 
 class I2SDFError(RuntimeError):
@@ -87,6 +88,7 @@ SIGNATURES = {
     "i2sdf_plan_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(_P)]),
     "i2sdf_plan_destroy": (None, [_P]),
     "i2sdf_plan_set_option": (C.c_int, [_P, _I32, _I32]),
+    "i2sdf_blocked_points": (_I64, [_P, _I32, _I64, _I64, _I32]),
     "i2sdf_plan_pack_floats": (_I64, [_P]),
     "i2sdf_plan_wgrad_floats": (_I64, [_P]),
     "i2sdf_pack_weights": (C.c_int, [_P, _P, _P, _P]),

@@ -101,6 +101,17 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   them through a per-wave LDS ring filled by DMA, several k-chunks ahead, with counted vmcnt waits (csrc/x3r.h): memory time
  *   overlaps matrix time instead of adding to it.  Same arithmetic, bitwise the same results.  Default 0. */
 #define I2SDF_OPT_SRC_RING 64
+/*   I2SDF_OPT_BLOCKED_SAVES: the 256-wide tensors saved for the backward (hs, abars, gus, gas, rs, gar) are stored in a blocked
+ *   layout [Mp/32][16 k-chunks][32 points][16 floats] for the points handled by the bf16x3 full workgroups (point-major for the
+ *   rest): a wave instruction of the K-outer kernels then moves one contiguous 2 KB run instead of touching 32 rows 1 KB apart.
+ *   Set it before the first i2sdf_sdf_forward_grad of a step and leave it unchanged through i2sdf_weight_grads; the tensors are
+ *   opaque to the caller (i2sdf_saved_rows_to_point_major converts a copy for inspection).  Default 0. */
+#define I2SDF_OPT_BLOCKED_SAVES 128
+/* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
+ * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
+ * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset
+ * (m/32)*8192 + (c/16)*512 + (m%32)*16 + c%16; points behind the count are ordinary rows m*256 + c. */
+int64_t i2sdf_blocked_points(const i2sdf_plan* plan, int32_t which, int64_t M, int64_t Mp, int32_t has_feat);
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);

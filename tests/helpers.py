@@ -185,20 +185,31 @@ def relu_flip_analysis(grads_fn, tau=1e-6, max_candidates=64):
     return base, cands, deltas
 
 
-def explain_by_relu_flips(err, deltas, scale):
-    """err, deltas[i]: {name: 1-D tensor} (same sampling), scale: {name: max |reference grad|}.  Finds the 0/1 combination of
-    candidate flips that best explains err (least squares, rounded) and returns (chosen indices, residual {name: max-norm rel})."""
+def explain_by_relu_flips(err, deltas, scale, max_flips=4):
+    """err, deltas[i]: {name: 1-D tensor} (same sampling), scale: {name: max |reference grad|}.  Greedy search for the set of
+    candidate flips (each applied whole: a backward mask is 0 or 1) that explains err: repeatedly apply the flip that lowers the
+    scaled max-norm of the residual the most, while it lowers it by at least a third.  Deterministic (no least squares: most
+    candidate columns are nearly zero).  Returns (chosen indices, residual {name: max-norm relative error})."""
     names = [n for n in err if scale[n] > 0]
     e = torch.cat([err[n].double() / scale[n] for n in names])
-    if not deltas:
-        return [], {n: float(err[n].abs().max()) / scale[n] for n in names}
-    A = torch.stack([torch.cat([d[n].double() / scale[n] for n in names]) for d in deltas], 1)
-    x = torch.linalg.lstsq(A, e.unsqueeze(1)).solution.squeeze(1)
-    chosen = [i for i, v in enumerate(x.tolist()) if v > 0.5]
-    r = e - (A[:, chosen].sum(1) if chosen else 0.0)
+    cols = [torch.cat([d[n].double() / scale[n] for n in names]) for d in deltas]
+    chosen = []
+    for _ in range(max_flips):
+        cur = float(e.abs().max())
+        best, best_val = None, cur
+        for i, c in enumerate(cols):
+            if i in chosen or float(c.abs().max()) < 1e-7:
+                continue
+            v = float((e - c).abs().max())
+            if v < best_val:
+                best, best_val = i, v
+        if best is None or best_val > cur * (2.0 / 3.0):
+            break
+        chosen.append(best)
+        e = e - cols[best]
     res, off = {}, 0
     for n in names:
         k = err[n].numel()
-        res[n] = float(r[off:off + k].abs().max())
+        res[n] = float(e[off:off + k].abs().max())
         off += k
     return chosen, res

@@ -23,7 +23,7 @@ def test_kernels_are_bitwise_reproducible(bf16x3):
     eng = make_engine(conf, sd)
     flat = eng.layout.flat_from_state_dict(sd).cuda()
     g = torch.Generator().manual_seed(6)
-    B, n = 420, 97                               # 42 000 points: bulk + split-K tail kernels, 42 weight-gradient chunks
+    B, n = 360, 97                               # 36 000 points: 256 full workgroups + 101 split-K tail workgroups, 36 weight-gradient chunks
     M = B * n + 3 * B
     x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.5).cuda()
     dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).cuda()
@@ -37,9 +37,12 @@ def test_kernels_are_bitwise_reproducible(bf16x3):
         bw = eng.sdf_backward(fwd, sbar=sb, fbar=fbar, m_fbar=B * n, nbar=nb)
         gflat = torch.zeros_like(flat)
         eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
-        cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": fwd["hs"][:, :M], "abars": fwd["abars"][:, :M],
-               "rgb": rgb_h, "rs": rs[:, :B * n], "gar": gar[:, :B * n], "fbar": fbar[:B * n], "gus": bw["gus"][1:, :M],
-               "gas": bw["gas"][:, :M], "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
+        # saved tensors in point-major form (the padding points of a blocked tile are never written: compare real points only)
+        pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]
+        assert eng.blocked_points(0, M, fwd["Mp"]) in (0, 256 * 128), "the batch must exercise bulk + split-K tail"
+        cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": pm(fwd["hs"], 0, M), "abars": pm(fwd["abars"], 0, M),
+               "rgb": rgb_h, "rs": pm(rs, 1, B * n), "gar": pm(gar, 1, B * n), "fbar": fbar[:B * n], "gus": pm(bw["gus"], 0, M)[1:],
+               "gas": pm(bw["gas"], 0, M), "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
         if ref is None:
             ref = {k: v.clone() for k, v in cur.items()}
             continue
@@ -59,8 +62,8 @@ def test_tail_overlap_changes_nothing(bf16x3):
     conf["bf16x3"] = bf16x3
     eng = make_engine(conf, sd)
     g = torch.Generator().manual_seed(8)
-    B, n = 420, 97
-    M = B * n + 3 * B                              # 42 000 points: 256 full workgroups + a 9 232-point split-K tail
+    B, n = 360, 97
+    M = B * n + 3 * B                              # 36 000 points: 256 full workgroups + a 3 232-point split-K tail (101 workgroups)
     x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.5).cuda()
     nb, sb = torch.randn(M, 3, generator=g).cuda(), torch.randn(M, generator=g).cuda()
     fb = torch.randn(B * n, 256, generator=g).cuda()
@@ -69,8 +72,9 @@ def test_tail_overlap_changes_nothing(bf16x3):
         fwd = eng.sdf_forward_grad(points=x)
         bw = eng.sdf_backward(fwd, sbar=sb, fbar=fb, m_fbar=B * n, nbar=nb)
         # consumers on the caller's stream right behind the entry points: they must see the tail's results
-        return {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "hs": fwd["hs"][:, :M].clone(),
-                "abars": fwd["abars"][:, :M].clone(), "gus": bw["gus"][1:, :M].clone(), "gas": bw["gas"][:, :M].clone()}
+        pm = lambda t_: eng.saved_to_point_major(t_, fwd["blk"])[:, :M]       # real points only (padding points of a blocked tile are never written)
+        return {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "hs": pm(fwd["hs"]),
+                "abars": pm(fwd["abars"]), "gus": pm(bw["gus"])[1:], "gas": pm(bw["gas"])}
 
     eng.set_tail_overlap(False)
     ref = run()

@@ -44,11 +44,12 @@ def test_sdf_forward_grad_and_saves(which):
     assert_close(out["sdf"].cpu(), fw["sdf"], TOL, "sdf")
     assert_close(out["feat"][:M].cpu(), fw["feat"], TOL, "feature")
     assert_close(out["grad"].cpu(), fw["n"], TOL, "d sdf/dx")
+    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_to_point_major(out["abars"], out["blk"])
     for l in range(L - 1):
         ref_h = orc.softplus100(fw["a"][l])
         w = ref_h.shape[1]
-        assert_close(out["hs"][l, :M, :w].cpu(), ref_h, TOL, f"h_{l+1}")
-        assert_close(out["abars"][l, :M, :w].cpu(), fw["abar"][l], TOL, f"abar_{l}")
+        assert_close(hs_pm[l, :M, :w].cpu(), ref_h, TOL, f"h_{l+1}")
+        assert_close(ab_pm[l, :M, :w].cpu(), fw["abar"][l], TOL, f"abar_{l}")
 
 
 def test_sdf_forward_grad_ray_mode_matches_point_mode():
@@ -128,7 +129,8 @@ def test_rgb_forward_split_k_tail():
     x = torch.cat([orc.positional_encode(dirs.double()[idx // n], 4), feat.double()[idx]], -1)
     W0 = orc.effective_weight(dbl(sd), "rendering_network.lin0")
     r1 = torch.relu(x @ W0.t() + sd["rendering_network.lin0.bias"].double())
-    assert_close(rs[0].cpu()[idx], r1, TOL, "r_1")
+    rs_pm = eng.saved_to_point_major(rs, eng.blocked_points(1, M, Mp))
+    assert_close(rs_pm[0].cpu()[idx], r1, TOL, "r_1")
     assert_close(pev.cpu()[idx][:, :27], orc.positional_encode(dirs.double()[idx // n], 4), 1e-6, "PE(view)")
 
 
@@ -150,8 +152,10 @@ def test_sdf_forward_grad_split_k_tail(light):
     assert_close(out["feat"].cpu()[idx], fw["feat"], TOL, "feature")
     assert_close(out["grad"].cpu()[idx], fw["n"], TOL, "d sdf/dx")
     assert_close(out["pe"].cpu()[idx][:, :39], fw["p"], 1e-6, "PE")
+    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_to_point_major(out["abars"], out["blk"])
+    assert out["blk"] in (0, 256 * 128), "blocked prefix = the points of the full workgroups"
     for l in range(L - 1):
         ref_h = orc.softplus100(fw["a"][l])
         wd = ref_h.shape[1]
-        assert_close(out["hs"][l].cpu()[idx][:, :wd], ref_h, TOL, f"h_{l+1}")
-        assert_close(out["abars"][l].cpu()[idx][:, :wd], fw["abar"][l], TOL, f"abar_{l}")
+        assert_close(hs_pm[l].cpu()[idx][:, :wd], ref_h, TOL, f"h_{l+1}")
+        assert_close(ab_pm[l].cpu()[idx][:, :wd], fw["abar"][l], TOL, f"abar_{l}")
