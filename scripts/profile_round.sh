@@ -1,11 +1,12 @@
 #!/bin/bash
 # Refresh profiles/: rocprofv3 kernel stats of the default bench command + PMC passes (counters only, separate runs).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r1}
+R=${1:-r2}
+BARGS="--no-cpu-baseline --no-extras --scaling weak"     # the headline workload only (same kernels as the default command)
 O=gpurun_out/profiles_$R
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O -o ${R}_bench --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${R}_bench_under_rocprof.log 2>&1
-run() { rocprofv3 --kernel-trace --pmc $2 -d $O -o ${R}_$1 --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${R}_$1.log 2>&1; }
+rocprofv3 --kernel-trace --stats -d $O -o ${R}_bench --output-format csv -- python bench.py --steps 5 --warmup 2 $BARGS > $O/${R}_bench_under_rocprof.log 2>&1
+run() { rocprofv3 --kernel-trace --pmc $2 -d $O -o ${R}_$1 --output-format csv -- python bench.py --steps 2 --warmup 1 $BARGS > $O/${R}_$1.log 2>&1; }
 run sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"

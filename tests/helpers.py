@@ -27,12 +27,14 @@ def rel_max(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def assert_close(a, b, tol, what=""):
+def assert_close(a, b, tol, what="", floor=0.0):
+    """max-norm relative error <= tol.  `floor`: lower bound of the denominator, for quantities with a natural O(1) scale whose
+    reference can be ~0 on a particular batch (e.g. the colours of rays that all miss the geometry)."""
     a_ = torch.as_tensor(a).detach().cpu()
     b_ = torch.as_tensor(b).detach().cpu()
     assert a_.shape == b_.shape, f"{what}: shape {tuple(a_.shape)} vs {tuple(b_.shape)}"
     assert torch.isfinite(a_.double()).all(), f"{what}: non-finite values"
-    err = rel_max(a_, b_)
+    err = rel_max(a_, b_) if floor <= 0 else float((a_.double() - b_.double()).abs().max() / max(float(b_.double().abs().max()), floor))
     assert err <= tol, f"{what}: max-norm relative error {err:.3e} > {tol:.1e}"
     return err
 

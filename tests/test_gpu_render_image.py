@@ -87,8 +87,10 @@ def test_render_image_chunks_vs_oracle():
         z = full["z_vals"][lo:hi].cpu()[S].to(D)
         ref = orc.network_forward(sd64, ocfg, {"uv": sub["uv"][:, S].to(D), "intrinsics": sub["intrinsics"].to(D), "pose": sub["pose"].to(D)},
                                   training=False, z_override=(z, z[:, :1]))
+        # rgb / weight_sum live in [0, 1] and depth in [0, 2R]: a chunk whose rays all miss the sphere (the top and bottom rows of the
+        # view) has references of ~1e-6, so the error is taken relative to max(|ref|, 1e-2) there
         for k in ("rgb_values", "depth_values", "weight_sum"):
-            assert_close(full[k][lo:hi].cpu()[S], ref[k], 1e-4, f"chunk {ci} {k}")
+            assert_close(full[k][lo:hi].cpu()[S], ref[k], 1e-4, f"chunk {ci} {k}", floor=1e-2)
         hit = ref["weight_sum"].reshape(-1) > 1e-2
         if bool(hit.any()):
             assert_close(full["normal_map"][lo:hi].cpu()[S][hit], ref["normal_map"][hit], 1e-4, f"chunk {ci} normal_map (weight_sum > 0.01)")
