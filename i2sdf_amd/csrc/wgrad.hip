@@ -260,8 +260,10 @@ constexpr int W3P_RAW = 2 * W3_PTS * 256;                 // floats per raw stag
 constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
 constexpr int W3P_LDS_BYTES = (2 * W3P_RAW + 2 * W3P_PL) * 4;
 
-__global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time, so that the point-major
+// instance keeps the round-1 code exactly: runtime selects cost 5 % here through a worse MFMA / split interleave)
+template <bool BLKA, bool BLKB>
+__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   float* rawb = lds;
   float* plb = lds + 2 * W3P_RAW;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     // 4*(L>>4) + 2*(((L>>3)&1) ^ (j&1)) + (((L>>2)&1) ^ ((j>>1)&1)): every aligned group of 8 lanes still fetches one whole 128 B line
     // (two neighbouring points), and the swap pattern puts the four k-chunks a 16-lane group reads later into different LDS
     // banks (conflict-free ds_read_b128).
-    const bool blk = m_lo < (opB ? job.b_blk : job.a_blk);
+    const bool blk = opB ? BLKB : BLKA;        // (host: both jobs of a task share the operands' layouts)
+    const bool blk_lds = blk, blk_glb = blk;
     const float* bbase = (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * (w & 1)) * 512 + 4 * (lane & 3);
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
@@ -301,16 +304,16 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     int rj[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      rj[j] = blk ? 4 * (lane >> 4) + 2 * (((lane >> 3) & 1) ^ (j & 1)) + (((lane >> 2) & 1) ^ ((j >> 1) & 1)) : 8 * kg + j;
-    const float* fbase = blk ? bbase : dbase;
-    const int pstep = blk ? 512 : 0;              // blocked: piece j is k-chunk j of the quarter
+      rj[j] = blk_glb ? 4 * (lane >> 4) + 2 * (((lane >> 3) & 1) ^ (j & 1)) + (((lane >> 2) & 1) ^ ((j >> 1) & 1)) : 8 * kg + j;
+    const float* fbase = blk_glb ? bbase : dbase;
+    const int pstep = blk_glb ? 512 : 0;              // blocked: piece j is k-chunk j of the quarter
     auto issue = [&](int s) __attribute__((always_inline)) {
       float* dst = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         int row = s * W3_PTS + rj[j];
         row = row < rows ? row : rows - 1;
-        const int64_t off = blk ? (int64_t)((row >> 5) * 8192 + (row & 31) * 16) : (int64_t)row * dld;
+        const int64_t off = blk_glb ? (int64_t)((row >> 5) * 8192 + (row & 31) * 16) : (int64_t)row * dld;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fbase + off + j * pstep),
                                          (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
       }
@@ -322,8 +325,8 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
       const int j = i32 >> 2, q = i32 & 3, pt = 8 * kg + 2 * i;
       // position of (point pt, quad q) inside piece j as the fetch laid it out (pt is even: pt + 1 only flips the lowest bit)
       const int pos = 16 * (pt >> 2) + 8 * (((pt >> 1) & 1) ^ (j & 1)) + 4 * ((j >> 1) & 1) + q;
-      olo[i] = blk ? j * 256 + pos * 4 : (2 * i) * 256 + lane * 4;
-      ohi[i] = blk ? j * 256 + (pos ^ 4) * 4 : (2 * i + 1) * 256 + lane * 4;
+      olo[i] = blk_lds ? j * 256 + pos * 4 : (2 * i) * 256 + lane * 4;
+      ohi[i] = blk_lds ? j * 256 + (pos ^ 4) * 4 : (2 * i + 1) * 256 + lane * 4;
     }
     unsigned pl[4][3][4];                 // planes of the quarter being split: [tile][plane][point pair]
     // point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: read raw, mask / relu / bias sums, split
@@ -405,6 +408,17 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     for (int tt = 0; tt < 4; ++tt) bsum[tt] += __shfl_xor(bsum[tt], 32);
     if (kg == 0) *reinterpret_cast<f32x4*>(out + t.bias_off + (w & 1) * 128 + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
   }
+}
+
+__global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WgJob& j0 = L.t[blockIdx.y].j[0];
+  const int64_t m_lo = (int64_t)blockIdx.x * WG_CH;
+  const bool ba = m_lo < j0.a_blk, bb = m_lo < j0.b_blk;       // workgroup-uniform
+  if (ba && bb) wgrad3p_body<true, true>(L, lds);
+  else if (ba) wgrad3p_body<true, false>(L, lds);
+  else if (bb) wgrad3p_body<false, true>(L, lds);
+  else wgrad3p_body<false, false>(L, lds);
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------

@@ -125,9 +125,28 @@ def attach_data_parallel(net, group=None, equivalent: bool = False, native=None)
     the gradients would be reduced twice -- this hook IS the data-parallel strategy of the module.  Under
     gradient accumulation use `with no_sync(net):` for all but the last micro-batch, as with DDP."""
     world = dist.get_world_size(group)
+    explicit = native is True
     if native is None:
         native = dist.get_backend(group) == "nccl"
-    comm = RcclComm(group) if native else None
+    comm = None
+    if native:
+        # all ranks must end up on the same transport: create the communicator, then agree on the outcome through the group
+        err = None
+        try:
+            comm = RcclComm(group)
+        except Exception as e:       # RCCL not loadable / init failed on this rank
+            err = e
+        ok = torch.tensor([0.0 if comm is None else 1.0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if float(ok.item()) < 1.0:
+            if comm is not None:
+                comm.close()
+                comm = None
+            if explicit:
+                raise RuntimeError(f"i2sdf_amd.dist: the library's RCCL communicator could not be created on every rank ({err})")
+            import warnings
+            warnings.warn(f"i2sdf_amd.dist: library RCCL communicator unavailable ({err}); the gradient mean goes through "
+                          "torch.distributed.all_reduce (same collective, torch's communicator)")
     xchg = None
     if equivalent:
         xchg = comm if comm is not None else TorchExchange(group)
