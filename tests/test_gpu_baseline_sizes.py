@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 D = torch.float64
 
 
-def _build(train, seed=61, beta=0.02):
+def _build(train, seed=61, beta=0.02, light=False):
     from i2sdf_amd import I2SDFNetwork, synthetic_conf
-    conf = dict(synthetic_conf(False))
+    conf = dict(synthetic_conf(light))
     conf["use_normal"] = True
-    ocfg = orc.synthetic_cfg(False)
+    ocfg = orc.synthetic_cfg(light)
     ocfg.use_normal = True
     sd = orc.perturb_params(orc.init_params(ocfg, seed=seed), 0.03, seed=seed + 1)
     sd["density.beta"] = torch.tensor(beta)
@@ -50,9 +50,10 @@ def _check_depths(z_all, far=6.0):
     assert float(z.min()) >= 0.0 and float(z.max()) <= far and bool((z[:, -1] == far).all())
 
 
-@pytest.mark.parametrize("B", [1024, 1600, 4096])
-def test_training_step_full_size(B):
-    net, ocfg, sd = _build(True)
+@pytest.mark.parametrize("B,light", [(1024, False), (1024, True), (1600, False), (4096, False)])
+def test_training_step_full_size(B, light):
+    """(1024, light=True) is BASELINE config 3: synthetic_light_mask.yml networks (7-layer SDF, 3-layer radiance, light-mask head)."""
+    net, ocfg, sd = _build(True, light=light)
     inp = camera_inputs(B, (0.0, 0.0, -2.0), seed=7)
     g = torch.Generator().manual_seed(B)
     R = ocfg.scene_bounding_sphere
@@ -85,7 +86,8 @@ def test_training_step_full_size(B):
     nn = out["normal_values"].detach()[hit].norm(dim=1)
     assert float((nn - 1).abs().max()) < 1e-4
     # ---- probe loss on the subset rays only
-    w = {"rgb": torch.randn(len(S), 3, generator=g), "depth": torch.randn(len(S), generator=g), "nrm": torch.randn(len(S), 3, generator=g)}
+    w = {"rgb": torch.randn(len(S), 3, generator=g), "depth": torch.randn(len(S), generator=g), "nrm": torch.randn(len(S), 3, generator=g),
+         "lm": torch.randn(len(S), 1, generator=g)}
     Sc = S.cuda()
     # the normal of a ray that hits nothing is the direction of a vanishing sum (ill-conditioned in the reference itself): the probe
     # weights normals only on rays with weight_sum > 0.01, the same rays on both sides
@@ -96,6 +98,8 @@ def test_training_step_full_size(B):
             + 0.3 * (out["normal_values"][Sc] * w["nrm"].cuda()).sum()
             + 0.1 * ((gth[Sc].norm(2, dim=1) - 1) ** 2).sum() + 0.1 * ((gth[B + Sc].norm(2, dim=1) - 1) ** 2).sum()
             + 0.05 * out["diff_norm"][Sc].sum())
+    if light:
+        loss = loss + (out["light_mask"][Sc] * w["lm"].cuda()).sum()
     net.zero_grad()
     loss.backward()
     for n_, p in net.named_parameters():
@@ -116,6 +120,9 @@ def test_training_step_full_size(B):
              + 0.3 * (ref["normal_values"] * w["nrm"].to(D)).sum()
              + 0.1 * ((rth[:n_s].norm(2, dim=1) - 1) ** 2).sum() + 0.1 * ((rth[n_s:].norm(2, dim=1) - 1) ** 2).sum()
              + 0.05 * ref["diff_norm"].sum())
+    if light:
+        assert_close(out["light_mask"].detach().cpu()[S], ref["light_mask"].detach(), 1e-4, "light_mask (subset)")
+        rloss = rloss + (ref["light_mask"] * w["lm"].to(D)).sum()
     assert_close(loss.detach().cpu(), rloss.detach(), 1e-5, "probe loss")
     names = list(params)
     rg = dict(zip(names, torch.autograd.grad(rloss, [params[kk] for kk in names], allow_unused=True)))
@@ -126,7 +133,7 @@ def test_training_step_full_size(B):
             assert float(p.grad.abs().max()) == 0.0, n_
         else:
             worst = max(worst, assert_close(p.grad.cpu(), r, 1e-4, "grad " + n_))
-    print(f"B={B}: sampler iterations {k}; worst relative parameter-gradient error of the subset probe vs fp64 {worst:.2e}")
+    print(f"B={B} light={light}: sampler iterations {k}; worst relative parameter-gradient error of the subset probe vs fp64 {worst:.2e}")
 
 
 def test_eval_chunk_12000_rays():
