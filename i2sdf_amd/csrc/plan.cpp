@@ -377,6 +377,10 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     p->wgrad_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
+  if (option == I2SDF_OPT_WGRAD_BF16X2) {
+    p->wgrad_bf16x2 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
   if (option == I2SDF_OPT_BLOCKED_SAVES) {
     p->blocked_saves = value ? 1 : 0;
     return I2SDF_OK;

@@ -72,6 +72,7 @@ struct i2sdf_plan {
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
   i2sdf_exchange exchange{nullptr, nullptr};   // i2sdf_plan_set_exchange: small data-parallel exchanges (copied)
   int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
+  int32_t wgrad_bf16x2 = 0;          // I2SDF_OPT_WGRAD_BF16X2: 256x256 weight-gradient blocks with two split planes / three products
   int32_t blocked_saves = 0;         // I2SDF_OPT_BLOCKED_SAVES: saved tensors of the bf16x3 full workgroups in the blocked layout (mlp_common.h)
   int32_t src_ring = 0;              // I2SDF_OPT_SRC_RING: saved-tensor reads of the bf16x3 kernels through the per-wave LDS DMA ring (x3r.h)
   int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones

@@ -262,7 +262,9 @@ constexpr int W3P_LDS_BYTES = (2 * W3P_RAW + 2 * W3P_PL) * 4;
 
 // BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time, so that the point-major
 // instance keeps the round-1 code exactly: runtime selects cost 5 % here through a worse MFMA / split interleave)
-template <bool BLKA, bool BLKB>
+// NPL = split planes per operand: 3 = bf16x3 (six partial products, error 2^-24: fp32-equivalent); 2 = bf16x2 (x = x0 + x1, the
+// three products a0b0, a0b1, a1b0; per-product error <= 3 * 2^-18, I2SDF_OPT_WGRAD_BF16X2 -- see the note at the option)
+template <bool BLKA, bool BLKB, int NPL>
 __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   float* rawb = lds;
   float* plb = lds + 2 * W3P_RAW;
@@ -328,7 +330,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       olo[i] = blk_lds ? j * 256 + pos * 4 : (2 * i) * 256 + lane * 4;
       ohi[i] = blk_lds ? j * 256 + (pos ^ 4) * 4 : (2 * i + 1) * 256 + lane * 4;
     }
-    unsigned pl[4][3][4];                 // planes of the quarter being split: [tile][plane][point pair]
+    unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: read raw, mask / relu / bias sums, split
     auto split_pair = [&](int s, int i) __attribute__((always_inline)) {
       const float* src = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
@@ -339,7 +341,8 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       for (int tt = 0; tt < 4; ++tt) {
         const float x0 = fmaxf(lo[tt], relu_lo) * k0, x1 = fmaxf(hi_[tt], relu_lo) * k1;
         bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
-        split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][2][i]);
+        if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
+        else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
       }
     };
     auto write_planes = [&](int s) __attribute__((always_inline)) {
@@ -347,7 +350,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NPL; ++p)
           *reinterpret_cast<u32x4*>(dst + (tt * 3 + p) * 256) = u32x4{pl[tt][p][0], pl[tt][p][1], pl[tt][p][2], pl[tt][p][3]};
     };
     auto plane = [&](int s, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
@@ -368,20 +371,21 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();                     // planes(s) written, raw(s+1) landed, everyone done with stage s-1
       if (s + 2 < nst) issue(s + 2);       // into the raw slot of stage s (already split)
-      u32x4 ap[4][3];
+      u32x4 ap[4][NPL];
 #pragma unroll
       for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) ap[ta][p] = plane(s, wa, ta, p);
+        for (int p = 0; p < NPL; ++p) ap[ta][p] = plane(s, wa, ta, p);
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) {
-        u32x4 bp[3];
+        u32x4 bp[NPL];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) bp[p] = plane(s, 2 + wb, tb, p);
+        for (int p = 0; p < NPL; ++p) bp[p] = plane(s, 2 + wb, tb, p);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? 2 : 0);
-          const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? 2 : 0);
+        for (int q = 0; q < (NPL == 3 ? 6 : 3); ++q) {
+          // (sa, sb): NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
+          const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
+          const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
 #pragma unroll
           for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[sb], acc[ta][tb]);
         }
@@ -410,15 +414,16 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   }
 }
 
+template <int NPL>
 __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WgJob& j0 = L.t[blockIdx.y].j[0];
   const int64_t m_lo = (int64_t)blockIdx.x * WG_CH;
   const bool ba = m_lo < j0.a_blk, bb = m_lo < j0.b_blk;       // workgroup-uniform
-  if (ba && bb) wgrad3p_body<true, true>(L, lds);
-  else if (ba) wgrad3p_body<true, false>(L, lds);
-  else if (bb) wgrad3p_body<false, true>(L, lds);
-  else wgrad3p_body<false, false>(L, lds);
+  if (ba && bb) wgrad3p_body<true, true, NPL>(L, lds);
+  else if (ba) wgrad3p_body<true, false, NPL>(L, lds);
+  else if (bb) wgrad3p_body<false, true, NPL>(L, lds);
+  else wgrad3p_body<false, false, NPL>(L, lds);
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
@@ -661,8 +666,13 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
       dim3 grid((unsigned)n_chunks, (unsigned)L.n);
       if (var == 4) {
-        (void)hipFuncSetAttribute((const void*)wgrad3p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
-        wgrad3p_kernel<<<grid, 256, W3P_LDS_BYTES, st>>>(L);
+        if (p->wgrad_bf16x2) {
+          (void)hipFuncSetAttribute((const void*)wgrad3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
+          wgrad3p_kernel<2><<<grid, 256, W3P_LDS_BYTES, st>>>(L);
+        } else {
+          (void)hipFuncSetAttribute((const void*)wgrad3p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
+          wgrad3p_kernel<3><<<grid, 256, W3P_LDS_BYTES, st>>>(L);
+        }
       } else if (var == 0) {
         wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       } else {

@@ -51,6 +51,12 @@ __device__ __forceinline__ void split3_pair(float xa, float xb, unsigned& p0, un
   p2 = pk_bf16(ra, rb);
 }
 
+// two values -> their two leading split planes (bf16x2: x = x0 + x1 + O(2^-18 |x|))
+__device__ __forceinline__ void split2_pair(float xa, float xb, unsigned& p0, unsigned& p1) {
+  p0 = pk_bf16(xa, xb);
+  p1 = pk_bf16(xa - bf16_lo(p0), xb - bf16_hi(p0));
+}
+
 // this lane's B-operand values of an input vector given in reduction-index order (NC16 k-chunks)
 template <int NC16>
 __device__ __forceinline__ void x3_select_pe(const float (&full)[NC16 * 16], float (&sel)[NC16 * 8], int hi) {

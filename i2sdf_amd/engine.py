@@ -45,6 +45,9 @@ class RenderEngine:
         self.src_ring = False
         if cfg.bf16x3 and os.environ.get("I2SDF_SRC_RING", "0") != "0":       # off by default (no gain measured); I2SDF_SRC_RING=1 for A/B runs
             self.set_src_ring(True)
+        self.wgrad_bf16x2 = False
+        if cfg.bf16x3 and os.environ.get("I2SDF_WGRAD_BF16X2", "0") != "0":   # opt-in (see include/i2sdf.h); bench.py reports it as a sub-record
+            self.set_wgrad_bf16x2(True)
         self.blocked_saves = False
         if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
             self.set_blocked_saves(True)
@@ -137,6 +140,12 @@ class RenderEngine:
         """Radiance forward / backward (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_RGB_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.rgb_bf16x3 = bool(on)
+
+    def set_wgrad_bf16x2(self, on: bool):
+        """256x256 weight-gradient blocks with two split planes / three products (I2SDF_OPT_WGRAD_BF16X2): 16+ mantissa bits per
+        operand -- above the reference's own `float32_matmul_precision('medium')`, below fp32; the gradients stay inside the 1e-4 bar."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_WGRAD_BF16X2, int(bool(on))), "i2sdf_plan_set_option")
+        self.wgrad_bf16x2 = bool(on)
 
     def set_blocked_saves(self, on: bool):
         """Saved 256-wide tensors of the bf16x3 full workgroups in the blocked layout (I2SDF_OPT_BLOCKED_SAVES, csrc/mlp_common.h).

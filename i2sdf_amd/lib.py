@@ -71,6 +71,7 @@ OPT_RGB_BF16X3 = 16
 OPT_TAIL_OVERLAP = 32
 OPT_SRC_RING = 64
 OPT_BLOCKED_SAVES = 128
+OPT_WGRAD_BF16X2 = 256
 
 
 class I2SDFError(RuntimeError):

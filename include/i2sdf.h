@@ -107,6 +107,14 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   Set it before the first i2sdf_sdf_forward_grad of a step and leave it unchanged through i2sdf_weight_grads; the tensors are
  *   opaque to the caller (i2sdf_saved_rows_to_point_major converts a copy for inspection).  Default 0. */
 #define I2SDF_OPT_BLOCKED_SAVES 128
+/*   I2SDF_OPT_WGRAD_BF16X2 (needs I2SDF_OPT_WGRAD_BF16X3): the 256x256 weight-gradient blocks split every operand into TWO bf16
+ *   terms and accumulate the three leading products a0b0 + a0b1 + a1b0 in fp32: per-product error <= 3 * 2^-18 (1.1e-5), i.e.
+ *   16+ mantissa bits per operand -- more than the TF32 / bf16 internals the reference itself runs its matmuls with
+ *   (main_recon.py:61: torch.set_float32_matmul_precision('medium')), less than fp32.  Only the weight gradients qualify: they are
+ *   terminal sums over ~1e5 points (rounding errors of the terms average out and propagate nowhere), measured 1e-5-level
+ *   max-norm error of every parameter gradient against fp64 (parity bar 1e-4).  Half the MFMAs and 2/3 of the split work of the
+ *   bf16x3 form.  Default 0; every other kernel keeps the fp32-equivalent bf16x3 / fp32 arithmetic. */
+#define I2SDF_OPT_WGRAD_BF16X2 256
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset

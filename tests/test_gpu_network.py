@@ -475,3 +475,40 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     e3 = max(assert_close(g3[k], ref_g[k], 1e-4, "grad " + k + " (bf16x3 vs fp64)") for k in g1)
     e1 = max(assert_close(g1[k], ref_g[k], 1e-4, "grad " + k + " (fp32 kernels vs fp64)") for k in g1)
     print(f"worst relative parameter-gradient error vs fp64: bf16x3 kernels {e3:.2e}, fp32-MFMA kernels {e1:.2e}")
+
+
+@pytest.mark.parametrize("B", [40, 400])
+def test_wgrad_bf16x2_stays_inside_the_parity_bar(B):
+    """I2SDF_OPT_WGRAD_BF16X2 (opt-in): the 256x256 weight-gradient blocks with two bf16 planes per operand and three products.
+    Every parameter gradient of a full-width training step against the fp64 oracle: must stay within the 1e-4 bar, and the error
+    is printed next to the bf16x3 (fp32-equivalent) form's.  B = 40 is the hard case (few points to average rounding over)."""
+    from i2sdf_amd import synthetic_conf, I2SDFLoss
+    ocfg = orc.synthetic_cfg(False)
+    ocfg.use_normal = True
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=41), 0.03, seed=42)
+    sd["density.beta"] = torch.tensor(0.05)
+    inp = camera_inputs(B, (0.0, 0.0, -2.0), seed=5)
+    gt = make_gt(B)
+    dr = make_draws(ocfg, B, n_row=128, seed=2)
+    cam, dirs, dn = orc.prepare_rays(inp["uv"], inp["pose"], inp["intrinsics"])
+    z_all, z_eik = orc.sample_z_vals(sd, ocfg, dirs, cam, training=True, draws=dr, force_iters=1)
+    D = torch.float64
+    lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
+    d64 = orc.Draws(eik_pts=dr.eik_pts.to(D), nbr_off=dr.nbr_off.to(D))
+    gt64 = {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}
+    _, _, ref_g = orc.training_step_grads({k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64, lc, d64,
+                                          step=10, z_override=(z_all.to(D), z_eik.to(D)))
+    worst = {}
+    for x2 in (False, True):
+        net = build(synthetic_conf(False), sd, train=True)
+        eng = net._engine_for("cuda:0")
+        eng.set_wgrad_bf16x2(x2)
+        c, d, n = eng.ray_setup(inp["uv"].cuda(), inp["pose"].cuda(), inp["intrinsics"].cuda())
+        out = net.render(cuda(inp), c, d, n, z_all.cuda(), z_eik.cuda(), draws={"eik_pts": dr.eik_pts.cuda(), "nbr_off": dr.nbr_off.cuda()})
+        loss = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)(out, cuda(gt), 10)["loss"]
+        net.zero_grad()
+        loss.backward()
+        errs = {n_: rel_max(p.grad.cpu(), ref_g[n_]) for n_, p in net.named_parameters() if float(ref_g[n_].abs().max()) > 0}
+        worst[x2] = max(errs.items(), key=lambda kv: kv[1])
+        assert worst[x2][1] <= 1e-4, (x2, worst[x2])
+    print(f"B={B}: worst parameter-gradient error vs fp64: bf16x3 wgrad {worst[False][1]:.2e} ({worst[False][0]}), bf16x2 wgrad {worst[True][1]:.2e} ({worst[True][0]})")
