@@ -134,6 +134,60 @@ def test_plan_options(lib):
     h.i2sdf_plan_destroy(plan)
 
 
+def test_new_plan_options_and_blocked_prefix(lib):
+    """Round-2 options toggle on 256-wide nets; i2sdf_blocked_points follows the split of a launch into full rounds of 128-point
+    workgroups (one per CU, 256 without a device) and the split-K tail (csrc/mlp_common.h: split_bulk_points)."""
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    h = lib.load()
+    rc, plan, _, _ = _plan(lib, synthetic_conf())
+    assert rc == 0
+    for opt in (lib.OPT_SRC_RING, lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2):
+        assert h.i2sdf_plan_set_option(plan, opt, 1) == 0 and h.i2sdf_plan_set_option(plan, opt, 0) == 0
+    for opt in (lib.OPT_TRAIN_FWD_BF16X3, lib.OPT_SDF_BWD_BF16X3, lib.OPT_RGB_BF16X3, lib.OPT_TAIL_OVERLAP):
+        assert h.i2sdf_plan_set_option(plan, opt, 1) == 0
+    M = 1024 * 98 + 1024 * 2                                   # the training batch: 98 shaded + 2 eikonal points per ray
+    Mp = (M + 127) // 128 * 128
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0      # option off: point-major rows everywhere
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1) == 0
+    n_wg = Mp // 128
+    bulk = (n_wg // 256) * 256 * 128                           # 3 full rounds of 256 workgroups, 32 workgroups of tail
+    assert 0 < bulk < M and (n_wg - bulk // 128) * 4 <= 256
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == bulk
+    assert h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == bulk
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 0) == Mp     # eikonal-only launches (no feature output) are never split
+    M2 = 360 * 98
+    Mp2 = (M2 + 127) // 128 * 128
+    assert h.i2sdf_blocked_points(plan, 0, M2, Mp2, 1) == 256 * 128   # one full round + 20 tail workgroups
+    M3 = 200 * 98                                                      # less than one round: no split, all blocked
+    Mp3 = (M3 + 127) // 128 * 128
+    assert h.i2sdf_blocked_points(plan, 0, M3, Mp3, 1) == Mp3
+    assert h.i2sdf_blocked_points(None, 0, M, Mp, 1) == 0
+    h.i2sdf_plan_destroy(plan)
+    rc, plan, _, _ = _plan(lib, plumbing_conf())                # 64-wide nets have no bf16x3 train path: nothing is blocked
+    assert rc == 0
+    h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1)
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0
+    h.i2sdf_plan_destroy(plan)
+
+
+def test_saved_to_point_major_matches_the_documented_layout():
+    """Engine.saved_to_point_major against the address formula of include/i2sdf.h (row of point m at (m/32)*8192 + (m%32)*16,
+    k-chunk kc at +512*kc) written as explicit loops."""
+    import torch
+    from i2sdf_amd.engine import RenderEngine as Engine
+    Lr, Mp, nb = 2, 256, 128
+    flat = torch.arange(Lr * Mp * 256, dtype=torch.float32).reshape(Lr, Mp, 256)
+    got = Engine.saved_to_point_major(flat, nb)
+    for l in range(Lr):
+        base = flat[l].reshape(-1)
+        for m in (0, 1, 31, 32, 77, 127):
+            for kc in (0, 5, 15):
+                off = (m // 32) * 8192 + (m % 32) * 16 + 512 * kc
+                assert torch.equal(got[l, m, 16 * kc:16 * kc + 16], base[off:off + 16])
+        assert torch.equal(got[l, nb:], flat[l, nb:])            # the tail behind the blocked prefix keeps ordinary rows
+    assert torch.equal(Engine.saved_to_point_major(flat, 0), flat)
+
+
 def test_missing_library_fails_loudly(monkeypatch, lib):
     from i2sdf_amd import lib as L
     monkeypatch.setattr(L, "_lib", None)
