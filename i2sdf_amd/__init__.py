@@ -17,6 +17,12 @@ def __getattr__(name):
     if name == "FusedAdam":
         from .optim import FusedAdam
         return FusedAdam
+    if name == "BubblePDF":
+        from .bubble import BubblePDF
+        return BubblePDF
+    if name in ("GridAxes", "uniform_axes", "aligned_axes"):
+        from . import grid
+        return getattr(grid, name)
     if name == "RenderEngine":
         from .engine import RenderEngine
         return RenderEngine

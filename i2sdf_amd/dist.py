@@ -253,6 +253,25 @@ def render_image(net, model_input: Dict[str, torch.Tensor], split_n_pixels: int 
     return merged
 
 
+def sdf_volume(net, axes, rot=None, trans=None, order: str = "volume", chunk: int = 1 << 21, group=None) -> torch.Tensor:
+    """Multi-GPU SDF volume for marching cubes (row N4): every rank evaluates one contiguous slab of the flat output with ONE
+    library call and the slabs are all-gathered (4 B/point).  Points do not interact, so the volume is identical to the 1-GPU one."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = net.sdf_volume(axes, rot, trans, order, chunk, rank=rank, world_size=world)
+    if world == 1:
+        return mine
+    x, y, z = (axes.x, axes.y, axes.z) if hasattr(axes, "shortest_axis_index") else axes
+    nx, ny, nz = len(x), len(y), len(z)
+    total = nx * ny * nz
+    per = (total + world - 1) // world
+    pad = torch.zeros(per, dtype=mine.dtype, device=mine.device)
+    pad[: mine.shape[0]] = mine
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    flat = torch.cat(parts)[:total]
+    return flat.view(nx, ny, nz) if order == "volume" else flat
+
+
 def global_any(flag: torch.Tensor, group=None) -> torch.Tensor:
     """MAX-reduce a small flag tensor on the host side of the ABI (kept for callers that run their own loop; the module's
     sampler uses the device-side exchange hook instead)."""

@@ -420,6 +420,29 @@ class RenderEngine:
                 "i2sdf_render_image")
         return o
 
+    def sdf_grid(self, x, y, z, rot=None, trans=None, order: int = L.GRID_ORDER_VOLUME, first: int = 0, count: Optional[int] = None,
+                 chunk: int = 1 << 21):
+        """SDF values on the grid x (nx) x y (ny) x z (nz) without materialising the points (include/i2sdf.h: i2sdf_sdf_grid).
+        x, y, z: device fp32 vectors; rot (3,3) / trans (3,): host values, evaluated point = rot @ p + trans.  Returns (count,)."""
+        x, y, z = (t.detach().to(torch.float32).contiguous() for t in (x, y, z))
+        dev = x.device
+        nx, ny, nz = x.numel(), y.numel(), z.numel()
+        total = nx * ny * nz
+        count = total - first if count is None else count
+        chunk = int(max(128, min(chunk, max(count, 128))))
+        ws = getattr(self, "_grid_ws", None)
+        n_ws = int(self._lib.i2sdf_sdf_grid_workspace_floats(chunk))
+        if ws is None or ws.numel() < n_ws or ws.device != dev:
+            ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+            self._grid_ws = ws
+        out = torch.empty(count, dtype=torch.float32, device=dev)
+        host = lambda v, n: None if v is None else (C.c_float * n)(*[float(a) for a in torch.as_tensor(v, dtype=torch.float32).reshape(-1).tolist()])
+        r, t = host(rot, 9), host(trans, 3)
+        L.check(self._lib.i2sdf_sdf_grid(self._plan, L.ptr(self.packed), L.ptr(x), L.ptr(y), L.ptr(z), nx, ny, nz, int(order),
+                                         C.cast(r, C.c_void_p) if r is not None else None, C.cast(t, C.c_void_p) if t is not None else None,
+                                         int(first), int(count), L.ptr(out), L.ptr(ws), chunk, L.stream_ptr()), "i2sdf_sdf_grid")
+        return out
+
     # -- light-mask head ---------------------------------------------------------------------------
     def light_forward(self, feat, M, save=True):
         Mp, dev = feat.shape[0], feat.device

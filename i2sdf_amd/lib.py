@@ -72,6 +72,7 @@ OPT_TAIL_OVERLAP = 32
 OPT_SRC_RING = 64
 OPT_BLOCKED_SAVES = 128
 OPT_WGRAD_BF16X2 = 256
+GRID_ORDER_MESHGRID, GRID_ORDER_VOLUME = 0, 1
 
 
 class I2SDFError(RuntimeError):
@@ -127,6 +128,11 @@ SIGNATURES = {
     # plan, packed, params, cfg, uv, pose, pose_is_quat, intrinsics, P, chunk, t_lin, u_more, u_final, extra_tab, workspace,
     # o_rgb, o_depth, o_wsum, o_normal, o_lmask, o_z, o_iters, stream
     "i2sdf_render_image": (C.c_int, [_P, _P, _P, C.POINTER(SamplerCfg), _P, _P, _I32, _P, _I64, _I64] + [_P] * 13),
+    "i2sdf_sdf_grid_workspace_floats": (_I64, [_I64]),
+    # plan, packed, x, y, z, nx, ny, nz, order, rot (host), trans (host), first, count, sdf_out, workspace, chunk_points, stream
+    "i2sdf_sdf_grid": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I64, _P, _P, _I64, _P]),
+    # pred, target, channels, pixel_idx, first_pixel, n, pointlinks, n_links, pdf_max, pdf_prune, pdf, n_pdf, n_bad, stream
+    "i2sdf_pdf_update": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P, _I64, C.c_double, C.c_double, _P, _I64, _P, _P]),
     "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_loss_scratch_floats": (_I64, []),

@@ -458,6 +458,42 @@ int i2sdf_render_image(const i2sdf_plan* plan, const float* packed, const float*
                        float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* o_z, int32_t* o_iters,
                        void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * SDF volume for marching cubes -- model/eval/recon.py:46-51 (coarse uniform grid) and :75-103 (the
+ * PCA-aligned fine grid evaluated through GridDataset / a 32-worker DataLoader), utils/plots.py:440-489 (get_grid_uniform,
+ * get_grid: np.meshgrid(x, y, z) flattened to an (n,3) host tensor).  The axis vectors are the whole input: grid points are
+ * generated on the device one chunk ahead of the SDF kernel and never exist on the host.
+ *   x (nx), y (ny), z (nz)   device fp32 axis coordinates (the reference casts its float64 linspace / arange to float)
+ *   order   I2SDF_GRID_ORDER_MESHGRID: output index ((iy*nx)+ix)*nz+iz = np.meshgrid(x,y,z).ravel() order, the order of the
+ *           reference's flat `z` before its reshape(ny,nx,nz).transpose([1,0,2]);  I2SDF_GRID_ORDER_VOLUME: ((ix*ny)+iy)*nz+iz,
+ *           i.e. that transposed (nx,ny,nz) volume itself, ready for measure.marching_cubes
+ *   rot (9, row-major, HOST) | NULL, trans (3, HOST) | NULL : evaluated point = rot * (x,y,z) + trans; the aligned grid of
+ *           model/eval/recon.py:82-85 passes rot = vecs^T, trans = s_mean
+ *   [first, first+count) the output indices to evaluate (a rank's slab; count = nx*ny*nz for everything)
+ *   sdf_out (count); workspace i2sdf_sdf_grid_workspace_floats(chunk_points) floats; chunk_points > 0
+ * Enqueues ceil(count/chunk_points) generator + SDF launches on `stream`; no allocation, no synchronisation.
+ * ---------------------------------------------------------------------------------------------- */
+#define I2SDF_GRID_ORDER_MESHGRID 0
+#define I2SDF_GRID_ORDER_VOLUME 1
+int64_t i2sdf_sdf_grid_workspace_floats(int64_t chunk_points);
+int i2sdf_sdf_grid(const i2sdf_plan* plan, const float* packed, const float* x, const float* y, const float* z, int32_t nx,
+                   int32_t ny, int32_t nz, int32_t order, const float* rot, const float* trans, int64_t first, int64_t count,
+                   float* sdf_out, float* workspace, int64_t chunk_points, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bubble-PDF update (row N4) -- VolumeRenderSystem.update_pdf fused with the error it is fed (model/trainer/recon.py:142-152,
+ * :195-199 in the initial sweep over all images, :246-252 every training step):
+ *   channels == 1: v = |pred - target|                         (criterion DEPTH: depth_values vs depth image)
+ *   channels == 3: v = mean_c |clamp(pred,0,1) - clamp(target,0,1)|   (criterion RGB)
+ *   v = min(v, pdf_max) unless pdf_max is NaN / inf ("None");  v = 0 where v < pdf_prune;
+ *   link = pointlinks[pixel];  pdf[link] = v where link != -1
+ *   pixel_idx (n) global pixel indices, or NULL for the run first_pixel .. first_pixel+n-1 (a split of one image)
+ *   n_bad: device counter of out-of-range pixels / links (skipped), or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_pdf_update(const float* pred, const float* target, int32_t channels, const int64_t* pixel_idx, int64_t first_pixel,
+                     int64_t n, const int64_t* pointlinks, int64_t n_links, double pdf_max, double pdf_prune, float* pdf,
+                     int64_t n_pdf, int32_t* n_bad, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

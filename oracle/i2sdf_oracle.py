@@ -750,6 +750,77 @@ def training_step_grads(sd, cfg: NetCfg, inputs, gt, lc: LossCfg, draws: Draws, 
 
 
 # --------------------------------------------------------------------------------------
+# marching-cubes grids and the bubble PDF (callers of the SDF forward / of predict_only rendering)
+# --------------------------------------------------------------------------------------
+def get_grid_uniform(resolution: int, grid_boundary=(-2.0, 2.0)):
+    """utils/plots.py:440-451.  Returns {grid_points (n,3) float32 in np.meshgrid(x,y,z) ravel order, xyz float64 axes, ...}."""
+    import numpy as np
+    x = np.linspace(grid_boundary[0], grid_boundary[1], resolution)
+    y = x
+    z = x
+    xx, yy, zz = np.meshgrid(x, y, z)
+    grid_points = torch.tensor(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T, dtype=torch.float)
+    return {"grid_points": grid_points, "shortest_axis_length": 2.0, "xyz": [x, y, z], "shortest_axis_index": 0}
+
+
+def get_grid(points: Tensor, resolution: int, input_min=None, input_max=None, eps: float = 0.1):
+    """utils/plots.py:453-489: `resolution` points along the shortest axis of the bounding box (+-eps), the same step along the others."""
+    import numpy as np
+    if input_min is None or input_max is None:
+        input_min = torch.min(points, dim=0)[0].squeeze().numpy()
+        input_max = torch.max(points, dim=0)[0].squeeze().numpy()
+    bounding_box = input_max - input_min
+    shortest_axis = int(np.argmin(bounding_box))
+    if shortest_axis == 0:
+        x = np.linspace(input_min[0] - eps, input_max[0] + eps, resolution)
+        length = np.max(x) - np.min(x)
+        y = np.arange(input_min[1] - eps, input_max[1] + length / (x.shape[0] - 1) + eps, length / (x.shape[0] - 1))
+        z = np.arange(input_min[2] - eps, input_max[2] + length / (x.shape[0] - 1) + eps, length / (x.shape[0] - 1))
+    elif shortest_axis == 1:
+        y = np.linspace(input_min[1] - eps, input_max[1] + eps, resolution)
+        length = np.max(y) - np.min(y)
+        x = np.arange(input_min[0] - eps, input_max[0] + length / (y.shape[0] - 1) + eps, length / (y.shape[0] - 1))
+        z = np.arange(input_min[2] - eps, input_max[2] + length / (y.shape[0] - 1) + eps, length / (y.shape[0] - 1))
+    else:
+        z = np.linspace(input_min[2] - eps, input_max[2] + eps, resolution)
+        length = np.max(z) - np.min(z)
+        x = np.arange(input_min[0] - eps, input_max[0] + length / (z.shape[0] - 1) + eps, length / (z.shape[0] - 1))
+        y = np.arange(input_min[1] - eps, input_max[1] + length / (z.shape[0] - 1) + eps, length / (z.shape[0] - 1))
+    xx, yy, zz = np.meshgrid(x, y, z)
+    grid_points = torch.tensor(np.vstack([xx.ravel(), yy.ravel(), zz.ravel()]).T, dtype=torch.float)
+    return {"grid_points": grid_points, "shortest_axis_length": length, "xyz": [x, y, z], "shortest_axis_index": shortest_axis}
+
+
+def align_grid_points(grid_points: Tensor, vecs: Tensor, s_mean: Tensor) -> Tensor:
+    """model/eval/recon.py:82-85: every grid point p -> vecs^T p + s_mean (the PCA frame of the coarse mesh back to the world)."""
+    return torch.bmm(vecs.unsqueeze(0).repeat(grid_points.shape[0], 1, 1).transpose(1, 2), grid_points.unsqueeze(-1)).squeeze(-1) + s_mean
+
+
+def grid_volume(z_flat, xyz):
+    """model/eval/recon.py:53-54,94: the flat SDF vector as the (nx,ny,nz) volume marching cubes is run on."""
+    return z_flat.reshape(xyz[1].shape[0], xyz[0].shape[0], xyz[2].shape[0]).transpose(1, 0, 2) if not torch.is_tensor(z_flat) \
+        else z_flat.reshape(xyz[1].shape[0], xyz[0].shape[0], xyz[2].shape[0]).permute(1, 0, 2)
+
+
+def pdf_error(criterion: str, model_outputs: Dict[str, Tensor], ground_truth: Dict[str, Tensor]) -> Tensor:
+    """model/trainer/recon.py:195-199 / :248-252."""
+    if criterion == "RGB":
+        return (model_outputs["rgb_values"].detach().clamp(0, 1) - ground_truth["rgb"].clamp(0, 1)).abs().mean(dim=-1)
+    return (model_outputs["depth_values"].detach() - ground_truth["depth"]).abs()
+
+
+def update_pdf(pdf: Tensor, value: Tensor, idx: Tensor, pointlinks: Tensor, pdf_max: Optional[float], pdf_prune: float) -> None:
+    """model/trainer/recon.py:142-152 (in place on `pdf`)."""
+    value = value.clone()
+    if pdf_max is not None:
+        value = value.clamp(max=pdf_max)
+    value[value < pdf_prune] = 0
+    link = pointlinks[idx]
+    mask = link != -1
+    pdf[link[mask]] = value[mask]
+
+
+# --------------------------------------------------------------------------------------
 # Analytic restatement of what autograd does (SURVEY appendix A) -- mirrors the HIP kernels
 # --------------------------------------------------------------------------------------
 def _sp_prime(a: Tensor) -> Tensor:

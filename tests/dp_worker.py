@@ -109,6 +109,14 @@ def worker(rank, world, port, Bh, result_path):
         res["image_equal"] = all(bool(torch.equal(merged[k], single[k])) for k in single)
         res["image_rows"] = int(merged["rgb_values"].shape[0])
         torch.save(res, result_path)
+    # ---- multi-GPU SDF volume (N4): contiguous slabs of the flat output, all-gathered
+    from i2sdf_amd.grid import aligned_axes
+    ax = aligned_axes(None, 7, torch.tensor([-0.9, -0.4, -1.1]).numpy(), torch.tensor([0.8, 0.5, 1.2]).numpy())
+    vol = i2dist.sdf_volume(ev, ax, chunk=300)
+    if rank == 0:
+        res = torch.load(result_path)
+        res["volume_equal"] = bool(torch.equal(vol, ev.sdf_volume(ax))) and tuple(vol.shape) == ax.shape_volume
+        torch.save(res, result_path)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -211,7 +211,58 @@ def full_width(ref_model, I2SDFLoss):
     save("g15_eval_full", **arrs)
 
 
+def n4_fixtures():
+    """G16: the reference's marching-cubes grids (utils/plots.py get_grid_uniform / get_grid) and its bubble-PDF update
+    (ReconstructionTrainer.update_pdf, model/trainer/recon.py:142-152, fed as in :195-199)."""
+    import importlib
+    import types
+    ref_import.import_reference()
+    plots = importlib.import_module("utils.plots")
+    trainer = importlib.import_module("model.trainer.recon").ReconstructionTrainer
+    cuda_was = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the grid builders end in .cuda(); this container has no device
+    try:
+        arrs = {}
+        gu = plots.get_grid_uniform(5, [-1.5, 1.5])
+        arrs.update({"uni.resolution": 5, "uni.boundary": np.array([-1.5, 1.5]), "uni.grid_points": gu["grid_points"],
+                     **{f"uni.xyz{a}": gu["xyz"][a] for a in range(3)}})
+        g = torch.Generator().manual_seed(7)
+        for case, (scale, res) in enumerate((((0.4, 1.0, 1.7), 6), ((1.2, 0.35, 2.0), 7), ((1.5, 0.9, 0.25), 5))):
+            pts = torch.randn(60, 3, generator=g) * torch.tensor(scale) + torch.tensor([0.1, -0.2, 0.05])
+            ga = plots.get_grid(pts, res)
+            assert ga["shortest_axis_index"] == case
+            arrs.update({f"al{case}.points": pts, f"al{case}.resolution": res, f"al{case}.grid_points": ga["grid_points"],
+                         f"al{case}.shortest_axis_length": ga["shortest_axis_length"], f"al{case}.shortest_axis_index": ga["shortest_axis_index"],
+                         **{f"al{case}.xyz{a}": ga["xyz"][a] for a in range(3)}})
+    finally:
+        torch.Tensor.cuda = cuda_was
+    # bubble PDF: 3 images of 12x10 pixels, ~70 % of the pixels carry a point
+    n_img, HW = 3, 120
+    has = torch.rand(n_img * HW, generator=g) < 0.7
+    links = -torch.ones(n_img * HW, dtype=torch.long)
+    links[has] = torch.arange(int(has.sum()))
+    n_pts = int(has.sum())
+    idx = torch.randperm(n_img * HW, generator=g)[:150]
+    rgb_pred, rgb_gt = torch.rand(150, 3, generator=g) * 1.6 - 0.3, torch.rand(150, 3, generator=g) * 1.4 - 0.2
+    d_pred, d_gt = torch.rand(150, generator=g) * 4, torch.rand(150, generator=g) * 4
+    arrs.update({"pdf.pointlinks": links, "pdf.idx": idx, "pdf.rgb_pred": rgb_pred, "pdf.rgb_gt": rgb_gt, "pdf.depth_pred": d_pred,
+                 "pdf.depth_gt": d_gt, "pdf.n_points": n_pts})
+    for tag, crit, pmax, prune in (("rgb", "RGB", None, 0.0), ("rgb_mp", "RGB", 0.3, 0.12), ("depth", "DEPTH", None, 0.0),
+                                   ("depth_mp", "DEPTH", 1.5, 0.4)):
+        self = types.SimpleNamespace(bubble_activated=True, train_dataset=types.SimpleNamespace(pointlinks=links),
+                                     pdf=torch.full((n_pts,), -1.0), pdf_max=pmax, pdf_prune=prune)
+        if crit == "RGB":                                    # the expressions of model/trainer/recon.py:196 / :199, evaluated by torch here
+            value = (rgb_pred.detach().clamp(0, 1) - rgb_gt.clamp(0, 1)).abs().mean(dim=-1)
+        else:
+            value = (d_pred.detach() - d_gt).abs()
+        trainer.update_pdf(self, value, idx)
+        arrs.update({f"pdf.{tag}.out": self.pdf, f"pdf.{tag}.max": np.nan if pmax is None else pmax, f"pdf.{tag}.prune": prune})
+    save("g16_grid_pdf", **arrs)
+
+
 def main():
+    if sys.argv[1:] == ["n4"]:
+        return n4_fixtures()
     ref_model, ref_utils = ref_import.import_reference()
     from model.network.embedder import get_embedder
     from model.network.mlp import ImplicitNetwork, RenderingNetwork
@@ -438,6 +489,9 @@ def main():
 
     # ---- G14 / G15 full-width (synthetic.yml shapes) end-to-end fixtures ---------------------------
     full_width(ref_model, I2SDFLoss)
+
+    # ---- G16 marching-cubes grids + bubble-PDF update ---------------------------------
+    n4_fixtures()
 
 
 if __name__ == "__main__":

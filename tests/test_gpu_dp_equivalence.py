@@ -45,5 +45,6 @@ def test_two_rank_step_equals_one_rank_step_on_the_concatenated_batch(tmp_path):
     assert res["rgb_err"] <= 1e-6, res["rgb_err"]                          # same depths -> same renders
     assert abs(res["loss_dp_mean"] - res["loss_ref"]) <= 1e-6 * abs(res["loss_ref"])
     assert res["image_equal"] and res["image_rows"] == 32 * 24, "2-rank sharded image render must equal the 1-rank image"
+    assert res["volume_equal"], "2-rank sharded SDF volume must equal the 1-rank volume"
     worst = max(res["grad_err"].items(), key=lambda kv: kv[1])
     assert worst[1] <= 1e-5, f"2-rank mean gradient vs 1-rank gradient on the concatenated batch: {worst}"

@@ -285,3 +285,44 @@ def test_g11_loss(golden):
     for k in l1:
         assert_close(l1[k], z["synthetic." + k], 1e-6, "synthetic." + k)
         assert_close(l2[k], z["light." + k], 1e-6, "light." + k)
+
+
+# ---- G16: marching-cubes grids and the bubble-PDF update -------------------------------------------------
+def test_g16_grids_oracle_and_host_axes(golden):
+    """The oracle's restatement of get_grid_uniform / get_grid AND the package's host-side axis helpers against the reference's
+    own output (axes exactly; points exactly -- same numpy arithmetic)."""
+    from i2sdf_amd import grid as G
+    z = golden("g16_grid_pdf")
+    res, bnd = int(z["uni.resolution"]), z["uni.boundary"]
+    o = orc.get_grid_uniform(res, list(bnd))
+    ax = G.uniform_axes(res, bnd)
+    for a in range(3):
+        assert np.array_equal(o["xyz"][a], z[f"uni.xyz{a}"]) and np.array_equal(ax.xyz[a], z[f"uni.xyz{a}"])
+    assert torch.equal(o["grid_points"], t(z["uni.grid_points"]))
+    for case in range(3):
+        pts, res = t(z[f"al{case}.points"]), int(z[f"al{case}.resolution"])
+        o = orc.get_grid(pts, res)
+        ax = G.aligned_axes(pts, res)
+        assert o["shortest_axis_index"] == ax.shortest_axis_index == int(z[f"al{case}.shortest_axis_index"]) == case
+        assert o["shortest_axis_length"] == ax.shortest_axis_length == float(z[f"al{case}.shortest_axis_length"])
+        for a in range(3):
+            assert np.array_equal(o["xyz"][a], z[f"al{case}.xyz{a}"]), (case, a)
+            assert np.array_equal(ax.xyz[a], z[f"al{case}.xyz{a}"]), (case, a)
+        assert torch.equal(o["grid_points"], t(z[f"al{case}.grid_points"]))
+        # explicit bounds instead of a point set
+        ax2 = G.aligned_axes(None, res, pts.min(0).values.numpy(), pts.max(0).values.numpy())
+        assert all(np.array_equal(ax2.xyz[a], ax.xyz[a]) for a in range(3))
+        assert ax.shape_volume == tuple(z[f"al{case}.xyz{a}"].shape[0] for a in range(3))
+
+
+def test_g16_update_pdf_oracle(golden):
+    z = golden("g16_grid_pdf")
+    links, idx = t(z["pdf.pointlinks"]), t(z["pdf.idx"])
+    for tag, crit in (("rgb", "RGB"), ("rgb_mp", "RGB"), ("depth", "DEPTH"), ("depth_mp", "DEPTH")):
+        pmax = None if np.isnan(z[f"pdf.{tag}.max"]) else float(z[f"pdf.{tag}.max"])
+        pdf = torch.full((int(z["pdf.n_points"]),), -1.0)
+        value = orc.pdf_error(crit, {"rgb_values": t(z["pdf.rgb_pred"]), "depth_values": t(z["pdf.depth_pred"])},
+                              {"rgb": t(z["pdf.rgb_gt"]), "depth": t(z["pdf.depth_gt"])})
+        orc.update_pdf(pdf, value, idx, links, pmax, float(z[f"pdf.{tag}.prune"]))
+        assert torch.equal(pdf, t(z[f"pdf.{tag}.out"])), tag
+        assert (pdf == -1).any() and (pdf == 0).any() == (tag.endswith("_mp"))      # untouched points stay; pruning only with a threshold
