@@ -14,6 +14,8 @@ for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip m
   for h in "$f" *.h ../../include/i2sdf.h build.sh; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ $stale = 1 ]; then
     extra=""; { [ "$f" = mlp_x3.hip ] || [ "$f" = mlp_x3r.hip ]; } && extra="$X3FLAGS"
+    # wgrad.hip: the hand-placed stage of wgrad3p_body is a 96-unit unrolled loop whose scalar ops must stay where they are written
+    [ "$f" = wgrad.hip ] && extra="$X3FLAGS -fno-slp-vectorize"
     ( hipcc $FLAGS $extra -x hip -c "$f" -o "$o" ) &
     pids+=($!)
   fi

@@ -45,6 +45,7 @@ __host__ __device__ constexpr int rowvec_chunks(int KC, int nrows) { return roun
 #define I2SDF_SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define I2SDF_MASK_MFMA 0x008
 #define I2SDF_MASK_DSREAD 0x100
+#define I2SDF_MASK_VALU 0x002
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

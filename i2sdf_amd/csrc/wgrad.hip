@@ -248,27 +248,38 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2 tiles of 128x128) per block and chunk.
-// 16 points form a stage.  Wave w owns one quarter of a stage (operand w>>1, column half w&1): it DMAs the raw fp32 rows
-// into LDS, reads them back in MFMA operand layout (lane = column quad 4i..4i+3 x 8 consecutive points), splits every value
-// ONCE into three bf16 terms and writes the planes back to LDS; consumers (two waves per quarter) read planes only and run
-// the six leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
-// The splits of stage s+1 are spread over the four MFMA phases of stage s.  (A first generation that let every wave split
-// both of its halves in registers needed 250 VGPRs and twice the VALU work: 1.75 vs 1.55 ms.)
-//   LDS: raw ring 2 x 32 KB + plane ring 2 x 48 KB = 160 KB.
+// 16 points form a stage.  Wave w owns one quarter of a stage (operand w>>1, column half w&1): it loads the raw fp32 rows
+// straight into registers in MFMA operand layout (lane = column quad 4i..4i+3 x 8 consecutive points, one stage ahead), splits
+// every value ONCE into three bf16 terms and writes the planes to LDS; consumers (two waves per quarter) read planes only and
+// run the six leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
+// History: every wave splitting both of its halves in registers (250 VGPRs, twice the VALU work) 1.75 ms; raw rows staged
+// through LDS by LDS-DMA, scheduler-ordered stage 1.55 ms (an LDS-DMA instruction costs its wave 60-185 cycles of issue, 8 per
+// stage; ablation: MFMA 0.9 + split 0.35 + DMA 0.17 ms, fully additive); this version see DESIGN.md.
+//   LDS: plane ring 2 x 48 KB = 96 KB.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int W3P_RAW = 2 * W3_PTS * 256;                 // floats per raw stage (32 KB)
 constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
-constexpr int W3P_LDS_BYTES = (2 * W3P_RAW + 2 * W3P_PL) * 4;
+constexpr int W3P_LDS_BYTES = 2 * W3P_PL * 4;
 
-// BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time, so that the point-major
-// instance keeps the round-1 code exactly: runtime selects cost 5 % here through a worse MFMA / split interleave)
+// BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time: a runtime select inside the
+// stage costs 5 % through a worse instruction stream).
 // NPL = split planes per operand: 3 = bf16x3 (six partial products, error 2^-24: fp32-equivalent); 2 = bf16x2 (x = x0 + x1, the
-// three products a0b0, a0b1, a1b0; per-product error <= 3 * 2^-18, I2SDF_OPT_WGRAD_BF16X2 -- see the note at the option)
-template <bool BLKA, bool BLKB, int NPL>
+// three products a0b0, a0b1, a1b0; per-product error <= 3 * 2^-18, I2SDF_OPT_WGRAD_BF16X2 -- see the note at the option).
+// PLAIN = every job of this workgroup covers whole 16-point stages and no operand needs a ReLU: the row masks and the max are
+// compiled out (all but the last chunk of a launch).
+//
+// The stage is a HAND-PLACED instruction stream.  One wave per SIMD issues in order, and an MFMA (32 cycles of pipe time) hides
+// at most ~5 other instructions behind it (MI355X_MICROARCH.md).  Measured by ablation on the scheduler's own order (first half
+// of a stage's MFMAs bare, the whole split packed into the second half, DMA pieces as one burst): MFMA 0.9 ms + split 0.35 ms +
+// DMA issue 0.17 ms, i.e. fully additive; sched_group_barrier pipelines did not change that.  So the stage is cut into one UNIT
+// per MFMA, fenced with sched_barrier(0): the MFMA, one sixth of a split item (2 values -> 3 planes, 11-17 VALU over 6 units; the
+// 16 items of a quarter fill the 96 units exactly) and at most one LDS / DMA instruction, each at least half a phase ahead of
+// its consumer.  (Build flags: -fno-slp-vectorize keeps the units' scalar ops from being merged into packed ops at one place,
+// and packed f32 VALU is slow beside MFMAs anyway; the lifted pragma-unroll cap keeps the 96-unit loop unrolled.)
+template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
 __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
-  float* rawb = lds;
-  float* plb = lds + 2 * W3P_RAW;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float* plb = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the DMA base addresses built from it stay in SGPRs
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x;
@@ -288,110 +299,121 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     if (m_hi <= m_lo) continue;
     const int rows = (int)(m_hi - m_lo);
     const int nst = (rows + W3_PTS - 1) / W3_PTS;
-    const float* dbase = (opB ? job.B : job.A) + m_lo * (opB ? job.ldb : job.lda) + 128 * (w & 1) + 4 * i32;
     const int dld = opB ? job.ldb : job.lda;
-    // Blocked operand (mlp_common.h): a 16-point stage x one 16-wide k-chunk is ONE contiguous 1 KB run, i.e. one DMA piece.
-    // Piece j of this wave's quarter = k-chunk 8*(w&1)+j; lane L fetches column quad L&3 of point
-    // 4*(L>>4) + 2*(((L>>3)&1) ^ (j&1)) + (((L>>2)&1) ^ ((j>>1)&1)): every aligned group of 8 lanes still fetches one whole 128 B line
-    // (two neighbouring points), and the swap pattern puts the four k-chunks a 16-lane group reads later into different LDS
-    // banks (conflict-free ds_read_b128).
     const bool blk = opB ? BLKB : BLKA;        // (host: both jobs of a task share the operands' layouts)
-    const bool blk_lds = blk, blk_glb = blk;
-    const float* bbase = (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * (w & 1)) * 512 + 4 * (lane & 3);
-    const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
-    const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    // raw rows of stage s: 8 DMA pieces of this wave's quarter (clamped rows are masked when they are split).  Branch-free in
-    // `blk` (a scalar branch inside the stage loop would cut the MFMA / split interleave into basic blocks): per piece j the lane's
-    // point of the stage is rj[j], and the row's float offset is selected from the two layouts
-    int rj[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      rj[j] = blk_glb ? 4 * (lane >> 4) + 2 * (((lane >> 3) & 1) ^ (j & 1)) + (((lane >> 2) & 1) ^ ((j >> 1) & 1)) : 8 * kg + j;
-    const float* fbase = blk_glb ? bbase : dbase;
-    const int pstep = blk_glb ? 512 : 0;              // blocked: piece j is k-chunk j of the quarter
-    auto issue = [&](int s) __attribute__((always_inline)) {
-      float* dst = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int row = s * W3_PTS + rj[j];
-        row = row < rows ? row : rows - 1;
-        const int64_t off = blk_glb ? (int64_t)((row >> 5) * 8192 + (row & 31) * 16) : (int64_t)row * dld;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(fbase + off + j * pstep),
-                                         (__attribute__((address_space(3))) void*)(dst + j * 256), 16, 0, 0);
-      }
-    };
-    // LDS float offsets (inside this wave's 8 pieces) of the two points of pair i for this lane
-    int olo[4], ohi[4];
+    // Raw rows of stage s: this lane holds columns 4*i32 .. 4*i32+3 of its quarter for the 8 points 8*kg .. 8*kg+7, as four
+    // point pairs (rlo[i], rhi[i]) = rows 8*kg+2i, 8*kg+2i+1 -- eight 16-byte loads per stage, address = scalar base + scalar
+    // stage offset + a per-lane offset computed once per job (voff).  Rows of the last, partial stage that lie beyond `rows`
+    // are read from the operand's padding (every operand has rows up to a multiple of 128, include/i2sdf.h) and masked when
+    // they are split.
+    //   point-major: the 32 lanes of one kg read 512 contiguous bytes of a row
+    //   blocked (mlp_common.h): columns 4*i32.. of point r sit at r*16 + (i32>>2)*512 + 4*(i32&3): groups of 4 lanes read the 64
+    //     bytes one point has in a k-chunk, and the pair's other point is the neighbouring 64 bytes (same 128 B line)
+    const float* ubase = blk ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * wb) * 512
+                             : (opB ? job.B : job.A) + m_lo * dld + 128 * wb;
+    unsigned voff[4];                           // bytes, row 8*kg + 2i; the pair's second row is `vnext` further
+    const unsigned vnext = 4u * (unsigned)(blk ? 16 : dld);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = i32 >> 2, q = i32 & 3, pt = 8 * kg + 2 * i;
-      // position of (point pt, quad q) inside piece j as the fetch laid it out (pt is even: pt + 1 only flips the lowest bit)
-      const int pos = 16 * (pt >> 2) + 8 * (((pt >> 1) & 1) ^ (j & 1)) + 4 * ((j >> 1) & 1) + q;
-      olo[i] = blk_lds ? j * 256 + pos * 4 : (2 * i) * 256 + lane * 4;
-      ohi[i] = blk_lds ? j * 256 + (pos ^ 4) * 4 : (2 * i + 1) * 256 + lane * 4;
+      const int r = 8 * kg + 2 * i;
+      voff[i] = 4u * (unsigned)(blk ? r * 16 + (i32 >> 2) * 512 + 4 * (i32 & 3) : r * dld + 4 * i32);
     }
-    unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
-    // point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: read raw, mask / relu / bias sums, split
-    auto split_pair = [&](int s, int i) __attribute__((always_inline)) {
-      const float* src = rawb + (s & 1) * W3P_RAW + (w * 8) * 256;
-      f32x4 lo = *reinterpret_cast<const f32x4*>(src + olo[i]), hi_ = *reinterpret_cast<const f32x4*>(src + ohi[i]);
-      const int p0 = s * W3_PTS + 8 * kg + 2 * i;
-      const float k0 = p0 < rows ? 1.f : 0.f, k1 = p0 + 1 < rows ? 1.f : 0.f;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        const float x0 = fmaxf(lo[tt], relu_lo) * k0, x1 = fmaxf(hi_[tt], relu_lo) * k1;
-        bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
-        if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
-        else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
-      }
+    const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
+    const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
+    f32x4 rlo[4], rhi[4];
+    auto gload = [&](int s, int i, int half) __attribute__((always_inline)) {
+      const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches two stages ahead without a branch)
+      const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
+      const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
+      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
+      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
     };
-    auto write_planes = [&](int s) __attribute__((always_inline)) {
+    unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
+    // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
+    auto prep = [&](int s, int i, float lo, float hi_, float& x0, float& x1) __attribute__((always_inline)) {
+      if (PLAIN) { x0 = lo; x1 = hi_; return; }
+      const int p0 = s * W3_PTS + 8 * kg + 2 * i;
+      x0 = p0 < rows ? fmaxf(lo, relu_lo) : 0.f;
+      x1 = p0 + 1 < rows ? fmaxf(hi_, relu_lo) : 0.f;
+    };
+    auto write_tile = [&](int s, int tt, int p) __attribute__((always_inline)) {
       float* dst = plb + (s & 1) * W3P_PL + w * (4 * 3 * 256) + lane * 4;
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-        for (int p = 0; p < NPL; ++p)
-          *reinterpret_cast<u32x4*>(dst + (tt * 3 + p) * 256) = u32x4{pl[tt][p][0], pl[tt][p][1], pl[tt][p][2], pl[tt][p][3]};
+      *reinterpret_cast<u32x4*>(dst + (tt * 3 + p) * 256) = u32x4{pl[tt][p][0], pl[tt][p][1], pl[tt][p][2], pl[tt][p][3]};
     };
     auto plane = [&](int s, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
       return *reinterpret_cast<const u32x4*>(plb + (s & 1) * W3P_PL + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
     };
-    __syncthreads();                       // the previous job is done with LDS
-    issue(0);
-    if (nst > 1) issue(1);
-    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split_pair(0, i);
-    write_planes(0);
-    // one stage.  MORE: stage s+1 exists and is split here, spread over the four MFMA phases
+    for (int i = 0; i < 4; ++i) { gload(0, i, 0); gload(0, i, 1); }
+    __syncthreads();                       // the previous job is done with LDS
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {          // stage 0 is split up front
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        float x0, x1;
+        prep(0, i, rlo[i][tt], rhi[i][tt], x0, x1);
+        bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
+        if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
+        else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { gload(1, i, 0); gload(1, i, 1); }
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int p = 0; p < NPL; ++p) write_tile(0, tt, p);
+    // one stage.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
+    // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use; a second
+    // register set for two stages of distance needs the stage body twice, by parity, and then spills)
     auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
-      // raw(s+1) was DMA'd one stage ago.  hipcc tracks LDS DMA per address and does NOT drain vmcnt at this barrier (the
-      // ISA shows lgkmcnt(0) only), so the wait is explicit: vmcnt(0) = every DMA piece this wave issued has landed.
-      __builtin_amdgcn_s_waitcnt(0x0F70);
-      __syncthreads();                     // planes(s) written, raw(s+1) landed, everyone done with stage s-1
-      if (s + 2 < nst) issue(s + 2);       // into the raw slot of stage s (already split)
-      u32x4 ap[4][NPL];
+      constexpr int NQ = (NPL == 3 ? 6 : 3), PH = 4 * NQ, NM = 4 * PH, GPI = NM / 16;     // MFMAs per phase / stage, units per item
+      __syncthreads();                     // planes(s) written, everyone done with stage s-1
+      u32x4 ap[4][NPL], bp[2][NPL];
+      // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
+      // waits for two loads, not for fifteen
 #pragma unroll
-      for (int ta = 0; ta < 4; ++ta)
+      for (int p = 0; p < NPL; ++p) {
+        bp[0][p] = plane(s, 2 + wb, 0, p);
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) ap[ta][p] = plane(s, wa, ta, p);
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        u32x4 bp[NPL];
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) bp[p] = plane(s, 2 + wb, tb, p);
-#pragma unroll
-        for (int q = 0; q < (NPL == 3 ? 6 : 3); ++q) {
-          // (sa, sb): NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
-          const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
-          const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
-#pragma unroll
-          for (int ta = 0; ta < 4; ++ta) acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[sb], acc[ta][tb]);
-        }
-        if (MORE) split_pair(s + 1, tb);
+        for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(s, wa, ta, p);
       }
-      if (MORE) write_planes(s + 1);
+      float x0 = 0.f, x1 = 0.f, ra = 0.f, rb = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        const int tb = g / PH, gg = g % PH, q = gg / 4, ta = g % 4;
+        // (sa, sb): NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
+        const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
+        const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
+        acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[tb & 1][sb], acc[ta][tb]);
+        if (MORE) {
+          // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
+          const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
+          if (st == 0) prep(s + 1, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
+          if (NPL == 3) {
+            if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
+            if (st == 3) pl[tt][1][i] = pk_bf16(ra, rb);
+            if (st == 4) { ra -= bf16_lo(pl[tt][1][i]); rb -= bf16_hi(pl[tt][1][i]); }
+            if (st == 5) pl[tt][2][i] = pk_bf16(ra, rb);
+          } else {
+            if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
+          }
+          // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
+          if (it >= 13 && st < NPL) write_tile(s + 1, tt - 1, st);
+          if (tt == 3 && st == 1) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2) gload(s + 2, i, 1);
+        }
+        // LDS reads of the next phase, one instruction per unit, half a phase ahead
+        if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(s, 2 + wb, tb + 1, gg - PH / 2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (MORE) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) write_tile(s + 1, 3, p);
+      }
     };
     using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
     for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
@@ -417,13 +439,25 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
 template <int NPL>
 __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const WgJob& j0 = L.t[blockIdx.y].j[0];
+  const WgTask& t = L.t[blockIdx.y];
   const int64_t m_lo = (int64_t)blockIdx.x * WG_CH;
-  const bool ba = m_lo < j0.a_blk, bb = m_lo < j0.b_blk;       // workgroup-uniform
-  if (ba && bb) wgrad3p_body<true, true, NPL>(L, lds);
-  else if (ba) wgrad3p_body<true, false, NPL>(L, lds);
-  else if (bb) wgrad3p_body<false, true, NPL>(L, lds);
-  else wgrad3p_body<false, false, NPL>(L, lds);
+  const bool ba = m_lo < t.j[0].a_blk, bb = m_lo < t.j[0].b_blk;       // workgroup-uniform
+  bool plain = t.relu_b == 0;
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const int64_t left = t.j[jb].m_count - m_lo;
+    plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
+  }
+  if (plain) {
+    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
+    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
+    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
+    else wgrad3p_body<false, false, NPL, true>(L, lds);
+  } else {
+    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
+    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
+    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
+    else wgrad3p_body<false, false, NPL, false>(L, lds);
+  }
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------

@@ -5,11 +5,13 @@ R=${1:-r2}
 BARGS="--no-cpu-baseline --no-extras --scaling weak"     # the headline workload only (same kernels as the default command)
 O=gpurun_out/profiles_$R
 mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O -o ${R}_bench --output-format csv -- python bench.py --steps 5 --warmup 2 $BARGS > $O/${R}_bench_under_rocprof.log 2>&1
+PASSES=${PASSES:-"stats sq fetch write"}      # e.g. PASSES=sq for a quick look at one kernel's issue counters
+has() { [[ " $PASSES " == *" $1 "* ]]; }
+has stats && rocprofv3 --kernel-trace --stats -d $O -o ${R}_bench --output-format csv -- python bench.py --steps 5 --warmup 2 $BARGS > $O/${R}_bench_under_rocprof.log 2>&1
 run() { rocprofv3 --kernel-trace --pmc $2 -d $O -o ${R}_$1 --output-format csv -- python bench.py --steps 2 --warmup 1 $BARGS > $O/${R}_$1.log 2>&1; }
-run sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
-run fetch "FETCH_SIZE"
-run write "WRITE_SIZE"
+has sq && run sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+has fetch && run fetch "FETCH_SIZE"
+has write && run write "WRITE_SIZE"
 python - <<PY
 import csv, glob, collections, os
 R="$R"; O="$O"
