@@ -8,7 +8,7 @@ mkdir -p ../lib ../lib/obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result"
 X3FLAGS="-mllvm -pragma-unroll-threshold=1000000"     # only where the bf16x3 training kernels live
 pids=()
-for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip mlp_x3.hip mlp_x3r.hip render.hip mlp_bwd.hip wgrad.hip sampler.hip loss.hip optim.hip grid.hip "$@"; do
+for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip mlp_x3.hip mlp_x3r.hip render.hip mlp_bwd.hip wgrad.hip sampler.hip loss.hip optim.hip grid.hip draws.hip "$@"; do
   o=../lib/obj/$(basename ${f%.*}).o
   stale=0
   for h in "$f" *.h ../../include/i2sdf.h build.sh; do [ "$h" -nt "$o" ] && stale=1; done

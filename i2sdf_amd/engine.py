@@ -355,6 +355,19 @@ class RenderEngine:
         return o
 
     # -- sampler -----------------------------------------------------------------------------------
+    def training_draws(self, B: int, seed: int, device, eik_radius: float = 0.0, want_eik: bool = True):
+        """Every random draw of one training forward in ONE launch (include/i2sdf.h: i2sdf_training_draws): dict(strat_u (B,N_eval),
+        cdf_u (B,N_samples), extra_idx (max_total_iters, N_extra) int32 | None, eik_idx (B) int32, eik_pts (B,3), nbr_off (B,3))."""
+        sc = self.cfg.sampler
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=device)
+        d = {"strat_u": e(B, sc.N_samples_eval), "cdf_u": e(B, sc.N_samples),
+             "extra_idx": e(sc.max_total_iters, sc.N_samples_extra, dt=torch.int32) if sc.N_samples_extra > 0 else None,
+             "eik_idx": e(B, dt=torch.int32), "eik_pts": e(B, 3) if want_eik else None, "nbr_off": e(B, 3) if want_eik else None}
+        L.check(self._lib.i2sdf_training_draws(int(seed) & (2 ** 64 - 1), B, sc.N_samples_eval, sc.N_samples, sc.N_samples_extra, sc.max_total_iters,
+                                               self.n_z, float(eik_radius), 0.005, L.ptr(d["strat_u"]), L.ptr(d["cdf_u"]), L.ptr(d["extra_idx"]),
+                                               L.ptr(d["eik_idx"]), L.ptr(d["eik_pts"]), L.ptr(d["nbr_off"]), L.stream_ptr()), "i2sdf_training_draws")
+        return d
+
     def sample_rays(self, flat_params, cam, dirs, training=False, strat_u=None, cdf_u=None, extra_idx=None, eik_idx=None, force_iters=0):
         """ErrorBoundSampler.get_z_vals on the device.  Returns z_all (B, N_samples+N_extra+2), z_eik (B,1), iters (device int32)."""
         B, dev = cam.shape[0], cam.device

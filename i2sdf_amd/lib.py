@@ -133,6 +133,8 @@ SIGNATURES = {
     "i2sdf_sdf_grid": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _I64, _I64, _P, _P, _I64, _P]),
     # pred, target, channels, pixel_idx, first_pixel, n, pointlinks, n_links, pdf_max, pdf_prune, pdf, n_pdf, n_bad, stream
     "i2sdf_pdf_update": (C.c_int, [_P, _P, _I32, _P, _I64, _I64, _P, _I64, C.c_double, C.c_double, _P, _I64, _P, _P]),
+    # seed, B, n_eval, n_samples, n_extra, max_iters, n_z, eik_radius, nbr_half_width, strat_u, cdf_u, extra_idx, eik_idx, eik_pts, nbr_off, stream
+    "i2sdf_training_draws": (C.c_int, [C.c_uint64, _I64, _I32, _I32, _I32, _I32, _I32, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_loss_scratch_floats": (_I64, []),

@@ -7,6 +7,8 @@ the C ABI of include/i2sdf.h; there is no CPU / eager-torch fallback for it.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional
 
 import torch
@@ -212,6 +214,8 @@ class I2SDFNetwork(nn.Module):
             raise NotImplementedError("detach_light_feature=False is not supported by the fused light head")
         self.layout = ParamLayout(cfg)
         self.force_iters = 0            # >0: fixed sampler iteration count (benchmarks); 0: the reference's data-dependent loop
+        # all random draws of a training forward in one library launch (False / I2SDF_FUSED_DRAWS=0: separate torch ops)
+        self.fused_draws = os.environ.get("I2SDF_FUSED_DRAWS", "1") != "0"
         self.grad_sync = None           # callable(flat_grad) for data-parallel training (i2sdf_amd.dist)
         self.dp_state = None            # i2sdf_amd.dist.DataParallelState once attach_data_parallel() was called
         self.last_sampler_iters = None  # device int32 tensor of the last forward
@@ -299,8 +303,15 @@ class I2SDFNetwork(nn.Module):
         dev = cam.device
         training = self.training
         draws = draws or {}
+        user_extra = "extra_idx" in draws
         with torch.cuda.device(dev), torch.no_grad():
             if training:
+                if not draws and self.fused_draws:
+                    # production path: one launch for all draws of this forward, keyed by a 62-bit seed from torch's CPU generator
+                    # (so torch.manual_seed / pl.seed_everything still decide the run); explicit `draws` (tests) bypass it
+                    seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                    draws = eng.training_draws(N, seed, dev, self.scene_bounding_sphere, want_eik=not predict_only)
+                    draws = {k: v for k, v in draws.items() if v is not None}
                 strat_u = draws.get("strat_u")
                 if strat_u is None:
                     strat_u = torch.rand(N, sc.N_samples_eval, device=dev)
@@ -320,7 +331,7 @@ class I2SDFNetwork(nn.Module):
                 if dp is not None and dp.equivalent:
                     # 1-GPU-equivalent data parallelism: the reference draws ONE randperm for all rays of a batch (ray_sampler.py:223),
                     # so every rank must use rank 0's columns; and the convergence test is the OR over all ranks (device-side hook)
-                    if "extra_idx" not in draws and extra is not None:
+                    if not user_extra and extra is not None:
                         extra = extra.contiguous()
                         if dp.comm is not None:
                             dp.comm.broadcast(extra, 0)

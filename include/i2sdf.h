@@ -494,6 +494,19 @@ int i2sdf_pdf_update(const float* pred, const float* target, int32_t channels, c
                      int64_t n, const int64_t* pointlinks, int64_t n_links, double pdf_max, double pdf_prune, float* pdf,
                      int64_t n_pdf, int32_t* n_bad, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * All random draws of one training forward in one launch (Philox4x32-10 keyed by `seed`; a different stream, not torch's) --
+ * the torch.rand / randperm / randint / uniform_ calls of ray_sampler.py:60-66,176-177,223,234 and
+ * model/network/__init__.py:177,184.  Every output may be NULL (not drawn):
+ *   strat_u (B, n_eval) in [0,1)      stratified jitter            cdf_u (B, n_samples) in [0,1)   inverse-CDF draws
+ *   extra_idx (max_iters, n_extra)    row it = n_extra distinct columns of [0, n_eval*(it+1)) in random order
+ *                                     (= randperm(n)[:n_extra] for the row length the sampler has after `it` iterations)
+ *   eik_idx (B) in [0, n_z)           eik_pts (B,3) in [-eik_radius, eik_radius)    nbr_off (B,3) in [-w, w), w = nbr_half_width
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_training_draws(uint64_t seed, int64_t B, int32_t n_eval, int32_t n_samples, int32_t n_extra, int32_t max_iters,
+                         int32_t n_z, float eik_radius, float nbr_half_width, float* strat_u, float* cdf_u,
+                         int32_t* extra_idx, int32_t* eik_idx, float* eik_pts, float* nbr_off, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
