@@ -253,8 +253,7 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 // every value ONCE into three bf16 terms and writes the planes to LDS; consumers (two waves per quarter) read planes only and
 // run the six leading partial products: 96 MFMAs of 32 cycles per stage and wave, where the fp32 kernel needs 128 of 64 cycles.
 // History: every wave splitting both of its halves in registers (250 VGPRs, twice the VALU work) 1.75 ms; raw rows staged
-// through LDS by LDS-DMA, scheduler-ordered stage 1.55 ms (an LDS-DMA instruction costs its wave 60-185 cycles of issue, 8 per
-// stage; ablation: MFMA 0.9 + split 0.35 + DMA 0.17 ms, fully additive); this version see DESIGN.md.
+// through LDS by LDS-DMA, scheduler-ordered stage 1.55 ms; this version (hand-placed stream, register loads) 1.35 ms, DESIGN.md.
 //   LDS: plane ring 2 x 48 KB = 96 KB.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
@@ -268,18 +267,17 @@ constexpr int W3P_LDS_BYTES = 2 * W3P_PL * 4;
 // compiled out (all but the last chunk of a launch).
 //
 // The stage is a HAND-PLACED instruction stream.  One wave per SIMD issues in order, and an MFMA (32 cycles of pipe time) hides
-// at most ~5 other instructions behind it (MI355X_MICROARCH.md).  Measured by ablation on the scheduler's own order (first half
-// of a stage's MFMAs bare, the whole split packed into the second half, DMA pieces as one burst): MFMA 0.9 ms + split 0.35 ms +
-// DMA issue 0.17 ms, i.e. fully additive; sched_group_barrier pipelines did not change that.  So the stage is cut into one UNIT
-// per MFMA, fenced with sched_barrier(0): the MFMA, one sixth of a split item (2 values -> 3 planes, 11-17 VALU over 6 units; the
-// 16 items of a quarter fill the 96 units exactly) and at most one LDS / DMA instruction, each at least half a phase ahead of
-// its consumer.  (Build flags: -fno-slp-vectorize keeps the units' scalar ops from being merged into packed ops at one place,
+// at most ~5 other instructions behind it (MI355X_MICROARCH.md).  The scheduler's own order ran the first half of a stage's MFMAs
+// bare and packed the whole split between the MFMAs of the second half, eight VALU per MFMA (50 % MFMA-busy); sched_group_barrier
+// pipelines changed the static order but not the time.  So the stage is cut into one UNIT per MFMA, fenced with
+// sched_barrier(0): the MFMA, one sixth of a split item (2 values -> 3 planes, 11-17 VALU over 6 units; the 16 items of a
+// quarter fill the 96 units exactly) and at most one LDS / global-memory instruction, each well ahead of its consumer.  (Build flags: -fno-slp-vectorize keeps the units' scalar ops from being merged into packed ops at one place,
 // and packed f32 VALU is slow beside MFMAs anyway; the lifted pragma-unroll cap keeps the 96-unit loop unrolled.)
 template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
 __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   float* plb = lds;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the DMA base addresses built from it stay in SGPRs
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x;
