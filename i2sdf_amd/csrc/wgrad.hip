@@ -624,7 +624,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
                                   int64_t n_chunks_cap, float* grad_flat, void* stream) {
   if (!p || !tb || !params || !partials || !grad_flat) return I2SDF_EINVAL;
   const int64_t Mp = tb->Mp, Ms = tb->M_sdf, Mm = tb->M_main;
-  if (Ms <= 0 || Mm < 0 || Mm > Ms || Mp < Ms) return I2SDF_EINVAL;
+  if (Ms <= 0 || Mm < 0 || Mm > Ms || Mp < Ms || Mp % 128 != 0) return I2SDF_EINVAL;    // (the kernels read whole 16-point stages: into the padding rows)
   const int n_chunks = (int)((Ms + WG_CH - 1) / WG_CH);
   if (n_chunks > n_chunks_cap) return I2SDF_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;

@@ -288,6 +288,8 @@ int i2sdf_composite_backward(const float* beta_param, float beta_min, const floa
  * reduced over all points, then the weight-norm backward (d/dg, d/dv of W = g v/||v||) and bias gradients, written
  * into `grad_flat` (same layout as `params`; entries of nets that took no part are left untouched).
  * All pointers are the per-point workspaces the kernels above produced ([Mp][ld], see their comments).
+ * Every one of them has Mp rows, Mp a multiple of 128 (as the producing kernels require): the bf16x3 kernel reads whole 16-point
+ * stages, i.e. up to 15 rows past M_sdf / M_main, and masks them -- the padding rows may hold anything but must exist.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct i2sdf_train_buffers {
   int64_t M_sdf;    /* points that went through the SDF network (render + eikonal + bubble points) */
