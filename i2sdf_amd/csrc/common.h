@@ -351,10 +351,24 @@ __device__ __forceinline__ void rowvec_op(WStream& ws, const float (&in)[KC * 4]
 // (1,2] and log2(1+z) has an ABSOLUTE error of ~1 ulp(1) = 6e-8, i.e. 6e-10 on h after the /100 -- below fp32 resolution of
 // the O(0.01..1) activations it is added to; above the threshold z < 2e-9 vanishes against 1 and h == a exactly (torch's
 // threshold branch).  6 VALU ops, 2 of them transcendental.
+// max(a, 0) as ONE instruction: fmaxf() makes hipcc put a canonicalising v_max_f32 x,x,x in front of the v_max (the operand
+// could be a signalling NaN); beside MFMAs every VALU slot counts (8 of them per k-chunk in the bf16x3 forward).  Only in the
+// translation units that define I2SDF_RELU_ASM (the bf16x3 kernels, built with the lifted unroll cap): the unroller prices an
+// inline-asm statement far above one instruction, and in the other units the fully unrolled stage loops would fall back to rolled
+// loops with their register arrays in scratch (measured: the sampler's forward 24x slower).
+__device__ __forceinline__ float relu0(float a) {
+#ifdef I2SDF_RELU_ASM
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a));
+  return r;
+#else
+  return fmaxf(a, 0.f);
+#endif
+}
 __device__ __forceinline__ float softplus100(float a) {
   const float z = __builtin_amdgcn_exp2f(-fabsf(a) * (100.f * 1.44269504088896341f));
   const float l = __builtin_amdgcn_logf(1.0f + z);                 // log2
-  return fmaf(l, 0.693147180559945309f * 0.01f, fmaxf(a, 0.f));
+  return fmaf(l, 0.693147180559945309f * 0.01f, relu0(a));
 }
 // sigma = softplus100'(a) recovered from h = softplus100(a):  1 - exp(-100 h)   (exactly 1 in the threshold
 // branch up to rounding: 1 - e^-20 rounds to 1.0f).

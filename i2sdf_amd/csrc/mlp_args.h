@@ -15,6 +15,7 @@ struct SdfTrainFwdArgs {
   float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
   float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
   int kcs = 16;                         // layout of hs / abars for the points of THIS launch: 16 point-major, 512 blocked (mlp_common.h)
+  int wg0 = 0;                          // first 128-point workgroup of this launch (point ranges, plan.h: PartRun)
 };
 
 struct SdfBwdArgs {
@@ -33,6 +34,7 @@ struct SdfBwdArgs {
   float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
   float* ones4;                         // (Mp,4) {1,0,0,0}
   int kcs = 16;                         // layout of hs / abars / gus / gas for the points of this launch
+  int wg0 = 0;                          // first 128-point workgroup of this launch
 };
 
 struct RgbFwdArgs {
@@ -44,6 +46,7 @@ struct RgbFwdArgs {
   float* rs;                            // (L-1, Mp, H) post-ReLU activations r_1..r_{L-1}, or nullptr
   float* pev_save;                      // (Mp, PECV*8) PE(view dir), or nullptr
   int kcs = 16;                         // layout of rs for the points of this launch
+  int wg0 = 0;                          // first 128-point workgroup of this launch
 };
 
 struct RgbBwdArgs {
@@ -56,6 +59,7 @@ struct RgbBwdArgs {
   float* ga_last;           // (Mp, 4)       G(a_{L-1}) (3 used)
   float* fbar;              // (Mp, F)
   int kcs = 16;             // layout of rs / gar for the points of this launch
+  int wg0 = 0;              // first 128-point workgroup of this launch
 };
 
 // bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void sdf_bwd_kernel(SdfBwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FC = F / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void rgb_bwd_kernel(RgbBwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, FT = F / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -413,7 +413,19 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       a3.kcs = sdf_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
       i2sdf_launch_sdf_bwd3(a3, g, st, p->src_ring != 0);
     };
-    if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
+    if (x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun): both sweeps of a range on the range's stream
+      PartRun pr;
+      i2sdf_parts_begin(p, st, M, &pr);
+      for (int q = 0; q < pr.n; ++q) {
+        if (pr.hi[q] <= pr.lo[q]) continue;
+        st = pr.st[q];
+        a.wg0 = (int)(pr.lo[q] / PTS_PER_WG);
+        launch3((unsigned)((pr.hi[q] - pr.lo[q] + PTS_PER_WG - 1) / PTS_PER_WG));
+      }
+      st = (hipStream_t)stream;
+      a.wg0 = 0;
+      i2sdf_parts_end(p, st, &pr);
+    } else if (bulk > 0) {          // full rounds + the partial last round as split-K workgroups (ksplit.h)
       hipStream_t ts = i2sdf_tail_fork(p, st);       // tail first, on the side stream when the overlap is on (plan.h)
       launch_lds_bytes(KS_LDS_BYTES, sdf_bwd_split_kernel<256, 256, 6>, (unsigned)((M - bulk + 31) / 32), ts, a, bulk);
       a.M = bulk;
@@ -459,7 +471,19 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
         launch_lds(rgb_bwd_kernel<256, 256>, g, st, x);
       }
     };
-    if (bulk > 0) {
+    if (p->rgb_bf16x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun)
+      PartRun pr;
+      i2sdf_parts_begin(p, st, M, &pr);
+      for (int q = 0; q < pr.n; ++q) {
+        if (pr.hi[q] <= pr.lo[q]) continue;
+        st = pr.st[q];
+        RgbBwdArgs b = a;
+        b.wg0 = (int)(pr.lo[q] / PTS_PER_WG);
+        full(b, (unsigned)((pr.hi[q] - pr.lo[q] + PTS_PER_WG - 1) / PTS_PER_WG));
+      }
+      st = (hipStream_t)stream;
+      i2sdf_parts_end(p, st, &pr);
+    } else if (bulk > 0) {
       a.M = bulk;
       full(a, (unsigned)(bulk / PTS_PER_WG));
       a.M = M;

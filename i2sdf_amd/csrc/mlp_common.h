@@ -51,11 +51,13 @@ inline bool sdf_x3_path(const i2sdf_plan* p) {
 // leading points of a batch of M points whose saved SDF tensors are in the blocked layout (0 = none)
 inline int64_t sdf_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp, bool has_feat = true) {
   if (!p->blocked_saves || !sdf_x3_path(p)) return 0;
+  if (i2sdf_parts_on(p)) return Mp;                           // point ranges: no split-K tail, everything blocked
   const int64_t bulk = split_bulk_points(M, p->n_cu);
   return (bulk > 0 && has_feat) ? bulk : Mp;
 }
 inline int64_t rgb_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp) {
   if (!p->blocked_saves || !p->rgb_bf16x3 || p->rgb.d.hidden != 256 || p->F != 256) return 0;
+  if (i2sdf_parts_on(p)) return Mp;
   const int64_t bulk = split_bulk_points(M, p->n_cu);
   return bulk > 0 ? bulk : Mp;
 }

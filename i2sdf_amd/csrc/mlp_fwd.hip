@@ -5,6 +5,9 @@
 using namespace i2sdf;
 
 int i2sdf_hip_check(hipError_t e, const char* what);
+// bf16x3 variant of the sdf-only forward: sdf_fwd3_kernel lives in mlp_x3.hip (the translation unit with the lifted unroll cap)
+void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
+                           float* sdf_out, unsigned grid, hipStream_t st);
 
 namespace {
 
@@ -59,51 +62,6 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
   }
 }
 
-// bf16x3 variant of the sdf-only forward (x3.h): same result to fp32 rounding level at 3/8 of the matrix-pipe cycles.
-template <int H, int LF>
-__global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
-                                                        const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out) {
-  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NPE = PE16 * 8;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  if (skip_flag != nullptr && skip_flag[0] != 0) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
-  const bool valid = m < M;
-  const int64_t mc = valid ? m : M - 1;
-  float px, py, pz;
-  fetch_point(ps, mc, px, py, pz);
-  float pe[NPE];
-  {
-    float full[PE<LF>::PEC * 8], pad[PE16 * 16];
-    pe_full<LF>(px, py, pz, full);
-#pragma unroll
-    for (int i = 0; i < PE16 * 16; ++i) pad[i] = (i < PED) ? full[i] : 0.f;
-    x3_select_pe<PE16>(pad, pe, hi);
-  }
-  WStream ws;
-  ws.begin(stream, lds, n_stages, tid);
-  f32x16 accP[NT], accN[NT];
-  {
-    X3FwdSrc<NT, 0, NPE, false> src{accN, pe, nullptr, hi, valid};
-    dense_x3g<NT, PE16, 1>(ws, src, accP, tid);
-  }
-  for (int l = 1; l < L - 1; ++l) {
-    X3FwdSrc<NT, KH16, NPE, false> src{accP, pe, nullptr, hi, valid};
-    if (l == skip) dense_x3g<NT, KH16 + PE16, 1>(ws, src, accN, tid);
-    else dense_x3g<NT, KH16, 1>(ws, src, accN, tid);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
-  }
-  float h[NT * 16];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accP[nt][r]);
-  float s[1];
-  rowvec_op<1, KC>(ws, h, s, tid);
-  if (valid && hi == 0) sdf_out[m] = s[0];
-}
-
 template <int H, int F, int LF>
 int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, const int* skip_flag, int64_t M, float* sdf_out,
                    float* feat_out, int64_t ld_feat, hipStream_t st) {
@@ -113,8 +71,7 @@ int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, c
   if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && p->sdf.fwd3_chunks > 0) {
     const float* s3 = packed + p->scale_floats + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;
     const int ns3 = sdf_fwd3_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
-    launch_lds(sdf_fwd3_kernel<H, LF>, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st, s3, ns3, d.n_lin, d.skip_layer, points,
-               skip_flag, M, sdf_out);
+    i2sdf_launch_sdf_fwd3(H, s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st);
     return i2sdf_hip_check(hipGetLastError(), "sdf_forward (bf16x3) launch");
   }
   const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);

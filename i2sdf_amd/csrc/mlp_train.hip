@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd_kernel(SdfTrainFwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32), FT = F / 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   float px, py, pz;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void rgb_fwd_kernel(RgbFwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, PECV = PE<LFV>::PEC, FC = F / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t ray = mc / a.n_per_ray;
@@ -396,7 +396,20 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st, p->src_ring != 0);                                            \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
-  if (p->H == 256 && p->F == 256) {
+  if (x3 && i2sdf_parts_on(p)) {
+    // point ranges (plan.h: PartRun): one launch pair per range, each on the range's own stream; no split-K tail
+    PartRun pr;
+    i2sdf_parts_begin(p, st, M, &pr);
+    for (int q = 0; q < pr.n; ++q) {
+      if (pr.hi[q] <= pr.lo[q]) continue;
+      st = pr.st[q];
+      a.wg0 = (int)(pr.lo[q] / PTS_PER_WG);
+      LAUNCH3((unsigned)((pr.hi[q] - pr.lo[q] + PTS_PER_WG - 1) / PTS_PER_WG));
+    }
+    st = (hipStream_t)stream;
+    a.wg0 = 0;
+    i2sdf_parts_end(p, st, &pr);
+  } else if (p->H == 256 && p->F == 256) {
     const int64_t bulk = split_bulk_points(M, p->n_cu);
     if (bulk > 0 && feat != nullptr) {      // full rounds + the partial last round as split-K workgroups (ksplit.h)
       const int64_t M_all = a.M;
@@ -453,7 +466,19 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
         launch_lds(rgb_fwd_kernel<256, 256, 4>, g, st, x);
       }
     };
-    if (bulk > 0) {          // full rounds with one 32-point tile per wave, the partial last round as split-K workgroups
+    if (p->rgb_bf16x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun)
+      PartRun pr;
+      i2sdf_parts_begin(p, st, M, &pr);
+      for (int q = 0; q < pr.n; ++q) {
+        if (pr.hi[q] <= pr.lo[q]) continue;
+        st = pr.st[q];
+        RgbFwdArgs b = a;
+        b.wg0 = (int)(pr.lo[q] / PTS_PER_WG);
+        full(b, (unsigned)((pr.hi[q] - pr.lo[q] + PTS_PER_WG - 1) / PTS_PER_WG));
+      }
+      st = (hipStream_t)stream;
+      i2sdf_parts_end(p, st, &pr);
+    } else if (bulk > 0) {          // full rounds with one 32-point tile per wave, the partial last round as split-K workgroups
       RgbFwdArgs b = a;
       b.M = bulk;
       full(b, (unsigned)(bulk / PTS_PER_WG));

@@ -1,11 +1,60 @@
 // bf16x3 split-arithmetic twins of the SDF training kernels (x3.h): forward with saves, d sdf/dx chain, backward sweeps.
 // Kept in their own translation unit: their fully unrolled K-outer stage loops need -mllvm -pragma-unroll-threshold (build.sh),
 // which the fp32 MFMA kernels must not be compiled with (it changes their unrolling and costs them ~4 %).
+#ifndef I2SDF_NO_RELU_ASM      // (A/B builds)
+#define I2SDF_RELU_ASM 1      // common.h: relu0
+#endif
 #include "mlp_args.h"
 
 using namespace i2sdf;
 
 namespace {
+
+// bf16x3 variant of the sdf-only forward (sampler passes, grid queries; fp32 twin: mlp_fwd.hip): same result to fp32 rounding level
+// at 3/8 of the matrix-pipe cycles.
+template <int H, int LF>
+__global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
+                                                        const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out) {
+  constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NPE = PE16 * 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  if (skip_flag != nullptr && skip_flag[0] != 0) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const bool valid = m < M;
+  const int64_t mc = valid ? m : M - 1;
+  float px, py, pz;
+  fetch_point(ps, mc, px, py, pz);
+  float pe[NPE];
+  {
+    float full[PE<LF>::PEC * 8], pad[PE16 * 16];
+    pe_full<LF>(px, py, pz, full);
+#pragma unroll
+    for (int i = 0; i < PE16 * 16; ++i) pad[i] = (i < PED) ? full[i] : 0.f;
+    x3_select_pe<PE16>(pad, pe, hi);
+  }
+  WStream ws;
+  ws.begin(stream, lds, n_stages, tid);
+  f32x16 accP[NT], accN[NT];
+  {
+    X3FwdSrc<NT, 0, NPE, false> src{accN, pe, nullptr, hi, valid};
+    dense_x3g<NT, PE16, 1>(ws, src, accP, tid);
+  }
+  for (int l = 1; l < L - 1; ++l) {
+    X3FwdSrc<NT, KH16, NPE, false> src{accP, pe, nullptr, hi, valid};
+    if (l == skip) dense_x3g<NT, KH16 + PE16, 1>(ws, src, accN, tid);
+    else dense_x3g<NT, KH16, 1>(ws, src, accN, tid);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
+  }
+  float h[NT * 16];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h[nt * 16 + r] = softplus100(accP[nt][r]);
+  float s[1];
+  rowvec_op<1, KC>(ws, h, s, tid);
+  if (valid && hi == 0) sdf_out[m] = s[0];
+}
 
 // bf16x3 variant (x3.h): same outputs and saved tensors, K-outer loops on the bf16 matrix pipe.  The activations of a layer
 // are produced (softplus, store, split) as the B operand of the NEXT op, one k-chunk ahead of their use; two accumulator
@@ -17,7 +66,7 @@ __global__ __launch_bounds__(256) void sdf_train_fwd3_kernel(SdfTrainFwdArgs a) 
   static_assert(NT == FT, "feature tiles reuse the hidden accumulator set");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   float px, py, pz;
@@ -79,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -154,7 +203,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   constexpr int NT = H / 32, KH16 = H / 16, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NGP = PE16 * 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -202,7 +251,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -262,7 +311,7 @@ __global__ __launch_bounds__(256) void rgb_fwd3_kernel(RgbFwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PECV = PE<LFV>::PEC, PEDV = PE<LFV>::DIM, PV16 = cdiv(PEDV, 16);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t ray = mc / a.n_per_ray;
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
   static_assert(FT == NT, "feature tiles reuse the hidden accumulator set");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -390,6 +439,11 @@ __global__ __launch_bounds__(256) void rgb_bwd3_kernel(RgbBwdArgs a) {
 
 }  // namespace
 
+void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
+                           float* sdf_out, unsigned grid, hipStream_t st) {
+  if (H == 256) launch_lds(sdf_fwd3_kernel<256, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
+  else launch_lds(sdf_fwd3_kernel<64, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
+}
 void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st, bool ring) {
   launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, grid, st, a);
   if (grad) {

@@ -1,6 +1,9 @@
 // bf16x3 kernels whose saved-tensor reads go through the per-wave LDS ring (x3r.h): backward sweeps, d sdf/dx chain, radiance
 // backward.  Same arguments, same arithmetic and same results as their twins in mlp_x3.hip (which keep the VGPR-load form of
 // the sources); selected by I2SDF_OPT_SRC_RING.  Own translation unit: each of these fully unrolled kernels takes minutes to compile.
+#ifndef I2SDF_NO_RELU_ASM      // (A/B builds)
+#define I2SDF_RELU_ASM 1      // common.h: relu0
+#endif
 #include "mlp_args.h"
 #include "x3r.h"
 
@@ -25,7 +28,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   float* ring = wave_ring(lds, wave);
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep1_kernel(SdfBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   float* ring = wave_ring(lds, wave);
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3r_sweep2_kernel(SdfBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   float* ring = wave_ring(lds, wave);
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void rgb_bwd3r_kernel(RgbBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   float* ring = wave_ring(lds, wave);
-  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * 32 + (lane & 31);
+  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * 4 + wave) * 32 + (lane & 31);
   const bool valid = m < a.M;
   const int64_t mc = valid ? m : a.M - 1;
   const int64_t lstride = a.Mp * H;

@@ -3,6 +3,7 @@
 #include <string.h>
 #include <string>
 #include "plan.h"
+#include <stdlib.h>
 
 using namespace i2sdf;
 
@@ -323,6 +324,8 @@ extern "C" void i2sdf_plan_destroy(i2sdf_plan* p) {
   if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
   if (p->ev_join) (void)hipEventDestroy(p->ev_join);
   if (p->side) (void)hipStreamDestroy(p->side);
+  for (hipEvent_t e : p->part_ev) if (e) (void)hipEventDestroy(e);
+  for (hipStream_t s : p->part_st) if (s) (void)hipStreamDestroy(s);
   delete p;
 }
 
@@ -351,8 +354,114 @@ void i2sdf_tail_join(const i2sdf_plan* p, hipStream_t st, hipStream_t side) {
   (void)hipStreamWaitEvent(st, p->ev_join, 0);
 }
 
+// ---- point ranges (plan.h: PartRun) ---------------------------------------------------------------------------------
+namespace {
+constexpr int64_t PART_ALIGN = 1024;          // == i2sdf_wgrad_chunk_points(): a weight-gradient chunk never straddles two ranges
+
+bool parts_resources(const i2sdf_plan* p) {
+  for (int q = 0; q < I2SDF_MAX_PARTS; ++q)
+    if (!p->part_ev[q] && hipEventCreateWithFlags(&p->part_ev[q], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  for (int q = 0; q + 1 < p->parts; ++q)
+    if (!p->part_st[q] && hipStreamCreateWithFlags(&p->part_st[q], hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return true;
+}
+// boundaries of n ranges over a batch of M points, in whole chunks.  Relative sizes: equal, or I2SDF_PART_WEIGHTS="w0,w1,..." (read
+// once; an experiment knob: unequal ranges finish their kernels at different times, which is what fills the partly empty rounds)
+void part_bounds(int64_t M, int n, int64_t (&b)[I2SDF_MAX_PARTS + 1]) {
+  static double w[I2SDF_MAX_PARTS] = {0, 0, 0, 0};
+  static int nw = -1;
+  if (nw < 0) {
+    nw = 0;
+    if (const char* e = getenv("I2SDF_PART_WEIGHTS")) {
+      while (*e && nw < I2SDF_MAX_PARTS) {
+        char* end = nullptr;
+        const double v = strtod(e, &end);
+        if (end == e) break;
+        w[nw++] = v > 0 ? v : 0;
+        e = (*end == ',') ? end + 1 : end;
+      }
+    }
+  }
+  const int64_t nch = (M + PART_ALIGN - 1) / PART_ALIGN;
+  double tot = 0, acc = 0;
+  for (int q = 0; q < n; ++q) tot += (nw == n) ? w[q] : 1.0;
+  b[0] = 0;
+  for (int q = 1; q <= n; ++q) {
+    acc += (nw == n) ? w[q - 1] : 1.0;
+    int64_t c = tot > 0 ? (int64_t)(nch * (acc / tot) + 0.5) : nch * q / n;
+    if (c < b[q - 1] / PART_ALIGN) c = b[q - 1] / PART_ALIGN;
+    b[q] = (c > nch ? nch : c) * PART_ALIGN;
+  }
+  b[n] = nch * PART_ALIGN;
+}
+}  // namespace
+
+void i2sdf_parts_fence(const i2sdf_plan* p, hipStream_t st) {
+  (void)hipEventRecord(p->part_ev[0], st);
+  for (int q = 0; q + 1 < p->parts; ++q) (void)hipStreamWaitEvent(p->part_st[q], p->part_ev[0], 0);
+}
+void i2sdf_parts_join_all(const i2sdf_plan* p, hipStream_t st) {
+  for (int q = 0; q + 1 < p->parts; ++q) {
+    if (!p->part_st[q] || !p->part_ev[q + 1]) continue;
+    (void)hipEventRecord(p->part_ev[q + 1], p->part_st[q]);
+    (void)hipStreamWaitEvent(st, p->part_ev[q + 1], 0);
+  }
+}
+bool i2sdf_parts_begin(const i2sdf_plan* p, hipStream_t st, int64_t M, PartRun* pr) {
+  pr->n = 1; pr->st[0] = st; pr->lo[0] = 0; pr->hi[0] = M; pr->own = false;
+  if (!i2sdf_parts_on(p) || M <= 0) return false;
+  const bool chain = p->chain_active != 0;
+  const int64_t Mref = chain ? (p->chain_M > M ? p->chain_M : M) : M;
+  if ((Mref + PART_ALIGN - 1) / PART_ALIGN < p->parts) return false;        // fewer chunks than ranges: one launch
+  if (!parts_resources(p)) return false;
+  int64_t b[I2SDF_MAX_PARTS + 1];
+  part_bounds(Mref, p->parts, b);
+  pr->n = p->parts;
+  for (int q = 0; q < pr->n; ++q) {
+    pr->st[q] = q == 0 ? st : p->part_st[q - 1];
+    pr->lo[q] = b[q] < M ? b[q] : M;
+    pr->hi[q] = b[q + 1] < M ? b[q + 1] : M;
+  }
+  if (!chain) { i2sdf_parts_fence(p, st); pr->own = true; }
+  return true;
+}
+void i2sdf_parts_end(const i2sdf_plan* p, hipStream_t st, PartRun* pr) {
+  if (pr->own) i2sdf_parts_join_all(p, st);
+  pr->own = false;
+}
+
+extern "C" int i2sdf_chain_begin(const i2sdf_plan* p, int64_t M, void* stream) {
+  if (!p || M < 0) return I2SDF_EINVAL;
+  if (!i2sdf_parts_on(p) || M == 0) return I2SDF_OK;
+  if (p->chain_active) return I2SDF_EINVAL;                  // chains do not nest
+  if (!parts_resources(p)) return i2sdf_hip_check(hipErrorOutOfMemory, "chain_begin: streams / events");
+  i2sdf_parts_fence(p, (hipStream_t)stream);
+  p->chain_active = 1;
+  p->chain_M = M;
+  return i2sdf_hip_check(hipGetLastError(), "chain_begin");
+}
+extern "C" int i2sdf_chain_fence(const i2sdf_plan* p, void* stream) {
+  if (!p) return I2SDF_EINVAL;
+  if (!p->chain_active) return I2SDF_OK;
+  i2sdf_parts_fence(p, (hipStream_t)stream);
+  return i2sdf_hip_check(hipGetLastError(), "chain_fence");
+}
+extern "C" int i2sdf_chain_end(const i2sdf_plan* p, void* stream) {
+  if (!p) return I2SDF_EINVAL;
+  if (!p->chain_active) return I2SDF_OK;
+  i2sdf_parts_join_all(p, (hipStream_t)stream);
+  p->chain_active = 0;
+  p->chain_M = 0;
+  return i2sdf_hip_check(hipGetLastError(), "chain_end");
+}
+
 extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t value) {
   if (!p) return I2SDF_EINVAL;
+  if (option == I2SDF_OPT_PARTS) {
+    if (value < 0 || value > I2SDF_MAX_PARTS || p->chain_active) return I2SDF_EINVAL;
+    p->parts = value >= 2 ? value : 0;
+    return I2SDF_OK;
+  }
   if (option == I2SDF_OPT_SDF_FWD_BF16X3) {
     if (value && p->sdf.fwd3_chunks == 0) return I2SDF_EINVAL;      // no bf16x3 stream for this shape
     p->sdf_fwd_bf16x3 = value ? 1 : 0;

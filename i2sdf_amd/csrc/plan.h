@@ -79,7 +79,36 @@ struct i2sdf_plan {
   // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
   mutable hipStream_t side = nullptr;
   mutable hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // I2SDF_OPT_PARTS (see PartRun below): number of point ranges the per-point entry points are cut into (0 / 1 = off)
+  int32_t parts = 0;
+  mutable hipStream_t part_st[I2SDF_MAX_PARTS - 1] = {nullptr, nullptr, nullptr};
+  mutable hipEvent_t part_ev[I2SDF_MAX_PARTS] = {nullptr, nullptr, nullptr, nullptr};   // [0] fork event, [q] join event of part q
+  mutable int32_t chain_active = 0;          // between i2sdf_chain_begin and i2sdf_chain_end
+  mutable int64_t chain_M = 0;               // the point count the active chain's ranges were cut from
 };
+
+// ---- point ranges ("parts") ---------------------------------------------------------------------------------------
+// A launch over M points of 128-point workgroups on 256 CUs runs ceil(M/128/256) rounds, the last one partly empty, and the
+// next kernel of the chain (forward -> d sdf/dx -> radiance -> ... ) cannot start before it has drained.  With I2SDF_OPT_PARTS
+// = n the point batch is cut into n ranges at multiples of the weight-gradient chunk (1024 points); range q runs its whole
+// chain of kernels on its own stream (range 0 on the caller's, the others on streams owned by the plan), so the ranges drift
+// apart and the partly empty last round of one kernel is filled by workgroups of another range's next kernel.  No split-K tail
+// workgroups in this mode: every point goes through the bf16x3 kernels, every saved tensor is blocked throughout.
+//   parts_begin : fills `pr` with the ranges of a batch of M points and the stream of each.  Outside a chain it forks the side
+//                 streams from `st` (they see everything enqueued on `st` so far); inside a chain (i2sdf_chain_begin) the streams
+//                 are already forked and stay un-joined between entry points.
+//   parts_end   : outside a chain joins the side streams back into `st` (the entry point returns stream-ordered on `st`).
+struct PartRun {
+  int n = 1;
+  hipStream_t st[I2SDF_MAX_PARTS];
+  int64_t lo[I2SDF_MAX_PARTS], hi[I2SDF_MAX_PARTS];     // point range of part q (lo a multiple of 1024; hi capped by M)
+  bool own = false;                                      // this call forked, this call joins
+};
+bool i2sdf_parts_begin(const i2sdf_plan* p, hipStream_t st, int64_t M, PartRun* pr);
+void i2sdf_parts_end(const i2sdf_plan* p, hipStream_t st, PartRun* pr);
+void i2sdf_parts_join_all(const i2sdf_plan* p, hipStream_t st);        // `st` waits for every side stream (also inside a chain)
+void i2sdf_parts_fence(const i2sdf_plan* p, hipStream_t st);           // every side stream waits for what is enqueued on `st`
+inline bool i2sdf_parts_on(const i2sdf_plan* p) { return p->parts >= 2; }
 
 // Fork: returns the stream the split-K tail of an entry point should be launched on -- the plan's side stream, ordered after
 // everything already enqueued on `st`, or `st` itself when the overlap is off.  Join: `st` waits for the side stream.

@@ -520,7 +520,9 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
   int* state = (int*)w;
   const float near = sc->near, far = 2.0f * p->desc.scene_bounding_sphere;
   const unsigned grid = (unsigned)((B + 3) / 4);
-  const i2sdf_exchange* gcomm = (p->exchange.allreduce && (p->dp_flags & I2SDF_DP_GLOBAL_SAMPLER) && force_iters <= 0) ? &p->exchange : nullptr;
+  // the batch-global OR over ranks exists for TRAINING batches only: eval calls (validation on one rank, render_image chunks dealt
+  // unevenly to the ranks, bubble sweeps) are rank-local and must not enter a collective that the other ranks never issue
+  const i2sdf_exchange* gcomm = (training && p->exchange.allreduce && (p->dp_flags & I2SDF_DP_GLOBAL_SAMPLER) && force_iters <= 0) ? &p->exchange : nullptr;
   sampler_init_kernel<<<grid, 256, 0, st>>>(B, sc->N_samples_eval, t_lin, training ? strat_u : nullptr, near, far, sc->eps, zA, samples, beta, state);
   // With a fixed iteration count the host knows where the loop ends; otherwise every iteration is enqueued and the ones after
   // convergence return immediately (device flag, no host synchronisation).

@@ -12,7 +12,7 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 
 namespace {
 
-constexpr int WG_CH = 1024;          // points per split-M chunk
+constexpr int WG_CH = 1024;          // points per split-M chunk (plan.cpp: PART_ALIGN -- point ranges are cut at chunk boundaries)
 constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
 
@@ -25,7 +25,7 @@ struct WgTask {
   int32_t variant, pad;
   int64_t out_off, bias_off;
 };
-struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t pad; int64_t chunk_stride; float* partials; };
+struct WgLaunch { WgTask t[MAX_TASKS]; int32_t n; int32_t chunk0; int64_t chunk_stride; float* partials; };     // chunk0: first chunk of this launch (point ranges)
 
 // AM = 0: A tile 128 wide (16 B per lane, rows 4i+ta)      AM = 1: A narrower than 32 columns (4 B per lane, row i)
 // BM = 0: B tile 128 wide (16 B per lane, cols 4j+tb)      BM = 1 / 2: B at most 32 / 64 columns wide (4 B per lane, col j + 32 tb)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
   const int lane = threadIdx.x & 63;
   const WgTask& t = L.t[blockIdx.y];
-  const int64_t chunk = blockIdx.x;
+  const int64_t chunk = blockIdx.x + L.chunk0;
   f32x16 acc[TA][TB];
   float bsum[TA];
   wgrad_accumulate<AM, BM, PFW>(t, chunk * WG_CH, chunk * WG_CH + WG_CH, lane, acc, bsum);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
   // wave index as a scalar: the buffer descriptors built from it must be wave-uniform (else every load becomes a waterfall loop)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const WgTask& t = L.t[blockIdx.y];
-  const int64_t chunk = blockIdx.x;
+  const int64_t chunk = blockIdx.x + L.chunk0;
   if (t.variant == 1) wgrad_narrow_body<1, 0>(L, t, chunk, wave, lane, wgn_lds);
   else if (t.variant == 2) wgrad_narrow_body<0, 1>(L, t, chunk, wave, lane, wgn_lds);
   else wgrad_narrow_body<0, 2>(L, t, chunk, wave, lane, wgn_lds);
@@ -280,7 +280,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
   const WgTask& t = L.t[blockIdx.y];
-  const int64_t chunk = blockIdx.x;
+  const int64_t chunk = blockIdx.x + L.chunk0;
   f32x16 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -438,7 +438,7 @@ template <int NPL>
 __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WgTask& t = L.t[blockIdx.y];
-  const int64_t m_lo = (int64_t)blockIdx.x * WG_CH;
+  const int64_t m_lo = (int64_t)(blockIdx.x + L.chunk0) * WG_CH;
   const bool ba = m_lo < t.j[0].a_blk, bb = m_lo < t.j[0].b_blk;       // workgroup-uniform
   bool plain = t.relu_b == 0;
   for (int jb = 0; jb < t.njobs; ++jb) {
@@ -690,13 +690,15 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   };
   for (WgTask& x : tl.tasks) x.variant = variant(x);
   hipStream_t st_main = st;
+  int c_lo = 0, c_hi = n_chunks;             // chunk range of the launches below (point ranges: one range at a time)
   auto launch = [&](const std::vector<WgTask>& sel, int var) {
     for (size_t off = 0; off < sel.size(); off += MAX_TASKS) {
       WgLaunch L{};
       L.n = (int32_t)std::min<size_t>(MAX_TASKS, sel.size() - off);
       for (int i = 0; i < L.n; ++i) L.t[i] = sel[off + i];
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
-      dim3 grid((unsigned)n_chunks, (unsigned)L.n);
+      L.chunk0 = c_lo;
+      dim3 grid((unsigned)(c_hi - c_lo), (unsigned)L.n);
       if (var == 4) {
         if (p->wgrad_bf16x2) {
           (void)hipFuncSetAttribute((const void*)wgrad3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
@@ -713,24 +715,36 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       }
     }
   };
-  hipStream_t side = st;
-  {  // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
-    std::vector<WgTask> sel;
-    for (int var : {3, 1, 2})
-      for (int nj = 2; nj >= 1; --nj)
-        for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel.push_back(x);
-    side = i2sdf_tail_fork(p, st_main);
+  std::vector<WgTask> sel_narrow, sel_blocks[2];
+  for (int var : {3, 1, 2})      // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
+    for (int nj = 2; nj >= 1; --nj)
+      for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel_narrow.push_back(x);
+  for (int v = 0; v < 2; ++v) {
+    for (const WgTask& x : tl.tasks) if (x.variant == (v == 0 ? 4 : 0)) sel_blocks[v].push_back(x);
+    std::stable_sort(sel_blocks[v].begin(), sel_blocks[v].end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
+  }
+  PartRun pr;
+  if (i2sdf_parts_on(p) && i2sdf_parts_begin(p, st_main, Ms, &pr)) {
+    // point ranges (plan.h: PartRun): the GEMMs of a range's chunks on the range's stream, behind that range's backward sweeps
+    for (int q = 0; q < pr.n; ++q) {
+      if (pr.hi[q] <= pr.lo[q]) continue;
+      c_lo = (int)(pr.lo[q] / WG_CH); c_hi = (int)((pr.hi[q] + WG_CH - 1) / WG_CH);
+      st = pr.st[q];
+      launch(sel_narrow, 1);
+      launch(sel_blocks[0], 4);
+      launch(sel_blocks[1], 0);
+    }
+    st = st_main; c_lo = 0; c_hi = n_chunks;
+    i2sdf_parts_join_all(p, st_main);                   // the reduction below reads every chunk's partials (also ends a chain's ranges)
+  } else {
+    hipStream_t side = i2sdf_tail_fork(p, st_main);
     st = side;
-    launch(sel, 1);
+    launch(sel_narrow, 1);
     st = st_main;
+    launch(sel_blocks[0], 4);
+    launch(sel_blocks[1], 0);
+    i2sdf_tail_join(p, st_main, side);
   }
-  for (int var : {4, 0}) {
-    std::vector<WgTask> sel;
-    for (const WgTask& x : tl.tasks) if (x.variant == var) sel.push_back(x);
-    std::stable_sort(sel.begin(), sel.end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
-    launch(sel, var);
-  }
-  i2sdf_tail_join(p, st_main, side);
   WnTab tab{};
   int row0 = 0;
   fill_wn(tab, p->sdf, 0, row0);

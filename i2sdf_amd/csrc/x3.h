@@ -336,7 +336,7 @@ struct X3ReluSrc {
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; float* rrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
-  __device__ __forceinline__ float value(int kc, int u, float&) { return fmaxf(accP[kc >> 1][8 * (kc & 1) + u], 0.f); }
+  __device__ __forceinline__ float value(int kc, int u, float&) { return relu0(accP[kc >> 1][8 * (kc & 1) + u]); }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (rrow != nullptr && valid) x3_store8(rrow, kc, hi, v, kcs);
   }

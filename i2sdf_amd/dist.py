@@ -30,9 +30,14 @@ class RcclComm:
     """`i2sdf_comm` of the C ABI: created collectively by all ranks of `group`; the 128-byte unique id travels through the
     torch.distributed group (any backend).  The calling thread's current device must be this rank's GPU."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, device=None):
         self._lib = L.load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        # i2sdf_comm_init_rank binds the communicator to the calling thread's CURRENT device: pin it to the module's device, so a
+        # caller that passes 'cuda:N' everywhere without torch.cuda.set_device does not put every rank's communicator on GPU 0
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         box = [None]
         if self.rank == 0:
             buf = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES)()
@@ -42,13 +47,15 @@ class RcclComm:
         dist.broadcast_object_list(box, src=src, group=group)
         uid = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES).from_buffer_copy(box[0])
         h = C.c_void_p()
-        L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
+        with torch.cuda.device(self.device):
+            L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
         self._h = h
         self._ex = L.Exchange()
         L.check(self._lib.i2sdf_comm_as_exchange(self._h, C.byref(self._ex)), "i2sdf_comm_as_exchange")
 
     def allreduce_mean(self, flat: torch.Tensor):
         assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        assert flat.device == self.device, f"communicator lives on {self.device}, gradient buffer on {flat.device}"
         with torch.cuda.device(flat.device):
             L.check(self._lib.i2sdf_allreduce_grads(L.ptr(flat), flat.numel(), self._h, L.stream_ptr()), "i2sdf_allreduce_grads")
 
@@ -133,9 +140,11 @@ def attach_data_parallel(net, group=None, equivalent: bool = False, native=None)
         # all ranks must end up on the same transport: create the communicator, then agree on the outcome through the group
         err = None
         try:
-            comm = RcclComm(group)
+            dev = next((p.device for p in net.parameters() if p.is_cuda), None)
+            comm = RcclComm(group, device=dev)
         except Exception as e:       # RCCL not loadable / init failed on this rank
             err = e
+            print(f"[i2sdf_amd.dist] rank {dist.get_rank(group)}: library RCCL communicator failed: {e}", flush=True)
         ok = torch.tensor([0.0 if comm is None else 1.0], device="cuda" if dist.get_backend(group) == "nccl" else "cpu")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if float(ok.item()) < 1.0:
@@ -187,6 +196,7 @@ def attach_loss(loss_fn, net):
     st = getattr(net, "dp_state", None)
     loss_fn.exchange = st.xchg.exchange() if (st is not None and st.equivalent) else None
     loss_fn._exchange_owner = st.xchg if st is not None else None
+    loss_fn._dp_state = st        # the loss exchanges only in training mode and while st.enabled (not under no_sync())
     return loss_fn
 
 

@@ -54,6 +54,11 @@ class RenderEngine:
         self.tail_overlap = False
         if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
             self.set_tail_overlap(True)
+        # point ranges on their own streams instead of split-K tail workgroups (include/i2sdf.h: I2SDF_OPT_PARTS); I2SDF_PARTS=0 for A/B runs
+        self.parts = 0
+        n_parts = int(os.environ.get("I2SDF_PARTS", "4"))
+        if cfg.bf16x3 and n_parts >= 2 and self.train_forward_bf16x3 and self.sdf_backward_bf16x3:
+            self.set_parts(n_parts)
         sc = cfg.sampler
         self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
                                   N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
@@ -177,6 +182,35 @@ class RenderEngine:
         """Split-K tail workgroups on the plan's side stream, concurrent with the full workgroups (I2SDF_OPT_TAIL_OVERLAP)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TAIL_OVERLAP, int(bool(on))), "i2sdf_plan_set_option")
         self.tail_overlap = bool(on)
+
+    def set_parts(self, n: int):
+        """Cut the per-point entry points into n point ranges, each on its own stream (I2SDF_OPT_PARTS; 0 / 1 = off).  Change it only
+        between training steps (the layout of the saved tensors depends on it)."""
+        n = int(n) if int(n) >= 2 else 0
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_PARTS, n), "i2sdf_plan_set_option")
+        self.parts = n
+
+    def chain(self, M: int):
+        """Context manager: the per-point entry points called inside leave their point ranges un-joined (i2sdf_chain_begin / _end);
+        a no-op without I2SDF_OPT_PARTS.  M = the largest point batch of the chain."""
+        eng = self
+        if not getattr(self, "use_chain", True) or not self.parts:
+            import contextlib
+            return contextlib.nullcontext()
+
+        class _Chain:
+            def __enter__(self_):
+                L.check(eng._lib.i2sdf_chain_begin(eng._plan, int(M), L.stream_ptr()), "i2sdf_chain_begin")
+                return self_
+
+            def __exit__(self_, *exc):
+                L.check(eng._lib.i2sdf_chain_end(eng._plan, L.stream_ptr()), "i2sdf_chain_end")
+                return False
+
+            def fence(self_):
+                L.check(eng._lib.i2sdf_chain_fence(eng._plan, L.stream_ptr()), "i2sdf_chain_fence")
+
+        return _Chain()
 
     def set_exchange(self, ex, flags: int = 0):
         """Install (or with ex=None remove) the data-parallel exchange hook of the plan (include/i2sdf.h: i2sdf_plan_set_exchange);

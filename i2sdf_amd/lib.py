@@ -72,6 +72,8 @@ OPT_TAIL_OVERLAP = 32
 OPT_SRC_RING = 64
 OPT_BLOCKED_SAVES = 128
 OPT_WGRAD_BF16X2 = 256
+OPT_PARTS = 512
+MAX_PARTS = 4
 GRID_ORDER_MESHGRID, GRID_ORDER_VOLUME = 0, 1
 
 
@@ -90,6 +92,9 @@ SIGNATURES = {
     "i2sdf_plan_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(_P)]),
     "i2sdf_plan_destroy": (None, [_P]),
     "i2sdf_plan_set_option": (C.c_int, [_P, _I32, _I32]),
+    "i2sdf_chain_begin": (C.c_int, [_P, _I64, _P]),
+    "i2sdf_chain_fence": (C.c_int, [_P, _P]),
+    "i2sdf_chain_end": (C.c_int, [_P, _P]),
     "i2sdf_blocked_points": (_I64, [_P, _I32, _I64, _I64, _I32]),
     "i2sdf_plan_pack_floats": (_I64, [_P]),
     "i2sdf_plan_wgrad_floats": (_I64, [_P]),

@@ -65,6 +65,7 @@ class I2SDFLoss(nn.Module):
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
         self.exchange = None       # i2sdf_amd.dist.attach_loss: lib.Exchange hook -> global denominators (1-GPU-equivalent data parallelism)
+        self._dp_state = None      # the attached module's DataParallelState (its `enabled` flag: no_sync())
 
     def _forward_fused(self, out, gt, current_step):
         from . import lib as L
@@ -73,7 +74,10 @@ class I2SDFLoss(nn.Module):
                         normal_w=self.normal_weight, angular_w=self.angular_weight, bubble_w=self.bubble_weight,
                         light_w=self.light_mask_weight, smooth_on=1 if smooth_on else 0)
         import ctypes as C_
-        if self.exchange is not None:
+        # global denominators only for a training-mode loss of an attached, syncing module: a validation loss on some ranks, or a
+        # micro-batch under no_sync(), must not enter a collective the other ranks do not issue (i2sdf_amd.dist.attach_loss)
+        st = getattr(self, "_dp_state", None)
+        if self.exchange is not None and self.training and (st is None or st.enabled):
             cfg.exchange = C_.pointer(self.exchange)
         surf = out.get("surface_sdf")
         gtc = dict(gt)

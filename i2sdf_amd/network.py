@@ -102,8 +102,11 @@ class _RenderFn(torch.autograd.Function):
         flat = net._flat
         B, n = st["z_all"].shape[0], st["z_all"].shape[1] - 1
         M_main = B * n
-        fw = eng.sdf_forward_grad(points=st["extra_pts"], rays=(st["cam"], st["dirs"], st["z_all"], n), want_grad=True, save=True)
-        rgb, rs, pev = eng.rgb_forward(st["dirs"], n, fw["feat"], M_main, save=True)
+        n_extra = 0 if st["extra_pts"] is None else st["extra_pts"].shape[0]
+        # one chain: with point ranges on (engine.parts) every range runs SDF forward -> d sdf/dx -> radiance net on its own stream
+        with eng.chain(M_main + n_extra):
+            fw = eng.sdf_forward_grad(points=st["extra_pts"], rays=(st["cam"], st["dirs"], st["z_all"], n), want_grad=True, save=True)
+            rgb, rs, pev = eng.rgb_forward(st["dirs"], n, fw["feat"], M_main, save=True)
         lm = hl = None
         if net.use_light:
             lm, hl = eng.light_forward(fw["feat"], M_main, save=True)
@@ -130,25 +133,27 @@ class _RenderFn(torch.autograd.Function):
         M_sdf = fw["M"]
         sbar = torch.zeros(M_sdf, device=dev)
         nbar = torch.zeros(M_sdf, 3, device=dev)
+        n_eik, n_pc = st["n_eik"], st["n_pc"]
+        if n_eik:                              # rows of the extra points (the compositing backward below fills the rays' rows)
+            nbar[M_main:M_main + n_eik] = g_eik
+        if n_pc:
+            sbar[M_main + n_eik:M_main + n_eik + n_pc] = g_surf.reshape(-1)
         off_beta = eng.layout.offset("density.beta")
         want_normal = st["want_normal"]
         cb = eng.composite_backward(flat[off_beta:], st["z_all"], fw["sdf"], ctx.rgb, fw["grad"], st["dnorm"], comp["nsum"],
                                     g_rgb, g_depth, g_wsum.reshape(-1), g_normal if want_normal else None,
                                     g_lmask.reshape(-1) if net.use_light else None, beta_grad_accum=gflat[off_beta:],
                                     sdf_bar_out=sbar, grad_bar_out=nbar if want_normal else None)
-        gar, ga_last, fbar = eng.rgb_backward(ctx.rgb, cb["rgb_bar"], ctx.rs, M_main)
         light = None
-        if net.use_light:
+        if net.use_light:                      # (before the chain: the head's kernels run on the caller's stream only)
             gal0, gal_last = eng.light_backward(ctx.lm, cb["lmask_bar"], ctx.hl, M_main)
             light = {"hl": ctx.hl, "gal0": gal0, "gal_last": gal_last}
-        n_eik, n_pc = st["n_eik"], st["n_pc"]
-        if n_eik:
-            nbar[M_main:M_main + n_eik] = g_eik
-        if n_pc:
-            sbar[M_main + n_eik:M_main + n_eik + n_pc] = g_surf.reshape(-1)
-        bw = eng.sdf_backward(fw, sbar=sbar, fbar=fbar, m_fbar=M_main, nbar=nbar)
-        eng.weight_grads(flat, gflat, fw, bw, M_main=M_main, fbar=fbar, rgb_fw={"pev": ctx.pev, "rs": ctx.rs},
-                         rgb_bw={"gar": gar, "ga_last": ga_last}, light=light)
+        # one chain: radiance backward -> SDF sweeps -> weight-gradient GEMMs per point range (i2sdf_weight_grads joins the ranges)
+        with eng.chain(M_sdf):
+            gar, ga_last, fbar = eng.rgb_backward(ctx.rgb, cb["rgb_bar"], ctx.rs, M_main)
+            bw = eng.sdf_backward(fw, sbar=sbar, fbar=fbar, m_fbar=M_main, nbar=nbar)
+            eng.weight_grads(flat, gflat, fw, bw, M_main=M_main, fbar=fbar, rgb_fw={"pev": ctx.pev, "rs": ctx.rs},
+                             rgb_bw={"gar": gar, "ga_last": ga_last}, light=light)
         if net.grad_sync is not None:
             net.grad_sync(gflat)
         grads = []

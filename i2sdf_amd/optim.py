@@ -44,8 +44,11 @@ class FusedAdam(torch.optim.Optimizer):
             self._flat_state[gi] = fs
         off = 0
         for p in params:
-            st = self.state[p]
             k = p.numel()
+            if p.grad is None and p not in self.state:      # torch.optim.Adam creates state lazily, for parameters that have a gradient
+                off += k
+                continue
+            st = self.state[p]
             for name, flat in (("exp_avg", fs[0]), ("exp_avg_sq", fs[1])):
                 view = flat[off:off + k].view(p.shape)
                 cur = st.get(name)
@@ -68,6 +71,8 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = L.load()
         for gi, group in enumerate(self.param_groups):
+            if group.get("amsgrad") or group.get("maximize"):      # e.g. a torch.optim.Adam checkpoint's param_groups
+                raise RuntimeError("FusedAdam implements plain Adam: amsgrad / maximize are not supported")
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
@@ -98,6 +103,8 @@ class FusedAdam(torch.optim.Optimizer):
                 else:
                     for p, s in zip(params, steps):
                         st = self.state[p]
+                        if not p.is_contiguous():
+                            raise RuntimeError("FusedAdam needs contiguous parameters (the kernel updates them in place through a raw pointer)")
                         g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                         L.check(lib.i2sdf_adam_step(L.ptr(p.data), L.ptr(g), L.ptr(st["exp_avg"]), L.ptr(st["exp_avg_sq"]), p.numel(), group["lr"],
                                                     beta1, beta2, group["eps"], group["weight_decay"], s, self.grad_scale, stream),

@@ -27,6 +27,7 @@ extern "C" {
 
 #define I2SDF_VERSION 100          /* major*10000 + minor*100 + patch */
 #define I2SDF_MAX_LAYERS 12
+#define I2SDF_MAX_PARTS 4           /* I2SDF_OPT_PARTS: point ranges per batch (one HIP stream each) */
 
 #define I2SDF_OK 0
 #define I2SDF_EINVAL (-1)          /* bad argument / unsupported shape */
@@ -115,12 +116,32 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   max-norm error of every parameter gradient against fp64 (parity bar 1e-4).  Half the MFMAs and 2/3 of the split work of the
  *   bf16x3 form.  Default 0; every other kernel keeps the fp32-equivalent bf16x3 / fp32 arithmetic. */
 #define I2SDF_OPT_WGRAD_BF16X2 256
+/*   I2SDF_OPT_PARTS (value n = 2..I2SDF_MAX_PARTS, 0 / 1 = off; 256-wide nets with the bf16x3 options on): the per-point entry points
+ *   (i2sdf_sdf_forward_grad, i2sdf_rgb_forward, i2sdf_rgb_backward, i2sdf_sdf_backward, the GEMMs of i2sdf_weight_grads) cut their
+ *   point batch into n ranges at multiples of i2sdf_wgrad_chunk_points(); range 0 runs on the caller's stream, the others on streams
+ *   owned by the plan.  On its own an entry point forks and joins (it returns stream-ordered on the caller's stream, as without the
+ *   option).  Between i2sdf_chain_begin and i2sdf_chain_end the ranges stay un-joined ACROSS entry points: every range runs its own
+ *   chain of kernels, the ranges drift apart, and the partly empty last round of one kernel (M/128 workgroups on 256 CUs) is filled
+ *   by another range's next kernel instead of idling -- which replaces the split-K tail workgroups (none in this mode: every point
+ *   goes through the full-workgroup kernels and every saved tensor is blocked throughout).  Results do not depend on n.  Default 0. */
+#define I2SDF_OPT_PARTS 512
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset
  * (m/32)*8192 + (c/16)*512 + (m%32)*16 + c%16; points behind the count are ordinary rows m*256 + c. */
 int64_t i2sdf_blocked_points(const i2sdf_plan* plan, int32_t which, int64_t M, int64_t Mp, int32_t has_feat);
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
+/* A chain (I2SDF_OPT_PARTS): the per-point entry points called between begin and end leave their point ranges un-joined.
+ *   i2sdf_chain_begin(plan, M, stream): the ranges are cut from a batch of M points (the LARGEST batch of the chain: entry points
+ *     with fewer points clip them); the side streams wait for everything enqueued on `stream` so far.
+ *   i2sdf_chain_fence(plan, stream): the side streams additionally wait for what was enqueued on `stream` since (call it after
+ *     enqueueing, on `stream`, an input that a later entry point of the chain reads).
+ *   i2sdf_chain_end(plan, stream): `stream` waits for every range; afterwards everything the chain wrote is visible on `stream`.
+ * Inside a chain only the entry points named at I2SDF_OPT_PARTS may be called, with the same `stream`; i2sdf_weight_grads joins the
+ * ranges itself before its final reduction.  Without I2SDF_OPT_PARTS all three calls do nothing. */
+int i2sdf_chain_begin(const i2sdf_plan* plan, int64_t M, void* stream);
+int i2sdf_chain_fence(const i2sdf_plan* plan, void* stream);
+int i2sdf_chain_end(const i2sdf_plan* plan, void* stream);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
 /* floats of the effective-weight gradient buffer i2sdf_weightnorm_backward consumes */

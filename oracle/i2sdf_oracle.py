@@ -595,6 +595,8 @@ def sample_z_vals(sd, cfg: NetCfg, dirs: Tensor, cam_loc: Tensor, training: bool
         if sc.N_samples_extra > 0:
             if training:
                 idx = draws.extra_idx.long()
+                if idx.dim() == 2:      # one randperm row per possible loop length (what a caller that cannot know the iteration count
+                    idx = idx[total_iters - 1]      # in advance draws): row it-1 indexes the N_eval*it depths of a loop that ran `it` times
             else:
                 idx = torch.linspace(0, z_vals.shape[1] - 1, sc.N_samples_extra).long().to(dev)   # ray_sampler.py:225
             extra = torch.cat([near, far, z_vals[:, idx]], -1)

@@ -103,11 +103,29 @@ def worker(rank, world, port, Bh, result_path):
     ys, xs = torch.meshgrid(torch.arange(Hi), torch.arange(Wi), indexing="ij")
     img = {"uv": torch.stack([xs, ys], -1).float().reshape(1, -1, 2).cuda(), "intrinsics": K.unsqueeze(0).cuda(), "pose": pose.unsqueeze(0).cuda()}
     merged = i2dist.render_image(ev, img, chunk)
+    # the ATTACHED net after its equivalent=True step (the exchange hook is installed on its plan): eval renders must stay rank-local.
+    # 7 chunks over 2 ranks = 4 + 3 chunks: a per-iteration collective inside the eval sampler would hang here (or OR the flags of
+    # unrelated chunks); same weights as `ev` (no optimizer step was taken), so the image must be the single-process image bit for bit
+    calls0 = net.dp_state.xchg.calls
+    net.eval()
+    merged_att = i2dist.render_image(net, img, 110)
+    if rank == 0:                                 # rank-0-only validation: forward + loss in eval mode, no collective may be entered
+        loss_fn.eval()
+        with torch.no_grad():
+            vo = net({k: v.cuda() for k, v in cut(inp).items()})
+        v_loss = float(loss_fn(vo, {k: v.cuda() for k, v in cut(gt).items() if k in ("rgb", "depth", "depth_mask")}, 10)["loss"])
+        loss_fn.train()
+    eval_calls = net.dp_state.xchg.calls - calls0
+    net.train()
     if rank == 0:
         single = ev.render_image(img, chunk)
+        single110 = ev.render_image(img, 110)
         res = torch.load(result_path)
         res["image_equal"] = all(bool(torch.equal(merged[k], single[k])) for k in single)
         res["image_rows"] = int(merged["rgb_values"].shape[0])
+        res["attached_image_equal"] = all(bool(torch.equal(merged_att[k], single110[k])) for k in single110)
+        res["eval_exchange_calls"] = int(eval_calls)
+        res["rank0_validation_loss"] = v_loss
         torch.save(res, result_path)
     # ---- multi-GPU SDF volume (N4): contiguous slabs of the flat output, all-gathered
     from i2sdf_amd.grid import aligned_axes

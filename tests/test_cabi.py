@@ -162,6 +162,17 @@ def test_new_plan_options_and_blocked_prefix(lib):
     Mp3 = (M3 + 127) // 128 * 128
     assert h.i2sdf_blocked_points(plan, 0, M3, Mp3, 1) == Mp3
     assert h.i2sdf_blocked_points(None, 0, M, Mp, 1) == 0
+    # round 3, I2SDF_OPT_PARTS: point ranges instead of a split-K tail -> every saved row is blocked; chains are no-ops while it is off
+    assert h.i2sdf_chain_begin(plan, M, None) == 0 and h.i2sdf_chain_fence(plan, None) == 0 and h.i2sdf_chain_end(plan, None) == 0
+    assert h.i2sdf_chain_begin(None, M, None) == -1 and h.i2sdf_chain_begin(plan, -1, None) == -1
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, lib.MAX_PARTS + 1) == -1 and h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, -1) == -1
+    for n in (2, 3, lib.MAX_PARTS):
+        assert h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, n) == 0
+        assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == Mp and h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == Mp
+        assert h.i2sdf_blocked_points(plan, 0, M2, Mp2, 1) == Mp2
+    for n in (0, 1):                                            # 0 / 1 = off: back to full rounds + split-K tail
+        assert h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, n) == 0
+        assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == bulk
     h.i2sdf_plan_destroy(plan)
     rc, plan, _, _ = _plan(lib, plumbing_conf())                # 64-wide nets have no bf16x3 train path: nothing is blocked
     assert rc == 0

@@ -115,13 +115,14 @@ def test_rgb_backward_param_and_feature_grads(which):
         assert_close(got[k], r, 1e-4, k)
 
 
-@pytest.mark.parametrize("which", ["synthetic", "light"])
-def test_backward_split_k_tail(which):
-    """256 full workgroups + a short tail: the tail of both backward kernels runs as split-K workgroups (ksplit.h).
+@pytest.mark.parametrize("which,parts", [("synthetic", 0), ("light", 0), ("synthetic", 4)])
+def test_backward_split_k_tail(which, parts):
+    """256 full workgroups + a short tail: the tail of both backward kernels runs as split-K workgroups (ksplit.h) with parts = 0, as
+    full workgroups of the last of four point ranges with parts = 4 (I2SDF_OPT_PARTS).
     The probe loss only weights the tail and a few bulk points, so the oracle differentiates just those."""
     ocfg, conf = _cfgs(which)
     sd = orc.perturb_params(orc.init_params(ocfg, seed=21), 0.05, seed=22)
-    eng = make_engine(conf, sd)
+    eng = make_engine(conf, sd, parts=parts)
     flat = eng.layout.flat_from_state_dict(sd).cuda()
     g = torch.Generator().manual_seed(23)
     n = 7

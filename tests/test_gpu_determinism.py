@@ -13,14 +13,16 @@ from test_gpu_train_forward import make_engine
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("bf16x3", [True, False])
-def test_kernels_are_bitwise_reproducible(bf16x3):
+@pytest.mark.parametrize("bf16x3,parts", [(True, 0), (True, 4), (False, 0)])
+def test_kernels_are_bitwise_reproducible(bf16x3, parts):
+    """parts = 0: full rounds + split-K tail workgroups (on a side stream); parts = 4: point ranges on four streams (I2SDF_OPT_PARTS)."""
     from i2sdf_amd.config import synthetic_conf
     ocfg = orc.synthetic_cfg(False)
     sd = orc.perturb_params(orc.init_params(ocfg, seed=13), 0.05, seed=14)
     conf = dict(synthetic_conf(False))
     conf["bf16x3"] = bf16x3
     eng = make_engine(conf, sd)
+    eng.set_parts(parts)
     flat = eng.layout.flat_from_state_dict(sd).cuda()
     g = torch.Generator().manual_seed(6)
     B, n = 360, 97                               # 36 000 points: 256 full workgroups + 101 split-K tail workgroups, 36 weight-gradient chunks
@@ -39,7 +41,10 @@ def test_kernels_are_bitwise_reproducible(bf16x3):
         eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
         # saved tensors in point-major form (the padding points of a blocked tile are never written: compare real points only)
         pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]
-        assert eng.blocked_points(0, M, fwd["Mp"]) in (0, 256 * 128), "the batch must exercise bulk + split-K tail"
+        if parts == 0:
+            assert eng.blocked_points(0, M, fwd["Mp"]) in (0, 256 * 128), "the batch must exercise bulk + split-K tail"
+        else:
+            assert eng.blocked_points(0, M, fwd["Mp"]) == fwd["Mp"], "point ranges: no tail, every saved row blocked"
         cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": pm(fwd["hs"], 0, M), "abars": pm(fwd["abars"], 0, M),
                "rgb": rgb_h, "rs": pm(rs, 1, B * n), "gar": pm(gar, 1, B * n), "fbar": fbar[:B * n], "gus": pm(bw["gus"], 0, M)[1:],
                "gas": pm(bw["gas"], 0, M), "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
@@ -61,6 +66,7 @@ def test_tail_overlap_changes_nothing(bf16x3):
     conf = dict(synthetic_conf(False))
     conf["bf16x3"] = bf16x3
     eng = make_engine(conf, sd)
+    eng.set_parts(0)                                 # the split-K tail only exists without point ranges
     g = torch.Generator().manual_seed(8)
     B, n = 360, 97
     M = B * n + 3 * B                              # 36 000 points: 256 full workgroups + a 3 232-point split-K tail (101 workgroups)
@@ -83,3 +89,47 @@ def test_tail_overlap_changes_nothing(bf16x3):
         cur = run()
         for k in cur:
             assert torch.equal(cur[k], ref[k]), f"{k}: overlap run {rep} differs from the single-stream run ({int((cur[k] != ref[k]).sum())} entries)"
+
+
+def test_point_ranges_change_nothing():
+    """I2SDF_OPT_PARTS: the per-point entry points cut into n point ranges, each on its own stream; inside a chain
+    (i2sdf_chain_begin / _end) the ranges stay un-joined across entry points.  The kernels and the points they own are the same
+    for every n >= 2, joined or not, so every output -- the parameter gradients included (fixed-order reduction of the per-chunk
+    partials) -- must be bitwise equal; a difference would mean a missing dependency between the streams."""
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=31), 0.05, seed=32)
+    eng = make_engine(dict(synthetic_conf(False)), sd)
+    flat = eng.layout.flat_from_state_dict(sd).cuda()
+    g = torch.Generator().manual_seed(9)
+    B, n = 300, 97                                   # 30 000 points = 29.3 chunks of 1024: ragged last chunk, ragged last workgroup
+    M = B * n + 3 * B
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.5).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).cuda()
+    cw = torch.randn(B * n, 3, generator=g).cuda()
+    nb, sb = torch.randn(M, 3, generator=g).cuda(), torch.randn(M, generator=g).cuda()
+
+    def run(chain):
+        import contextlib
+        with (eng.chain(M) if chain else contextlib.nullcontext()):
+            fwd = eng.sdf_forward_grad(points=x)
+            rgb_h, rs, pev = eng.rgb_forward(dirs, n, fwd["feat"], B * n)
+        # consumers on the caller's stream right behind the chain: they must see every range's results
+        out = {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "rgb": rgb_h.clone()}
+        gflat = torch.zeros_like(flat)
+        with (eng.chain(M) if chain else contextlib.nullcontext()):
+            gar, ga_last, fbar = eng.rgb_backward(rgb_h, cw, rs, B * n)
+            bw = eng.sdf_backward(fwd, sbar=sb, fbar=fbar, m_fbar=B * n, nbar=nb)
+            eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
+        pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]
+        out.update({"hs": pm(fwd["hs"], 0, M), "abars": pm(fwd["abars"], 0, M), "rs": pm(rs, 1, B * n), "gar": pm(gar, 1, B * n),
+                    "fbar": fbar[:B * n].clone(), "gus": pm(bw["gus"], 0, M)[1:], "gas": pm(bw["gas"], 0, M), "param_grads": gflat})
+        return out
+
+    eng.set_parts(2)
+    ref = run(False)
+    for parts, chain in ((2, True), (3, False), (3, True), (4, False), (4, True), (4, True)):
+        eng.set_parts(parts)
+        cur = run(chain)
+        for k in cur:
+            assert torch.equal(cur[k], ref[k]), f"{k}: parts={parts} chain={chain} differs from parts=2 ({int((cur[k] != ref[k]).sum())} entries)"

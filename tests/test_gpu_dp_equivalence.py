@@ -46,5 +46,9 @@ def test_two_rank_step_equals_one_rank_step_on_the_concatenated_batch(tmp_path):
     assert abs(res["loss_dp_mean"] - res["loss_ref"]) <= 1e-6 * abs(res["loss_ref"])
     assert res["image_equal"] and res["image_rows"] == 32 * 24, "2-rank sharded image render must equal the 1-rank image"
     assert res["volume_equal"], "2-rank sharded SDF volume must equal the 1-rank volume"
+    # eval on the ATTACHED net (hook installed by the training step): rank-local, no exchange, uneven chunk counts per rank
+    assert res["eval_exchange_calls"] == 0, "eval renders / a rank-0-only validation loss entered the data-parallel exchange"
+    assert res["attached_image_equal"], "render_image on the attached net (7 chunks over 2 ranks) must equal the 1-rank image"
+    assert res["rank0_validation_loss"] == res["rank0_validation_loss"]      # finite (not NaN)
     worst = max(res["grad_err"].items(), key=lambda kv: kv[1])
     assert worst[1] <= 1e-5, f"2-rank mean gradient vs 1-rank gradient on the concatenated batch: {worst}"

@@ -10,10 +10,13 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-def make_engine(conf, sd):
+def make_engine(conf, sd, parts=None):
+    """parts: None = the engine's default (point ranges on, I2SDF_OPT_PARTS); 0 = full rounds + split-K tail workgroups."""
     from i2sdf_amd.config import NetConfig
     from i2sdf_amd.engine import RenderEngine
     eng = RenderEngine(NetConfig.from_conf(conf))
+    if parts is not None:
+        eng.set_parts(parts)
     eng.pack(eng.layout.flat_from_state_dict(sd).cuda())
     return eng
 
@@ -106,12 +109,14 @@ def test_rgb_forward_golden(golden):
     assert_close(rgb.cpu(), z["rgb"], 2e-5, "RenderingNetwork.forward")
 
 
-def test_rgb_forward_split_k_tail():
-    """M = 256 full workgroups + a short tail: the tail runs through the split-K kernel (ksplit.h); both parts vs the oracle."""
+@pytest.mark.parametrize("parts", [0, 4])
+def test_rgb_forward_split_k_tail(parts):
+    """M = 256 full workgroups + a short tail.  parts = 0: the tail runs through the split-K kernel (ksplit.h); parts = 4: four point
+    ranges of full workgroups on their own streams (I2SDF_OPT_PARTS), ragged last workgroup.  Both against the oracle."""
     from i2sdf_amd.config import synthetic_conf
     ocfg = orc.synthetic_cfg(False)
     sd = orc.perturb_params(orc.init_params(ocfg, seed=7), 0.05, seed=8)
-    eng = make_engine(synthetic_conf(False), sd)
+    eng = make_engine(synthetic_conf(False), sd, parts=parts)
     g = torch.Generator().manual_seed(9)
     n = 7
     B = (256 * 128 + 777 + n - 1) // n
@@ -134,13 +139,14 @@ def test_rgb_forward_split_k_tail():
     assert_close(pev.cpu()[idx][:, :27], orc.positional_encode(dirs.double()[idx // n], 4), 1e-6, "PE(view)")
 
 
-@pytest.mark.parametrize("light", [False, True])
-def test_sdf_forward_grad_split_k_tail(light):
-    """256 full workgroups + a short tail (split-K workgroups): sdf, feature, d sdf/dx and every saved tensor of the tail."""
+@pytest.mark.parametrize("light,parts", [(False, 0), (True, 0), (False, 4)])
+def test_sdf_forward_grad_split_k_tail(light, parts):
+    """256 full workgroups + a short tail (parts = 0: split-K workgroups; parts = 4: point ranges of full workgroups): sdf, feature,
+    d sdf/dx and every saved tensor of the tail."""
     from i2sdf_amd.config import synthetic_conf
     ocfg = orc.synthetic_cfg(light)
     sd = orc.perturb_params(orc.init_params(ocfg, seed=5), 0.05, seed=6)
-    eng = make_engine(synthetic_conf(light), sd)
+    eng = make_engine(synthetic_conf(light), sd, parts=parts)
     g = torch.Generator().manual_seed(11)
     M = 256 * 128 + 601
     x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.0
@@ -153,7 +159,7 @@ def test_sdf_forward_grad_split_k_tail(light):
     assert_close(out["grad"].cpu()[idx], fw["n"], TOL, "d sdf/dx")
     assert_close(out["pe"].cpu()[idx][:, :39], fw["p"], 1e-6, "PE")
     hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_to_point_major(out["abars"], out["blk"])
-    assert out["blk"] in (0, 256 * 128), "blocked prefix = the points of the full workgroups"
+    assert out["blk"] in ((0, 256 * 128) if parts == 0 else (out["Mp"],)), "blocked prefix = the points of the full workgroups"
     for l in range(L - 1):
         ref_h = orc.softplus100(fw["a"][l])
         wd = ref_h.shape[1]
