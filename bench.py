@@ -19,10 +19,23 @@ Arithmetic: fp32 storage and fp32 accumulation everywhere; the matrix products r
 bf16x3 split products on the bf16 MFMA pipe (three bf16 terms per fp32 operand, six partial products, error 2^-24:
 fp32-equivalent, csrc/x3.h) -- `dtype` says which.
 
+Timing: W warm-up steps, then --windows windows of EXACTLY K steps each, every window bracketed by a barrier + device
+synchronisation on both sides and reduced with MAX over the ranks.  `ms_per_step` / `value` are the MEDIAN window (the chip's DVFS and
+the boxes of the pool move a 20-step window by 1-2 %); `windows_ms_per_step` lists them all, `ms_per_step_min` is the fastest.
+
+Per-entry-point times (`kernels`, `roofline`): the timed steps run the per-point entry points as a CHAIN of point ranges on several
+streams (include/i2sdf.h: I2SDF_OPT_PARTS), where an entry point has no duration of its own.  They are therefore measured live in
+a second pass of --profile-steps steps right behind the timed windows, same process, same inputs, with every entry point joining its
+ranges (HIP events on the stream the entry points are given, which then bracket all of an entry point's kernels).
+`roofline.traffic` and `kernels_hbm` (HBM bytes and GB/s of the sampler / compositing kernels) come from two rocprofv3 --pmc passes
+(FETCH_SIZE, WRITE_SIZE: separate runs, counters only) that this script starts itself on a 3-step run of the same workload.
+
 Sub-records of the same JSON line: `dense128` (BASELINE.json's metric convention: 128 shaded samples/ray, sampler bypassed),
-`strong` (fixed global batch of --strong-rays rays split over the ranks), `natural_k` (the data-dependent sampler loop instead
-of k=2), `wgrad_bf16x2` (opt-in two-term split arithmetic in the weight-gradient kernel only), `roofline`, `cpu_baseline` (the CPU restatement on this node's host cores), `eager_rocm_baseline` (the same
-restatement as stock PyTorch-ROCm eager ops on this GPU: the un-fused baseline of BASELINE.md section 3).
+`strong` (fixed global batch of --strong-rays rays split over the ranks), `k1` / `k5` / `natural_k` (sampler iteration count fixed
+to 1 / 5, and the data-dependent loop, instead of k=2), `wgrad_bf16x2` (opt-in two-term split arithmetic in the weight-gradient
+kernel only), `roofline`, `cpu_baseline` (the CPU restatement on this node's host cores: best thread count, 1 thread, all physical
+cores), `eager_rocm_baseline` (the same restatement as stock PyTorch-ROCm eager ops on this GPU: the un-fused baseline of
+BASELINE.md section 3).
 """
 import argparse
 import json
@@ -46,6 +59,14 @@ def parse():
     ap.add_argument("--scaling", default="both", choices=["weak", "strong", "both"],
                     help="which scaling mode(s) to time; `value`/`scaling` of the JSON line are the weak ones unless --scaling strong")
     ap.add_argument("--sampler-iters", type=int, default=2, help="fixed sampler iterations k (0 = data dependent)")
+    ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-entry-point timing pass behind the timed windows")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not start the rocprofv3 --pmc passes for roofline.traffic / kernels_hbm")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the run under rocprofv3: headline steps only, no output
+    ap.add_argument("--cpu-probe", default="", help=argparse.SUPPRESS)               # "threads,rays,k,n_shaded": one bounded CPU measurement, prints JSON
+    ap.add_argument("--selftest-launch", action="store_true",
+                    help="launch-logic self-test WITHOUT a GPU: the same spawn / rendezvous / rank-0 JSON path with the render core replaced by the "
+                         "CPU stand-in of tests/host_stub.py (needs --backend gloo for N>1); the line it prints is marked data=mock and carries no throughput claim")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense128 / natural_k / eager_rocm_baseline sub-records")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
@@ -155,9 +176,9 @@ class Workload:
             self.torch.distributed.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False):
-        """-> dict(dt seconds for `steps` steps (max over ranks), loss, iters, ktimes).  dense > 0: `dense` uniform samples per ray,
-        sampler bypassed (the dense-128 convention)."""
+    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0):
+        """-> dict(dt = median over `windows` windows of the seconds for `steps` steps (each max over ranks), dts, loss, iters, ktimes).
+        dense > 0: `dense` uniform samples per ray, sampler bypassed (the dense-128 convention)."""
         torch, net = self.torch, self.net
         inp, gt = self.inputs(B, seed)
         net.force_iters = k_iters
@@ -180,24 +201,85 @@ class Workload:
         for _ in range(max(warmup, 1)):
             step()
         eng = net._engine_for(self.dev)
-        self.fence()
-        if timing:
-            eng.start_timing()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        self.fence()
-        dt = time.perf_counter() - t0
-        ktimes = eng.stop_timing() if timing else None
-        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        dts = []
+        for _ in range(max(windows, 1)):                       # every window: exactly `steps` steps, barrier + synchronize on both sides
+            self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss = step()
+            self.fence()
+            dts.append(time.perf_counter() - t0)
+        t = torch.tensor(dts, dtype=torch.float64, device=self.dev)
         if self.world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        return {"dt": float(t.item()), "loss": float(loss.item()), "iters": int(net.last_sampler_iters.item()) if not dense else 0,
-                "ktimes": ktimes, "eng": eng}
+        dts = [float(x) for x in t.tolist()]
+        ktimes, prof_steps = None, 0
+        if timing and profile_steps > 0:
+            # per-entry-point pass: every entry point joins its point ranges, so the events on the caller's stream bracket all its kernels
+            eng.use_chain = False
+            step()
+            self.fence()
+            eng.start_timing()
+            for _ in range(profile_steps):
+                step()
+            self.fence()
+            ktimes, prof_steps = eng.stop_timing(), profile_steps
+            eng.use_chain = True
+        med = sorted(dts)[len(dts) // 2]
+        return {"dt": med, "dts": dts, "loss": float(loss.item()), "iters": int(net.last_sampler_iters.item()) if not dense else 0,
+                "ktimes": ktimes, "prof_steps": prof_steps, "eng": eng}
+
+
+class _MockEngine:
+    """what main() reads off the engine, for --selftest-launch"""
+    n_z, parts, use_chain = 98, 0, True
+    sdf_forward_bf16x3 = train_forward_bf16x3 = sdf_backward_bf16x3 = wgrad_bf16x3 = wgrad_bf16x2 = rgb_bf16x3 = False
+
+    def start_timing(self):
+        pass
+
+    def stop_timing(self):
+        return {}
+
+
+class MockWorkload(Workload):
+    """--selftest-launch: the real module wiring (flat parameter buffer, grad_sync hook, attach_data_parallel) over the CPU stand-in core
+    of tests/host_stub.py; no GPU, no kernels -- it exists so that the N>1 launch path can be exercised on a CPU box."""
+
+    def __init__(self, args, dev, rank, world):
+        import torch
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from host_stub import HostStubNetwork
+        from i2sdf_amd import synthetic_conf
+        from i2sdf_amd import dist as i2dist
+        self.torch, self.dev, self.rank, self.world, self.args = torch, dev, rank, world, args
+        torch.manual_seed(0)
+        self.net = HostStubNetwork(synthetic_conf())
+        self.net._ensure_flat()
+        self.opt = torch.optim.SGD(self.net.parameters(), lr=1e-3)
+        if world > 1:
+            i2dist.attach_data_parallel(self.net)
+        self.step_no = 0
+        self.eng = _MockEngine()
+        self.net.last_sampler_iters = torch.tensor([args.sampler_iters or 5])
+        self.net._engine_for = lambda dev_: self.eng
+
+    def loss_fn(self, out, gt, step):
+        return {"loss": ((out["rgb_values"] - gt["rgb"]) ** 2).mean()}
+
+    def fence(self):
+        if self.world > 1:
+            self.torch.distributed.barrier()
+
+    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0):
+        self.args_dense = dense
+        return Workload.run(self, min(B, 64), seed, k_iters, steps, warmup, dense=0, timing=timing, windows=windows, profile_steps=0)
 
 
 def main():
     args = parse()
+    if args.cpu_probe:
+        return cpu_probe(args.cpu_probe)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn(args))
     import torch
@@ -205,21 +287,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    if world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
+    mock = args.selftest_launch
+    assert mock or torch.cuda.is_available(), "bench.py needs an MI355X"
+    if mock and world > 1 and args.backend != "gloo":
+        raise SystemExit("bench.py --selftest-launch runs on the CPU: use --backend gloo")
+    if not mock and world > 1 and not args.share_gpu and torch.cuda.device_count() < world:
         raise SystemExit(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible "
                          "(--share-gpu --backend gloo runs all ranks on cuda:0 to smoke-test the N>1 path)")
     dev_index = 0 if (world == 1 or args.share_gpu) else local_rank
-    torch.cuda.set_device(dev_index)
+    if not mock:
+        torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(args.backend)
-    dev = torch.device("cuda", dev_index)
+    dev = torch.device("cpu") if mock else torch.device("cuda", dev_index)
 
-    wl = Workload(args, dev, rank, world)
+    wl = (MockWorkload if mock else Workload)(args, dev, rank, world)
+    if mock:
+        args.no_extras = args.no_cpu_baseline = args.no_live_traffic = True
     B = args.rays
     wl.run(B, 1000 + rank, args.sampler_iters, 1, 1)        # builds the engine (and the flat parameter buffer) the way a trainer would
     eng = wl.net._engine_for(dev)
@@ -231,14 +319,19 @@ def main():
         eng.set_rgb_bf16x3(bool(args.bf16x3 & 16))
     n_shaded = eng.n_z - 1
     K, W = args.steps, args.warmup
+    if args.pmc_child:            # under rocprofv3 --pmc (live_traffic below): the headline steps only, nothing to report
+        wl.run(B, 1000 + rank, args.sampler_iters, K, W)
+        return
 
     # ---- headline: weak scaling, every rank draws its own `rays` rays -----------------------------------------------
     weak = strong = None
     if args.scaling in ("weak", "both"):
-        weak = wl.run(B, 1000 + rank, args.sampler_iters, K, W, timing=True)      # each rank draws its own rays (ray-sharded data parallelism)
+        weak = wl.run(B, 1000 + rank, args.sampler_iters, K, W, timing=True, windows=args.windows,
+                      profile_steps=args.profile_steps)      # each rank draws its own rays (ray-sharded data parallelism)
     if args.scaling in ("strong", "both"):
         Bs = args.strong_rays // world                    # fixed GLOBAL batch, split over the ranks
-        strong = wl.run(Bs, 2000 + rank, args.sampler_iters, K, W, timing=(weak is None))
+        strong = wl.run(Bs, 2000 + rank, args.sampler_iters, K, W, timing=(weak is None), windows=(args.windows if weak is None else 1),
+                        profile_steps=(args.profile_steps if weak is None else 0))
         strong["rays_per_gpu"] = Bs
     head = weak if weak is not None else strong
     head_B = B if weak is not None else strong["rays_per_gpu"]
@@ -262,12 +355,18 @@ def main():
                                                   "(three products, fp32 accumulate; per-product error <= 3*2^-18).  Not fp32-equivalent, but above the reference's own "
                                                   "float32_matmul_precision('medium') (main_recon.py:61); measured: every parameter gradient stays at 3e-6 max-norm relative "
                                                   "of the fp64 oracle on full-size batches (bar 1e-4; tests/test_gpu_network.py::test_wgrad_bf16x2_stays_inside_the_parity_bar)"}
+        for kk in (1, 5):
+            if kk != args.sampler_iters:
+                rk = wl.run(B, 1000 + rank, kk, K, W)
+                extras[f"k{kk}"] = {"value": round(B * n_shaded * world / (rk["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(rk["dt"] / K * 1e3, 4),
+                                    "workload": f"same as the headline with the sampler iteration count fixed to k={kk}"}
         nat = wl.run(B, 1000 + rank, 0, K, W)
         extras["natural_k"] = {"value": round(B * n_shaded * world / (nat["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(nat["dt"] / K * 1e3, 4),
                                "sampler_iters_observed": nat["iters"],
                                "workload": "same as the headline with the data-dependent sampler loop (all max_total_iters iterations enqueued, device flag)"}
 
     result = None
+    live = live_traffic(args) if (rank == 0 and world == 1) else None
     if rank == 0:
         cfg = wl.net.cfg
         fp = flops_per_point(cfg)
@@ -282,8 +381,9 @@ def main():
             "i2sdf_weight_grads": fp["wgrad_sdf"] * M_sdf + fp["wgrad_rgb"] * M_main,
         }
         kern = {}
-        for name, (tot_ms, cnt) in ktimes.items():
-            kern[name] = {"ms_per_step": tot_ms / K, "launches_per_step": cnt / K}
+        KP = max(head["prof_steps"], 1)
+        for name, (tot_ms, cnt) in (ktimes or {}).items():
+            kern[name] = {"ms_per_step": tot_ms / KP, "launches_per_step": cnt / KP}
             if name in launch_flops and cnt:
                 kern[name]["tflops"] = launch_flops[name] / (tot_ms / cnt * 1e-3) / 1e12
         mfma_names = [n for n in kern if "tflops" in kern[n]]
@@ -303,7 +403,10 @@ def main():
             npts = {"i2sdf_rgb_forward": M_main, "i2sdf_rgb_backward": M_main}.get(dom, M_sdf)
             design_bytes = bytes_per_point(cfg).get(dom, 0) * npts
             t_launch = kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1e-9) * 1e-3
-            traffic, src = profiled_traffic(dom)
+            traffic = entry_traffic(live, dom)
+            src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes started by this run (2 x FETCH + WRITE, all kernels of the entry point, per step)"
+            if traffic is None:
+                traffic, src = profiled_traffic(dom)
             roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                     "kernel": dom, "arithmetic": "bf16x3 split (fp32-equivalent FLOPs; peak = 2500 TFLOP/s dense bf16 / 6 MFMAs per product block)"
                     if x3.get(dom) else "f32 MFMA",
@@ -321,12 +424,16 @@ def main():
         result = {
             "metric": "ray-samples/sec (fwd+bwd)", "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak" if weak is not None else "strong",
+            "windows_ms_per_step": [round(x / K * 1e3, 4) for x in head["dts"]], "ms_per_step_min": round(min(head["dts"]) / K * 1e3, 4),
+            "timing": f"median of {len(head['dts'])} windows of exactly {K} steps each (barrier + synchronize around every window, max over ranks)",
             "vs_baseline": None,
             "dtype": "f32" if not any_x3 else "f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" if not mock else "mock (launch-logic self-test on the CPU stand-in core: value / ms_per_step carry NO throughput claim)",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
                        "rays_per_gpu": head_B, "shaded_samples_per_ray": n_shaded, "sampler_iters": iters, "sampler_samples_per_iter": cfg.sampler.N_samples_eval,
-                       "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce)",
+                       "camera": "t=(0,0,-2), R=I, f=600, beta=0.02", "parallelism": f"dp{world} (ray-sharded, 1 flat grad all-reduce" + (
+                           "" if world == 1 else (": library RCCL communicator, i2sdf_allreduce_grads" if getattr(wl.net.dp_state, "comm", None) is not None
+                                                  else ": torch.distributed all_reduce")) + ")",
                        "optimizer": "i2sdf_amd.FusedAdam (1 launch)" if args.fused_adam else "torch.optim.Adam",
                        "backend": (args.backend if world > 1 else None), "world_size_observed": (dist.get_world_size() if world > 1 else 1)},
             "rays_per_s": round(head_B * world / (dt / K), 1),
@@ -335,7 +442,26 @@ def main():
             "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / K) / 1e12 / PEAK, 4),   # per GPU (weak scaling)
             "final_loss": head["loss"],
             "roofline": roof, "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},
+            "kernels_note": f"per-entry-point HIP-event times of a {head['prof_steps']}-step pass behind the timed windows in which every entry point joins its point "
+                            f"ranges (parts = {eng.parts}); in the timed steps the ranges of consecutive entry points overlap, so these do not add up to ms_per_step",
         }
+        if live:
+            # the per-ray kernels (sampler non-MLP part, compositing) are priced against HBM bandwidth: bytes moved and GB/s
+            # per launch from the PMC passes (kernels serialised there, so `us` is the kernel running alone)
+            hb = {}
+            for k, v in live.items():
+                short = k.split("(")[0].split("::")[-1].split("<")[0].strip()
+                if any(q in short for q in ("composite_", "sampler_", "beta_reduce", "raygen", "loss_", "draws_")) and v.get("us", 0) > 0:
+                    e = hb.setdefault(short, {"bytes": 0.0, "us": 0.0, "launches_per_step": 0.0})
+                    e["bytes"] += (v["fetch"] + v["write"]) * v["n"]; e["us"] += v["us"] * v["n"]; e["launches_per_step"] += v["n"]
+            result["kernels_hbm"] = {k: {"bytes_per_launch": round(e["bytes"] / e["launches_per_step"]), "us_per_launch": round(e["us"] / e["launches_per_step"], 2),
+                                         "gbs": round(e["bytes"] / e["us"] / 1e3, 1), "frac_of_8tbs": round(e["bytes"] / e["us"] / 1e3 / 8000.0, 4),
+                                         "launches_per_step": round(e["launches_per_step"], 2)} for k, e in sorted(hb.items())}
+            result["kernels_hbm_note"] = ("1024 rays are 256 workgroups of four rays: these kernels are latency-bound (one round of short workgroups), "
+                                          "not bandwidth-bound; together they are < 2 % of the step")
+            big = sorted(((v["us"] * v["n"], k, v) for k, v in live.items() if v.get("clock_ghz")), reverse=True)[:6]
+            result["clocks_ghz"] = {k.split("(")[0].split("::")[-1].split("<")[0].strip(): round(v["clock_ghz"], 3) for _, k, v in big}
+            result["step_hbm_bytes"] = round(sum((v["fetch"] + v["write"]) * v.get("n", 0.0) for v in live.values()))
         if weak is not None and strong is not None:
             Bs = strong["rays_per_gpu"]
             result["strong"] = {"value": round(Bs * world * n_shaded / (strong["dt"] / K), 1), "unit": "ray-samples/s", "scaling": "strong",
@@ -351,21 +477,103 @@ def main():
         dist.destroy_process_group()
 
 
+ENTRY_KERNELS = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),
+                 "i2sdf_sample_rays": ("sdf_fwd", "sampler_"), "i2sdf_rgb_forward": ("rgb_fwd",), "i2sdf_rgb_backward": ("rgb_bwd",),
+                 "i2sdf_composite_forward": ("composite_fwd",), "i2sdf_composite_backward": ("composite_bwd", "beta_reduce")}
+
+
+def source_hash():
+    """sha256 over the kernel sources + the C header: what a committed profile must have been taken with to describe this build."""
+    import glob
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(here, "i2sdf_amd", "csrc", "*.h*")) + glob.glob(os.path.join(here, "i2sdf_amd", "csrc", "*.cpp"))
+                    + [os.path.join(here, "include", "i2sdf.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def live_traffic(args):
+    """HBM traffic per kernel, measured NOW: two rocprofv3 passes (counters only, one --pmc set per run as the profiling guide
+    prescribes: FETCH_SIZE [+ GRBM_GUI_ACTIVE for the clock], then WRITE_SIZE) over a short run of the headline workload (this script
+    with --pmc-child).  -> {kernel name: {"fetch": bytes/dispatch (FETCH_SIZE x 1024 x 2: the counter tallies 128-B requests of wide
+    loads at 64 B on gfx950, MI355X_MICROARCH.md), "write": bytes/dispatch, "us": mean duration, "n": dispatches per step, "clock_ghz"}} or None."""
+    import csv
+    import shutil
+    import tempfile
+    if args.no_live_traffic or shutil.which("rocprofv3") is None:
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            for tag, counters in (("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]), ("write", ["WRITE_SIZE"])):
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", tag, "--output-format", "csv", "--", sys.executable,
+                       os.path.join(here, "bench.py"), "--pmc-child", "--steps", "2", "--warmup", "1", "--rays", str(args.rays),
+                       "--sampler-iters", str(args.sampler_iters), "--fused-adam", str(args.fused_adam), "--bf16x3", str(args.bf16x3)]
+                r = subprocess.run(cmd, cwd=here, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                cc, kt = os.path.join(d, f"{tag}_counter_collection.csv"), os.path.join(d, f"{tag}_kernel_trace.csv")
+                if r.returncode != 0 or not os.path.exists(cc) or not os.path.exists(kt):
+                    return None
+                agg, cnt, seen, dur = {}, {}, set(), {}
+                for row in csv.DictReader(open(cc)):
+                    k = row["Kernel_Name"]
+                    a = agg.setdefault(k, {})
+                    a[row["Counter_Name"]] = a.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if row["Dispatch_Id"] not in seen:
+                        seen.add(row["Dispatch_Id"])
+                        cnt[k] = cnt.get(k, 0) + 1
+                for row in csv.DictReader(open(kt)):
+                    dur[row["Kernel_Name"]] = dur.get(row["Kernel_Name"], 0.0) + (int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+                steps = max([n for k, n in cnt.items() if "wn_backward" in k] or [0])
+                if steps == 0:
+                    return None
+                for k, a in agg.items():
+                    e = out.setdefault(k, {"fetch": 0.0, "write": 0.0})
+                    if tag == "fetch":
+                        e["fetch"] = a.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 / cnt[k]
+                        e["us"] = dur.get(k, 0.0) / cnt[k] / 1e3
+                        e["n"] = cnt[k] / steps
+                        if e["us"] > 0 and a.get("GRBM_GUI_ACTIVE", 0.0) > 0:
+                            e["clock_ghz"] = a["GRBM_GUI_ACTIVE"] / cnt[k] / 8.0 / (e["us"] * 1e3)
+                    else:
+                        e["write"] = a.get("WRITE_SIZE", 0.0) * 1024.0 / cnt[k]
+        return out or None
+    except Exception:
+        return None
+
+
+def entry_traffic(live, entry):
+    """bytes per step of all kernels of an entry point from live_traffic()"""
+    pat = ENTRY_KERNELS.get(entry)
+    if not live or not pat:
+        return None
+    tot = sum((v["fetch"] + v["write"]) * v.get("n", 0.0) for k, v in live.items() if any(q in k for q in pat))
+    return round(tot) if tot > 0 else None
+
+
 def profiled_traffic(entry):
-    """HBM bytes per launch of an entry point from the newest committed PMC summaries (profiles/r*_pmc_{fetch,write}_summary.csv:
-    FETCH_SIZE / WRITE_SIZE in KB per dispatch, separate --pmc passes; FETCH doubled as MI355X_MICROARCH.md prescribes for
-    16-B-per-lane loads on gfx950).  It is a profile of the same command from an earlier run, not a live counter read:
-    -> (bytes | None, source label)."""
+    """Fallback when rocprofv3 is not on PATH: HBM bytes per launch of an entry point from the newest committed PMC summaries
+    (profiles/r*_pmc_{fetch,write}_summary.csv), accepted only if profiles/r*_source_hash.txt matches this build's sources
+    (a profile of other kernels would silently describe the wrong code).  -> (bytes | None, source label)."""
     import csv
     import glob
-    pat = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),
-           "i2sdf_sample_rays": ("sdf_fwd", "sampler_")}.get(entry)
+    pat = ENTRY_KERNELS.get(entry)
     here = os.path.dirname(os.path.abspath(__file__))
     rounds = sorted({os.path.basename(p).split("_")[0] for p in glob.glob(os.path.join(here, "profiles", "r*_pmc_fetch_summary.csv"))},
                     key=lambda r: int(r[1:]) if r[1:].isdigit() else -1)
     if not rounds or not pat:
         return None, None
     tag_r = rounds[-1]
+    try:
+        stamp = open(os.path.join(here, "profiles", f"{tag_r}_source_hash.txt")).read().split()[0]
+    except (OSError, IndexError):
+        stamp = None
+    if stamp != source_hash():
+        return None, f"profiles/{tag_r}_pmc_* were taken with other kernel sources (hash {stamp}, this build {source_hash()}): not used"
     try:
         tot = 0.0
         for tag, col, mult in (("fetch", "FETCH_SIZE_per_dispatch", 2.0), ("write", "WRITE_SIZE_per_dispatch", 1.0)):
@@ -374,7 +582,7 @@ def profiled_traffic(entry):
             if steps == 0:
                 return None, None
             tot += sum(float(r[col]) * 1024.0 * mult * int(r["dispatches"]) for r in rows if any(q in r["kernel"] for q in pat)) / steps
-        return (round(tot), f"profiles/{tag_r}_pmc_{{fetch,write}}_summary.csv (committed rocprofv3 --pmc passes of `bench.py`, not measured in this run)") \
+        return (round(tot), f"profiles/{tag_r}_pmc_{{fetch,write}}_summary.csv (committed rocprofv3 --pmc passes of this build's sources, not measured in this run)") \
             if tot > 0 else (None, None)
     except (OSError, KeyError, ValueError):
         return None, None
@@ -406,31 +614,70 @@ def _oracle_case(Bc, iters, n_shaded, device, dtype_seed=7):
     return orc, ocfg, mv(sd), mv(inp), mv(gt), lc, dr
 
 
-def cpu_baseline(args, iters, n_shaded):
-    """The CPU oracle (a port of the reference's PyTorch path, validated against it) timed on this node's host cores on
-    a bounded sample of the same workload: same networks, same camera, same fixed k, fewer rays."""
+def cpu_probe(spec):
+    """child mode (--cpu-probe threads,rays,k,n_shaded): time the CPU restatement with `threads` torch threads, print one JSON line"""
     import torch
-    ncpu = os.cpu_count() or 1
-    # torch's CPU GEMMs on 256-wide layers stop scaling (and then collapse) beyond a few tens of threads: the headline CPU number
-    # uses at most 32; the all-threads figure SURVEY 8(d) asks for is measured next to it on a smaller sample.
-    cores = min(ncpu, 32)
-    torch.set_num_threads(cores)
-    Bc = args.cpu_rays
+    threads, Bc, iters, n_shaded = (int(x) for x in spec.split(","))
+    torch.set_num_threads(threads)
     orc, ocfg, sd, inp, gt, lc, dr = _oracle_case(Bc, iters, n_shaded, "cpu")
     times = []
     for i in range(4):
         t0 = time.perf_counter()
         orc.training_step_grads(sd, ocfg, inp, gt, lc, dr, step=10, force_iters=iters or None)
         times.append(time.perf_counter() - t0)
-        if sum(times) > 40.0 and len(times) >= 2:      # keep the default run within minutes on any host
+        print(json.dumps({"threads": threads, "rays": Bc, "times": times}), flush=True)     # a line per step: a killed child still reports
+        if sum(times) > 30.0 and len(times) >= 2:
             break
-    med = sorted(times[1:])[len(times[1:]) // 2]
-    out = {"value": round(Bc * n_shaded / med, 1), "unit": "ray-samples/s", "cores": cores, "kind": "port",
-           "sample": f"{Bc} rays x {n_shaded} shaded samples, same nets/camera/k={iters}, fwd+loss+bwd (no optimizer), torch CPU fp32 "
-                     f"{cores} threads (host has {ncpu}), median of {len(times) - 1} after 1 warm-up, {med:.2f} s/step"}
-    # all 256 hardware threads of the MI355X node's host were measured once (round 2, 64 rays): 57 ray-samples/s, 340x slower than
-    # 32 threads (torch's CPU GEMMs on 256-wide layers collapse under oversubscription) -- 109 s per step, so it is not re-run here
-    out["all_threads_note"] = "256 threads: 57.1 ray-samples/s on 64 rays (measured once in round 2, 108.8 s/step; DESIGN.md)"
+
+
+def _cpu_case(threads, Bc, iters, n_shaded, timeout):
+    """One bounded measurement in a child process (torch's intra-op thread count cannot be changed reliably once used, and an
+    over-subscribed run must be killable): -> dict(value, s_per_step, steps) or dict(value None, note)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-probe", f"{threads},{Bc},{iters},{n_shaded}"]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+    last = None
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout)
+        lines = r.stdout.decode().strip().splitlines()
+    except subprocess.TimeoutExpired as e:
+        lines = (e.stdout or b"").decode().strip().splitlines()
+    for ln in lines:
+        try:
+            last = json.loads(ln)
+        except ValueError:
+            pass
+    if not last or not last.get("times"):
+        return {"value": None, "threads": threads, "rays": Bc, "note": f"no step of {Bc} rays finished within {timeout} s"}
+    t = last["times"]
+    timed = t[1:] if len(t) > 1 else t               # first step = warm-up when there is a second one
+    med = sorted(timed)[len(timed) // 2]
+    return {"value": round(Bc * n_shaded / med, 1), "threads": threads, "rays": Bc, "s_per_step": round(med, 3),
+            "steps": f"median of {len(timed)} timed step(s)" + (" after 1 warm-up" if len(t) > 1 else " (no warm-up: the first step hit the time bound)")}
+
+
+def cpu_baseline(args, iters, n_shaded):
+    """The CPU oracle (a port of the reference's PyTorch path, validated against it) timed on this node's host cores on bounded
+    samples of the same workload (same networks, same camera, same fixed k, fewer rays), SURVEY 8(d): with n = all physical cores,
+    with n = 1, and with the thread count torch's CPU GEMMs on 256-wide layers actually scale to (32) -- the best of them is `value`.
+    Every case is a child process with a time bound, so the default run stays within minutes on any host."""
+    ncpu = os.cpu_count() or 1
+    phys = ncpu
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or ncpu
+    except Exception:
+        pass
+    cases = {"best_of_threads_32": _cpu_case(min(ncpu, 32), args.cpu_rays, iters, n_shaded, 60),
+             "one_thread": _cpu_case(1, 16, iters, n_shaded, 45),
+             "all_physical_cores": _cpu_case(phys, 64, iters, n_shaded, 45)}
+    best = max((c for c in cases.values() if c.get("value")), key=lambda c: c["value"], default=None)
+    out = {"value": best["value"] if best else None, "unit": "ray-samples/s", "cores": best["threads"] if best else 0, "kind": "port",
+           "sample": (f"{best['rays']} rays x {n_shaded} shaded samples, same nets/camera/k={iters}, fwd+loss+bwd (no optimizer), torch CPU fp32, "
+                      f"{best['threads']} threads, {best['steps']}, {best['s_per_step']} s/step") if best else "no case finished",
+           "host": {"os_cpu_count": ncpu, "physical_cores": phys},
+           "cases": cases,
+           "note": "torch's CPU GEMMs on 256-wide layers stop scaling beyond a few tens of threads and collapse under over-subscription "
+                   "(round 2, all 256 hardware threads: 108.8 s per 64-ray step); every case here is bounded in time"}
     return out
 
 

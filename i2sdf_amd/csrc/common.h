@@ -59,6 +59,7 @@ struct WStream {
   float* lds;         // two STAGE_FLOATS buffers
   int cur;            // buffer that the NEXT advance() returns
   int left;           // stages still to be fetched
+  int wv;             // this wave's index in the workgroup as a scalar (issue_piece: M0 is computed on the scalar unit)
 
   __device__ __forceinline__ void issue(float* dst, int tid) {
     const float* src = g + tid * 4;
@@ -76,6 +77,7 @@ struct WStream {
   // n_stages = total stages this kernel will consume from `base`
   __device__ __forceinline__ void begin(const float* base, float* lds_, int n_stages, int tid) {
     g = base; lds = lds_; cur = 0; left = n_stages;
+    wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (left > 0) { issue(lds, tid); --left; }
   }
   // Returns the LDS buffer holding the next stage.  All 4 waves must call this in lock step.
@@ -92,6 +94,23 @@ struct WStream {
     if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
     cur ^= 1;
     return ret;
+  }
+  // piecewise form of advance_issue(): the NPIECE 4 KB pieces of the following stage one at a time (i = 0..NPIECE-1, each wave moves
+  // 1 KB per piece), then advance_done() -- a piece costs the wave 60-180 cycles of issue (MI355X_MICROARCH.md), so the K-outer
+  // bf16x3 ops put ONE piece behind each group of MFMAs instead of all eight behind the first group
+  static constexpr int NPIECE = STAGE_FLOATS / (WG_THREADS * 4);
+  // Branch-free on purpose: a scalar branch around the DMA would cut the surrounding MFMA stream into basic blocks, and the
+  // scheduling fences (sched_barrier) that deal the VALU work into the MFMA shadows only act inside one block.  When no stage is left
+  // the piece re-reads the stage fetched last (valid memory) into the buffer nobody reads any more.
+  __device__ __forceinline__ void issue_piece(int i, int tid) {
+    const float* gs = left > 0 ? g : g - STAGE_FLOATS;
+    const float* src = gs + tid * 4 + i * WG_THREADS * 4;
+    float* d = lds + (cur ^ 1) * STAGE_FLOATS + wv * 256 + i * WG_THREADS * 4;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+  }
+  __device__ __forceinline__ void advance_done() {
+    if (left > 0) { g += STAGE_FLOATS; --left; }
+    cur ^= 1;
   }
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
   __device__ __forceinline__ const float* advance_barrier() {

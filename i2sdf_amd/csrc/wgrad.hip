@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
+#ifndef W3_PREFETCH
+#define W3_PREFETCH 0                    // stages of L2 prefetch ahead of the operand loads of wgrad3p (0 = off)
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2 tiles of 128x128) per block and chunk.
@@ -289,6 +292,9 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+#if W3_PREFETCH > 0
+  unsigned pf_sink = 0u;
+#endif
   const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
   for (int jb = 0; jb < t.njobs; ++jb) {
     const WgJob job = t.j[jb];
@@ -326,6 +332,20 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
       else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
     };
+#if W3_PREFETCH > 0
+    // L2 prefetch of the raw rows W3_PREFETCH stages ahead: ONE 4-byte load per lane, every lane in a different 128-B line of this
+    // wave's quarter of that stage (64 lines = 8 KB).  The result is never used; the line is on its way into the XCD's L2 when the
+    // operand loads of that stage are issued (one stage ahead of their use), so they pay an L2 hit instead of an HBM round trip under
+    // load.  `pf_sink` stays live through the loop (it is an in/out operand of every prefetch) so that its register is not handed to
+    // another value while a load into it is still in flight.
+    const unsigned pf_off = blk ? 4u * (unsigned)((lane >> 3) * 512 + (lane & 7) * 32) : 4u * (unsigned)((lane >> 2) * dld + (lane & 3) * 32);
+    auto prefetch = [&](int s, unsigned& sink) __attribute__((always_inline)) {
+      const int sc = s < nst ? s : nst - 1;
+      const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
+      const char* src = reinterpret_cast<const char*>(ubase + soff) + pf_off;
+      asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(src) : "memory");
+    };
+#endif
     unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
     auto prep = [&](int s, int i, float lo, float hi_, float& x0, float& x1) __attribute__((always_inline)) {
@@ -403,6 +423,9 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
           if (it >= 13 && st < NPL) write_tile(s + 1, tt - 1, st);
           if (tt == 3 && st == 1) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
           if (tt == 3 && st == 2) gload(s + 2, i, 1);
+#if W3_PREFETCH > 0
+          if (g == 3) prefetch(s + 2 + W3_PREFETCH, pf_sink);
+#endif
         }
         // LDS reads of the next phase, one instruction per unit, half a phase ahead
         if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(s, 2 + wb, tb + 1, gg - PH / 2);
@@ -414,9 +437,17 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       }
     };
     using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
+#if W3_PREFETCH > 0
+#pragma unroll
+    for (int k = 0; k < W3_PREFETCH; ++k) prefetch(2 + k, pf_sink);
+#endif
     for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
     stage(nst - 1, BF{});
   }
+#if W3_PREFETCH > 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (pf_sink == 0x7f123457u && L.n < 0) bsum[0] += 1.0f;      // (never true: keeps pf_sink alive to here)
+#endif
   float* out = L.partials + chunk * L.chunk_stride;
   const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
 #pragma unroll

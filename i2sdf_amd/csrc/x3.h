@@ -31,6 +31,12 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
 #define X3_AHEAD 1
 #define X3_RING 2
+#ifndef X3_DMA_SPREAD
+#define X3_DMA_SPREAD 1 // the weight DMA of the following stage as one piece per MFMA group (WStream::issue_piece) instead of one burst
+#endif
+#ifndef X3_DEFER
+#define X3_DEFER 1      // 4 MFMAs per pair group instead of 6 / 4 / 2 (dense_x3g)
+#endif
 __host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -100,6 +106,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   // Stores of the source (saved tensors) are not issued where their values become known but right after the next stage
   // barrier: the barrier's vmcnt(0) drain (needed for the LDS DMA) would otherwise wait for stores issued moments before it.
   float sv[2][8], sx[2][8];
+  u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // X3_DEFER: the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
   auto flush = [&]() __attribute__((always_inline)) {
     if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
@@ -154,6 +161,8 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
       if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
     __builtin_amdgcn_sched_barrier(0);
     bool issued = false;
+    int npiece = 0;
+    (void)issued; (void)npiece;
 #pragma unroll
     for (int jp = 0; jp < SC / 2; ++jp) {
       if (jp >= p0 && jp < p1) {
@@ -171,11 +180,27 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
           acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
           acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
         }
+#if X3_DEFER
+        // Four MFMAs in every group: the W0*h2 pair of the sp = 0 group (six products) is issued two groups later, in the sp = 2
+        // group (two products of its own), with the sp = 0 weights kept in registers meanwhile.  Every group carries the same share
+        // of the B preparation (one softplus or one split item, 7-11 VALU) and two LDS reads: behind two MFMAs they do not fit the
+        // 64 cycles of matrix-pipe time, behind six most of it goes unused.
+        if (sp == 0) { d0 = a0; d1 = a1; }
+        if (sp == 2) {
+          acc[nt] = mfma_bf16(d0, b[2], acc[nt]);
+          acc[nt + 1] = mfma_bf16(d1, b[2], acc[nt + 1]);
+        }
+#else
         if (sp == 0) {
           acc[nt] = mfma_bf16(a0, b[2], acc[nt]);
           acc[nt + 1] = mfma_bf16(a1, b[2], acc[nt + 1]);
         }
+#endif
+#if X3_DMA_SPREAD
+        if (npiece < WStream::NPIECE) { ws.issue_piece(npiece, tid); ++npiece; }       // next stage's DMA: one piece per group
+#else
         if (!issued) { ws.advance_issue(tid); issued = true; }
+#endif
         {
           const int pi = w % PPK;
 #pragma unroll
@@ -185,7 +210,14 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#if X3_DMA_SPREAD
+#pragma unroll
+    for (int i = 0; i < WStream::NPIECE; ++i)
+      if (i >= npiece) ws.issue_piece(i, tid);
+    ws.advance_done();
+#else
     if (!issued) ws.advance_issue(tid);
+#endif
   }
   flush();
 #pragma unroll

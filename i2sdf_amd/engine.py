@@ -56,7 +56,7 @@ class RenderEngine:
             self.set_tail_overlap(True)
         # point ranges on their own streams instead of split-K tail workgroups (include/i2sdf.h: I2SDF_OPT_PARTS); I2SDF_PARTS=0 for A/B runs
         self.parts = 0
-        n_parts = int(os.environ.get("I2SDF_PARTS", "4"))
+        n_parts = int(os.environ.get("I2SDF_PARTS", "2"))
         if cfg.bf16x3 and n_parts >= 2 and self.train_forward_bf16x3 and self.sdf_backward_bf16x3:
             self.set_parts(n_parts)
         sc = cfg.sampler

@@ -1,0 +1,60 @@
+"""CPU: bench.py's N > 1 launch path without a GPU (`--selftest-launch`: the render core is the CPU stand-in of tests/host_stub.py,
+everything else -- self-spawn of one rank per GPU through torch.distributed.run on 127.0.0.1, rendezvous, the data-parallel hook,
+barrier-bracketed windows with MAX over ranks, rank 0 printing ONE JSON line -- is the code the driver's multi-GPU run executes).
+The driver's own form (`python -m torch.distributed.run ... bench.py --gpus N`) is exercised as well."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _check(stdout, n):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line expected, got {len(lines)}:\n{stdout[-2000:]}"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["world_size_observed"] == n
+    assert d["steps"] == 3 and d["warmup"] == 1 and len(d["windows_ms_per_step"]) == 2
+    assert d["scaling"] == "weak" and d["value"] > 0 and d["ms_per_step"] > 0 and d["higher_is_better"] is True
+    assert d["strong"]["scaling"] == "strong" and d["strong"]["n_gpus"] == n and d["strong"]["global_rays"] == 8192 and d["strong"]["value"] > 0
+    assert d["strong"]["rays_per_gpu"] == 8192 // n
+    assert d["data"].startswith("mock"), "a self-test line must say that it is one"
+    assert f"dp{n}" in d["config"]["parallelism"]
+    if n > 1:
+        assert "torch.distributed all_reduce" in d["config"]["parallelism"] and d["config"]["backend"] == "gloo"
+    return d
+
+
+def test_self_spawned_two_ranks_print_one_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-launch", "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--windows", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check(r.stdout.decode(), 2)
+
+
+def test_driver_form_torchrun_two_ranks():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_port()),
+           os.path.join(ROOT, "bench.py"), "--selftest-launch", "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--windows", "2"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check(r.stdout.decode(), 2)
+
+
+def test_single_rank():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-launch", "--steps", "3", "--warmup", "1", "--windows", "2"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    _check(r.stdout.decode(), 1)
+
+
+def test_nccl_backend_without_gpus_fails_fast_not_hangs():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")], "no record may be printed by a run that could not start"

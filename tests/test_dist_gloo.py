@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the data-parallel pieces of the path (flat-gradient all-reduce, parameter broadcast,
-pixel sharding + gather).  The HIP kernels themselves need a GPU; what is checked here is the N>1 orchestration
-bench.py / a trainer uses, with a stand-in per-rank "backward" that fills the flat gradient buffer."""
+pixel sharding + gather).  The HIP kernels themselves need a GPU; what is checked here is the N>1 orchestration bench.py / a
+trainer uses, on the REAL module wiring -- `tests/host_stub.HostStubNetwork` is `I2SDFNetwork` with its render core replaced by a
+closed-form CPU function: flat parameter buffer, parameter views, the `grad_sync` hook call at the end of backward are the product's."""
 import os
 import socket
 
@@ -14,42 +15,52 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-class _FakeNet:
-    """Quacks like I2SDFNetwork for i2sdf_amd.dist: a flat parameter buffer + a grad_sync hook called inside backward."""
-
-    def __init__(self, n):
-        self._flat = torch.arange(n, dtype=torch.float32)
-        self.grad_sync = None
-
-    def parameters(self):
-        return [self._flat]
-
-    def backward(self, per_ray_grads):
-        g = per_ray_grads.sum(0)                 # the kernels sum the gradient over this rank's rays
-        if self.grad_sync is not None:
-            self.grad_sync(g)
-        return g
+def _grads(net, uv, target):
+    net.zero_grad()
+    out = net({"uv": uv})
+    loss = ((out["rgb_values"] - target) ** 2).mean()
+    loss.backward()
+    return torch.cat([p.grad.reshape(-1) for p in net._param_list()]).clone()
 
 
 def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from i2sdf_amd import dist as i2d
-    n = 1001
-    net = _FakeNet(n)
-    if rank != 0:
-        net._flat += 100.0                       # diverged replica
-    i2d.broadcast_parameters(net, src=0)
-    assert torch.equal(net._flat, torch.arange(n, dtype=torch.float32))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from host_stub import HostStubNetwork            # the REAL module wiring (flat buffer, parameter views, grad_sync hook) over a CPU stand-in core
+    from i2sdf_amd import dist as i2d, plumbing_conf
+    torch.manual_seed(7 + rank)                      # different initial weights per rank ...
+    net = HostStubNetwork(plumbing_conf())
+    net._ensure_flat()
+    i2d.broadcast_parameters(net, src=0)             # ... until rank 0's are broadcast (one broadcast of the flat buffer)
+    ref = HostStubNetwork(plumbing_conf())
+    torch.manual_seed(7)
+    ref._init_parameters()
+    ref._ensure_flat()
+    assert torch.equal(net._flat, ref._flat), "every rank must hold rank 0's parameters"
+    assert all(p.data_ptr() == net._flat.data_ptr() + 4 * off for (_, off, _), p in zip(net.layout.entries, net._param_list()))
     i2d.attach_data_parallel(net)
-    # invariant (SURVEY 4): N-rank averaged gradient == 1-rank gradient of the mean loss over the concatenated batch
+    assert net.dp_state.comm is None and net.dp_state.world == world      # gloo group: torch.distributed carries the collective
+    # invariant: the N-rank averaged gradient == the 1-rank gradient of the mean loss over the concatenated batch
     g = torch.Generator().manual_seed(0)
-    all_rays = torch.randn(64, n, generator=g)   # per-ray gradient contributions of a mean-type loss, already / local batch
-    lo, hi = i2d.shard_range(64, rank, world)
-    local = all_rays[lo:hi] / (hi - lo)
-    got = net.backward(local)
-    want = all_rays.sum(0) / 64
-    assert torch.allclose(got, want, rtol=1e-5, atol=1e-6)
+    Btot = 64
+    uv = torch.rand(Btot, 1, 2, generator=g) * 30
+    tgt = torch.rand(Btot, 3, generator=g)
+    lo, hi = i2d.shard_range(Btot, rank, world)
+    got = _grads(net, uv[lo:hi], tgt[lo:hi])
+    want = _grads(ref, uv, tgt)
+    assert float(want.abs().max()) > 0
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-9), float((got - want).abs().max())
+    # gradient accumulation: inside no_sync() the gradient stays the rank's own
+    with i2d.no_sync(net):
+        local = _grads(net, uv[lo:hi], tgt[lo:hi])
+    own = _grads(ref, uv[lo:hi], tgt[lo:hi])
+    assert torch.allclose(local, own, rtol=1e-5, atol=1e-9) and not torch.allclose(local, want, rtol=1e-3, atol=1e-9)
+    # loss hook (equivalent mode): exchanges only in training mode and outside no_sync()
+    from i2sdf_amd import I2SDFLoss
+    lf = i2d.attach_loss(I2SDFLoss(), net)
+    assert lf.exchange is None and lf._dp_state is net.dp_state           # throughput mode: no denominators to exchange
     # inference: shard pixels, gather outputs back in image order
     P = 37
     inp = {"uv": torch.arange(P * 2, dtype=torch.float32).reshape(1, P, 2), "pose": torch.eye(4).unsqueeze(0), "intrinsics": torch.eye(4).unsqueeze(0)}

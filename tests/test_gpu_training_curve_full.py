@@ -8,11 +8,24 @@ model/network/__init__.py:289-406, PSNR utils/rend_util.py:13-22).
                 fused draws kernel (`i2sdf_training_draws`, Philox); they are taken out of the module call only so that the very
                 same numbers can be handed to the other side.
   * oracle    : the fp32 restatement's torch ops (autograd double backward) as stock PyTorch-ROCm eager kernels on the same GPU,
-                `torch.optim.Adam`, its own sampler decisions.
+                `torch.optim.Adam`, its own sampler decisions -- run THREE times: A from the same initial weights as the HIP side,
+                A' and A'' from weights that differ from them by fp32 rounding noise (relative 1e-7).
 
-Both start from identical weights and see identical batches / draws.  The scene is learnable (a shaded sphere: colour a smooth
-function of the pixel, analytic depth and normals), so the curves actually move.  Bars: PSNR of the rendered batch
-within 0.1 dB at EVERY step, total loss within 1e-2 relative, and the held-out PSNR of the two trained weight sets within 0.1 dB."""
+All runs see identical batches / draws.  The scene is learnable (a shaded sphere: colour a smooth function of the pixel, analytic depth
+and normals), so the curves actually move (8.6 -> ~24 dB).
+
+What can be asked of such a comparison was measured first (scripts/dev/curve_probe.py): this training loop amplifies rounding
+noise -- Adam with eps = 1e-15 turns a gradient entry of noise magnitude into a full +-lr step, so after ONE step two fp32 executions
+differ by 2 lr in some weights -- and after ~30 steps the per-batch PSNR of the restatement's own twins A / A' is 0.05 dB apart, after 50
+steps +-0.5 ... 1.5 dB (the curve itself fluctuates by +-1 dB from batch to batch).  "Within 0.1 dB at every one of 200 steps" is therefore
+not a property any two fp32 runs of the reference have, the reference on two different GPUs included.  The bars:
+  1. while the trajectories are still comparable (steps 0..24) the production PSNR is within 0.1 dB of A at every step (measured 4e-4 dB
+     at step 20) and the loss within 1e-3 relative;
+  2. over the whole run the production curve is no further from A than A's own rounding-noise twins are: RMS PSNR difference over steps
+     50..199 <= 1.5 x the twins' + 0.1 dB, and the mean PSNR of the last 50 steps within 0.1 dB + 2 x the twins' spread of that mean
+     (at least 0.5 dB: the resolution of a 50-step mean of a curve that moves by +-1 dB per batch);
+  3. the held-out PSNR (4096 fresh rays, the library's eval renderer) of the production-trained weights lies within the same envelope
+     around the restatement-trained ones (at least 1 dB: one evaluation of one set of final weights)."""
 import math
 
 import pytest
@@ -71,11 +84,14 @@ def test_200_step_curves_production_path_vs_restatement():
     opt_h = FusedAdam(net, lr=LR, eps=1e-15)
     eng = net._engine_for(dev)
     assert eng.train_forward_bf16x3 and eng.sdf_backward_bf16x3 and eng.wgrad_bf16x3 and eng.rgb_bf16x3 and eng.sdf_forward_bf16x3
-    # ---- restatement side (eager ROCm ops)
-    leaves = {k: torch.nn.Parameter(v.clone().to(dev)) for k, v in sd0.items()}
-    opt_o = torch.optim.Adam(list(leaves.values()), lr=LR, eps=1e-15)
+    # ---- restatement side (eager ROCm ops): A from the same weights, two twins from weights with fp32 rounding noise
+    gN = torch.Generator().manual_seed(99)
+    inits = [sd0] + [{k: v * (1 + 1e-7 * torch.randn(v.shape, generator=gN)) for k, v in sd0.items()} for _ in range(2)]
+    leaves = [{k: torch.nn.Parameter(v.clone().to(dev)) for k, v in sd.items()} for sd in inits]
+    opts = [torch.optim.Adam(list(lv.values()), lr=LR, eps=1e-15) for lv in leaves]
 
-    psnr_h, psnr_o, loss_h, loss_o, it_h = [], [], [], [], []
+    psnr_h, loss_h, it_h = [], [], []
+    psnr_o, loss_o = [[] for _ in leaves], [[] for _ in leaves]
     for step in range(STEPS):
         inp, gt = _batch(step, dev)
         draws = eng.training_draws(B, 7_000_000 + step, dev, net.scene_bounding_sphere, want_eik=True)        # the fused draws kernel
@@ -87,34 +103,47 @@ def test_200_step_curves_production_path_vs_restatement():
         psnr_h.append(float(orc.get_psnr(out["rgb_values"].detach(), gt["rgb"])))
         loss_h.append(float(losses["loss"].detach()))
         it_h.append(int(net.last_sampler_iters.item()))
-
         dr = orc.Draws(strat_u=draws["strat_u"], cdf_u=draws["cdf_u"], extra_idx=draws["extra_idx"], eik_idx=draws["eik_idx"],
                        eik_pts=draws["eik_pts"], nbr_off=draws["nbr_off"])
-        cur = {k: p.detach() for k, p in leaves.items()}
-        o_out, o_losses, grads = orc.training_step_grads(cur, ocfg, inp, gt, lc, dr, step=step)
-        opt_o.zero_grad(set_to_none=True)
-        for k, p in leaves.items():
-            p.grad = grads[k].reshape(p.shape).clone()
-        opt_o.step()
-        psnr_o.append(float(orc.get_psnr(o_out["rgb_values"].detach(), gt["rgb"])))
-        loss_o.append(float(o_losses["loss"].detach()))
+        for r, (lv, opt) in enumerate(zip(leaves, opts)):
+            cur = {k: p.detach() for k, p in lv.items()}
+            o_out, o_losses, grads = orc.training_step_grads(cur, ocfg, inp, gt, lc, dr, step=step)
+            opt.zero_grad(set_to_none=True)
+            for k, p in lv.items():
+                p.grad = grads[k].reshape(p.shape).clone()
+            opt.step()
+            psnr_o[r].append(float(orc.get_psnr(o_out["rgb_values"].detach(), gt["rgb"])))
+            loss_o[r].append(float(o_losses["loss"].detach()))
 
-    dps = max(abs(a - b) for a, b in zip(psnr_o, psnr_h))
-    dl = max(abs(a - b) / abs(a) for a, b in zip(loss_o, loss_h))
-    print(f"PSNR restatement {psnr_o[0]:.3f} -> {psnr_o[-1]:.3f} dB, production {psnr_h[0]:.3f} -> {psnr_h[-1]:.3f} dB, max |dPSNR| over {STEPS} steps "
-          f"{dps:.2e} dB; loss {loss_o[0]:.4f} -> {loss_o[-1]:.4f}, max rel diff {dl:.2e}; sampler iterations seen {sorted(set(it_h))}")
-    assert psnr_o[-1] - psnr_o[0] > 1.0, "the run must actually train (PSNR should rise by more than 1 dB)"
-    assert dps < 0.1, [(i, a, b) for i, (a, b) in enumerate(zip(psnr_o, psnr_h)) if abs(a - b) >= 0.1][:5]
-    assert dl < 1e-2, [(i, a, b) for i, (a, b) in enumerate(zip(loss_o, loss_h)) if abs(a - b) / abs(a) >= 1e-2][:5]
+    A = psnr_o[0]
+    rms = lambda x, y, lo=50: math.sqrt(sum((a - b) ** 2 for a, b in zip(x[lo:], y[lo:])) / len(x[lo:]))
+    tail = lambda x: sum(x[-50:]) / 50.0
+    early = max(abs(a - b) for a, b in zip(A[:25], psnr_h[:25]))
+    early_loss = max(abs(a - b) / abs(a) for a, b in zip(loss_o[0][:25], loss_h[:25]))
+    rms_h, rms_tw = rms(psnr_h, A), max(rms(psnr_o[1], A), rms(psnr_o[2], A))
+    spread_tail = max(abs(tail(psnr_o[1]) - tail(A)), abs(tail(psnr_o[2]) - tail(A)))
+    print(f"PSNR restatement {A[0]:.3f} -> mean of last 50 steps {tail(A):.3f} dB, production {psnr_h[0]:.3f} -> {tail(psnr_h):.3f} dB "
+          f"(twins {tail(psnr_o[1]):.3f}, {tail(psnr_o[2]):.3f}); steps 0..24: max |dPSNR| {early:.2e} dB, max rel loss diff {early_loss:.2e}; "
+          f"steps 50..199: RMS dPSNR production {rms_h:.3f} dB, restatement twins {rms_tw:.3f} dB; sampler iterations seen {sorted(set(it_h))}")
+    assert tail(A) - A[0] > 5.0, "the run must actually train"
+    assert early < 0.1, [(i, a, b) for i, (a, b) in enumerate(zip(A[:25], psnr_h[:25])) if abs(a - b) >= 0.1][:5]
+    assert early_loss < 1e-3, early_loss
+    assert rms_h <= 1.5 * rms_tw + 0.1, (rms_h, rms_tw)
+    # (two twins give a noisy estimate of the spread: the 50-step mean of a curve that moves by +-1 dB per batch has a standard error of
+    # ~0.15 dB, so differences below 0.5 dB between two runs are not distinguishable from the twins' own)
+    assert abs(tail(psnr_h) - tail(A)) <= max(0.1 + 2.0 * spread_tail, 0.5), (tail(psnr_h), tail(A), spread_tail)
 
-    # ---- held-out PSNR of the two trained weight sets, both rendered by the library's eval path (same renderer, different weights)
-    ref_net = I2SDFNetwork(conf)
-    ref_net.load_state_dict({k: p.detach().cpu() for k, p in leaves.items()})
-    ref_net = ref_net.to(dev).eval()
+    # ---- held-out PSNR of the trained weight sets, all rendered by the library's eval path (same renderer, different weights)
     net.eval()
     vin, vgt = _batch(10_000, dev, B=4096)
+    held = []
     with torch.no_grad():
         pa = float(orc.get_psnr(net(vin)["rgb_values"], vgt["rgb"]))
-        pb = float(orc.get_psnr(ref_net(vin)["rgb_values"], vgt["rgb"]))
-    print(f"held-out PSNR (4096 rays): production-trained {pa:.3f} dB, restatement-trained {pb:.3f} dB")
-    assert math.isfinite(pa) and abs(pa - pb) < 0.1, (pa, pb)
+        for lv in leaves:
+            ref_net = I2SDFNetwork(conf)
+            ref_net.load_state_dict({k: p.detach().cpu() for k, p in lv.items()})
+            ref_net = ref_net.to(dev).eval()
+            held.append(float(orc.get_psnr(ref_net(vin)["rgb_values"], vgt["rgb"])))
+    spread_held = max(abs(held[1] - held[0]), abs(held[2] - held[0]))
+    print(f"held-out PSNR (4096 rays): production-trained {pa:.3f} dB, restatement-trained {held[0]:.3f} dB (twins {held[1]:.3f}, {held[2]:.3f})")
+    assert math.isfinite(pa) and abs(pa - held[0]) <= max(0.1 + 2.0 * spread_held, 1.0), (pa, held)
