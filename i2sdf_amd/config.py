@@ -116,6 +116,24 @@ class NetConfig:
                             N_samples_eval=int(_get(rs, "N_samples_eval")), N_samples_extra=int(_get(rs, "N_samples_extra")),
                             eps=float(_get(rs, "eps")), beta_iters=int(_get(rs, "beta_iters")),
                             max_total_iters=int(_get(rs, "max_total_iters")), add_tiny=float(_get(rs, "add_tiny", 0.0)))
+        # --- what the kernels are instantiated for (csrc): anything else is refused HERE, with the reason, not at the first launch
+        if not ((hid[0] == 256 and fvs == 256 and rhid[0] == 256) or (hid[0] == 64 and fvs == 64 and rhid[0] == 64)):
+            raise NotImplementedError(
+                f"hidden width {hid[0]} / feature size {fvs} / radiance width {rhid[0]}: the MLP kernels are instantiated for 256/256/256 "
+                "(synthetic.yml, synthetic_light_mask.yml: bf16x3 and fp32 MFMA) and 64/64/64 (plumbing size, fp32 MFMA) only -- one wave holds "
+                "a whole layer's accumulators in registers (2 x width/32 x 16 of 512), which 512-wide layers do not fit; add an "
+                "instantiation in csrc/mlp_*.hip and csrc/plan.cpp for another width")
+        if len(set(rhid)) != 1:
+            raise NotImplementedError("radiance hidden widths must be uniform")
+        if multires != 6 or (mr_v not in (0, 4)):
+            raise NotImplementedError(f"positional encodings are instantiated for multires 6 (SDF net) and 4 (view directions); got {multires} / {mr_v}")
+        if sam.N_samples_eval > 128 or sam.N_samples > 128 or sam.N_samples_eval * sam.max_total_iters > 640 or sam.max_total_iters > 12 \
+                or sam.N_samples + sam.N_samples_extra + 2 > 256:
+            raise NotImplementedError(
+                f"ray_sampler N_samples_eval={sam.N_samples_eval}, N_samples={sam.N_samples}, N_samples_extra={sam.N_samples_extra}, "
+                f"max_total_iters={sam.max_total_iters}: the sampler kernels hold a ray's row in the registers of one wave, compiled for at most "
+                "128 new samples per iteration, rows of N_samples_eval * max_total_iters <= 640 depths and N_samples + N_samples_extra + 2 <= 256 "
+                "output depths (csrc/sampler.hip: NNEW, NMAX; the shipped configs use 128 / 64 / 32 / 5)")
         dens = _get(conf, "density")
         return NetConfig(feature_size=fvs, sdf=sdf, rgb=rgb, light=light, sampler=sam,
                          scene_bounding_sphere=float(_get(conf, "scene_bounding_sphere", 1.0)),

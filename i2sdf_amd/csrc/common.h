@@ -55,28 +55,33 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // Weight stream: linear walk over a packed buffer, global -> LDS by DMA, double buffered.
 // ---------------------------------------------------------------------------------------------
 struct WStream {
-  const float* g;     // next stage to fetch
+  // The DMA is `buffer_load_dwordx4 ... lds` (address = descriptor base + scalar byte offset + per-lane offset tid*16), not
+  // `global_load_lds`: hipcc counts the global form as a FLAT access (it may touch LDS out of order), and while one is pending every
+  // wait for an LDS READ result becomes s_waitcnt lgkmcnt(0) -- also for reads issued a few cycles earlier, so the read-ahead of the
+  // MFMA loops was worth nothing.  Behind the buffer form the waits carry exact counts (lgkmcnt(2), (4) ...).
+  __amdgpu_buffer_rsrc_t rs;   // the packed stream this kernel walks, from its first stage
+  unsigned goff;      // byte offset (from the descriptor base) of the next stage to fetch
   float* lds;         // two STAGE_FLOATS buffers
   int cur;            // buffer that the NEXT advance() returns
   int left;           // stages still to be fetched
-  int wv;             // this wave's index in the workgroup as a scalar (issue_piece: M0 is computed on the scalar unit)
+  int wv;             // this wave's index in the workgroup as a scalar (M0, the LDS address of a piece, is computed on the scalar unit)
 
+  __device__ __forceinline__ void piece(float* dst_stage, unsigned stage_off, int i, int tid) {
+    float* d = dst_stage + wv * 256 + i * WG_THREADS * 4;     // wave-uniform LDS base; the hardware adds lane*16 B
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16, tid * 16, stage_off + i * (WG_THREADS * 16), 0, 0);
+  }
   __device__ __forceinline__ void issue(float* dst, int tid) {
-    const float* src = g + tid * 4;
-    float* d = dst + (tid & ~63) * 4;     // wave-uniform LDS base; hardware adds lane*16 B
 #ifdef I2SDF_ABL_NODMA
-    g += STAGE_FLOATS; (void)src; (void)d; return;
+    goff += STAGE_FLOATS * 4; (void)dst; return;
 #endif
 #pragma unroll
-    for (int i = 0; i < STAGE_FLOATS / (WG_THREADS * 4); ++i) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * WG_THREADS * 4),
-                                       (__attribute__((address_space(3))) void*)(d + i * WG_THREADS * 4), 16, 0, 0);
-    }
-    g += STAGE_FLOATS;
+    for (int i = 0; i < STAGE_FLOATS / (WG_THREADS * 4); ++i) piece(dst, goff, i, tid);
+    goff += STAGE_FLOATS * 4;
   }
   // n_stages = total stages this kernel will consume from `base`
   __device__ __forceinline__ void begin(const float* base, float* lds_, int n_stages, int tid) {
-    g = base; lds = lds_; cur = 0; left = n_stages;
+    rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7ffffff0, 0x00020000);
+    goff = 0u; lds = lds_; cur = 0; left = n_stages;
     wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (left > 0) { issue(lds, tid); --left; }
   }
@@ -103,13 +108,10 @@ struct WStream {
   // scheduling fences (sched_barrier) that deal the VALU work into the MFMA shadows only act inside one block.  When no stage is left
   // the piece re-reads the stage fetched last (valid memory) into the buffer nobody reads any more.
   __device__ __forceinline__ void issue_piece(int i, int tid) {
-    const float* gs = left > 0 ? g : g - STAGE_FLOATS;
-    const float* src = gs + tid * 4 + i * WG_THREADS * 4;
-    float* d = lds + (cur ^ 1) * STAGE_FLOATS + wv * 256 + i * WG_THREADS * 4;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    piece(lds + (cur ^ 1) * STAGE_FLOATS, left > 0 ? goff : goff - STAGE_FLOATS * 4u, i, tid);
   }
   __device__ __forceinline__ void advance_done() {
-    if (left > 0) { g += STAGE_FLOATS; --left; }
+    if (left > 0) { goff += STAGE_FLOATS * 4; --left; }
     cur ^= 1;
   }
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)

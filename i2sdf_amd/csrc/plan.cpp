@@ -284,6 +284,16 @@ void assign_scales_and_wgrad(i2sdf_plan* p, NetPlan& np, int kind) {
 
 extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
   if (!desc || !out) return I2SDF_EINVAL;
+  {  // shapes the kernels are instantiated for: refuse anything else here, with the reason (i2sdf_last_hip_error), not at the first launch
+    const int H = desc->sdf.hidden, Hr = desc->rgb.hidden, F = desc->rgb.n_lin > 0 ? desc->rgb.in0 - (desc->rgb.multires > 0 ? 3 + 6 * desc->rgb.multires : 3) : 0;
+    const bool ok = (H == 256 && Hr == 256 && F == 256) || (H == 64 && Hr == 64 && F == 64);
+    if (!ok || desc->sdf.multires != 6 || (desc->rgb.multires != 4 && desc->rgb.multires != 0)) {
+      g_hip_err = "i2sdf_plan_create: SDF width " + std::to_string(H) + " / radiance width " + std::to_string(Hr) + " / feature size " + std::to_string(F) +
+                  " / multires " + std::to_string(desc->sdf.multires) + "," + std::to_string(desc->rgb.multires) +
+                  ": the MLP kernels are instantiated for 256/256/256 and 64/64/64 with multires 6 (points) and 4 (view directions) only";
+      return I2SDF_EINVAL;
+    }
+  }
   i2sdf_plan* p = new i2sdf_plan();
   p->desc = *desc;
   p->sdf.d = desc->sdf; p->rgb.d = desc->rgb; p->light.d = desc->light;

@@ -31,6 +31,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
 #define X3_AHEAD 1
 #define X3_RING 2
+#ifndef X3_ORDER
+#define X3_ORDER 0      // (needs X3_DEFER and X3_DMA_SPREAD) DMA piece + first MFMA pair in front of the group's LDS reads: measured +0.05 ms with the buffer-form DMA (exact lgkmcnt waits make it moot), kept for A/B runs
+#endif
 #ifndef X3_DMA_SPREAD
 #define X3_DMA_SPREAD 1 // the weight DMA of the following stage as one piece per MFMA group (WStream::issue_piece) instead of one burst
 #endif
@@ -169,11 +172,34 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         const int w = (s * SC + 2 * jp - NB) / 2;
         const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
         const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
+        const u32x4 (&b)[3] = bq[kc & 1];
+#if X3_ORDER
+        // Order inside a group: [DMA piece, first MFMA pair] | [LDS reads of the group two ahead, second MFMA pair, B preparation].
+        // hipcc follows an LDS-DMA instruction with s_waitcnt lgkmcnt(0) at the next use of ANY ds_read result; with the reads of this
+        // group issued in front of it, that wait covered reads a few cycles old (a full LDS latency exposed every other group).  Behind
+        // the first pair, the only reads it can still wait for are a whole group old.
+        if (npiece < WStream::NPIECE) { ws.issue_piece(npiece, tid); ++npiece; }
+        acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
+        acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
+        __builtin_amdgcn_sched_barrier(0);
         if (jp + PFP < p1) {
           ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
           ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
         }
-        const u32x4 (&b)[3] = bq[kc & 1];
+        if (sp < 2) {
+          acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
+          acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
+        }
+        if (sp == 0) { d0 = a0; d1 = a1; }
+        if (sp == 2) {
+          acc[nt] = mfma_bf16(d0, b[2], acc[nt]);
+          acc[nt + 1] = mfma_bf16(d1, b[2], acc[nt + 1]);
+        }
+#else
+        if (jp + PFP < p1) {
+          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
+          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
+        }
         acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
         acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
         if (sp < 2) {
@@ -200,6 +226,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         if (npiece < WStream::NPIECE) { ws.issue_piece(npiece, tid); ++npiece; }       // next stage's DMA: one piece per group
 #else
         if (!issued) { ws.advance_issue(tid); issued = true; }
+#endif
 #endif
         {
           const int pi = w % PPK;

@@ -178,7 +178,7 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         lib = load()
         msg = lib.i2sdf_strerror(rc).decode()
-        if rc == -2:
+        if rc == -2 or (rc == -1 and what == "i2sdf_plan_create"):      # (plan creation leaves the reason of a refused shape there)
             msg += ": " + lib.i2sdf_last_hip_error().decode()
         if rc == -5:
             msg += ": " + lib.i2sdf_last_comm_error().decode()

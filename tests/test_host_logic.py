@@ -102,3 +102,24 @@ def test_loss_module_has_no_cpu_path():
     out = {"rgb_values": torch.rand(4, 3), "depth_values": torch.rand(4), "weight_sum": torch.rand(4, 1)}
     with pytest.raises(RuntimeError, match="no eager-torch or CPU fallback"):
         lf(out, {"rgb": torch.rand(4, 3)}, 0)
+
+
+def test_unsupported_shapes_are_refused_at_construction_with_the_reason():
+    """Widths / sampler capacities the kernels are not instantiated for raise when the config is read, not at the first launch."""
+    import copy
+    import pytest
+    from i2sdf_amd.config import NetConfig, synthetic_conf
+    for mutate, needle in (
+            (lambda c: c["implicit_network"].update(dims=[128] * 8), "hidden width 128"),
+            (lambda c: c["implicit_network"].update(dims=[512] * 8), "hidden width 512"),
+            (lambda c: c["rendering_network"].update(dims=[128] * 4), "radiance width 128"),
+            (lambda c: c["ray_sampler"].update(N_samples_eval=256), "N_samples_eval=256"),
+            (lambda c: c["ray_sampler"].update(max_total_iters=8), "max_total_iters=8"),
+            (lambda c: c["implicit_network"].update(multires=10), "multires")):
+        conf = copy.deepcopy(synthetic_conf())
+        mutate(conf)
+        with pytest.raises(NotImplementedError) as e:
+            NetConfig.from_conf(conf)
+        assert needle in str(e.value), (needle, str(e.value))
+    NetConfig.from_conf(synthetic_conf())          # the shipped shapes pass
+    NetConfig.from_conf(synthetic_conf(True))
