@@ -450,7 +450,7 @@ def main():
             # per launch from the PMC passes (kernels serialised there, so `us` is the kernel running alone)
             hb = {}
             for k, v in live.items():
-                short = k.split("(")[0].split("::")[-1].split("<")[0].strip()
+                short = _short(k)
                 if any(q in short for q in ("composite_", "sampler_", "beta_reduce", "raygen", "loss_", "draws_")) and v.get("us", 0) > 0:
                     e = hb.setdefault(short, {"bytes": 0.0, "us": 0.0, "launches_per_step": 0.0})
                     e["bytes"] += (v["fetch"] + v["write"]) * v["n"]; e["us"] += v["us"] * v["n"]; e["launches_per_step"] += v["n"]
@@ -460,7 +460,7 @@ def main():
             result["kernels_hbm_note"] = ("1024 rays are 256 workgroups of four rays: these kernels are latency-bound (one round of short workgroups), "
                                           "not bandwidth-bound; together they are < 2 % of the step")
             big = sorted(((v["us"] * v["n"], k, v) for k, v in live.items() if v.get("clock_ghz")), reverse=True)[:6]
-            result["clocks_ghz"] = {k.split("(")[0].split("::")[-1].split("<")[0].strip(): round(v["clock_ghz"], 3) for _, k, v in big}
+            result["clocks_ghz"] = {_short(k): round(v["clock_ghz"], 3) for _, k, v in big}
             result["step_hbm_bytes"] = round(sum((v["fetch"] + v["write"]) * v.get("n", 0.0) for v in live.values()))
         if weak is not None and strong is not None:
             Bs = strong["rays_per_gpu"]
@@ -544,6 +544,14 @@ def live_traffic(args):
         return out or None
     except Exception:
         return None
+
+
+def _short(kernel_name):
+    """'void (anonymous namespace)::sdf_fwd3_kernel<256, 6>(float const*, ...)' -> 'sdf_fwd3_kernel'"""
+    import re
+    m = re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:<[^()]*>)?\s*\(", kernel_name)
+    m = [x for x in m if x not in ("void", "anonymous", "namespace")]
+    return m[0] if m else kernel_name[:40]
 
 
 def entry_traffic(live, entry):

@@ -59,27 +59,33 @@ __global__ __launch_bounds__(256) void draws_kernel(DrawArgs a) {
     for (int i = 0; i < 4; ++i)
       if (4 * t + i < a.B) a.eik_idx[4 * t + i] = (int32_t)(((unsigned long long)v[i] * (unsigned)a.n_z) >> 32);
   }
-  // row t: n_extra distinct columns of [0, n_eval*(t+1)), random order.  One thread per row (the chain is sequential), the row is
-  // kept in LDS while it grows (global round trips per duplicate check would make this thread the kernel's critical path)
-  __shared__ int32_t s_row[MAX_EXTRA_ROWS][MAX_EXTRA];
-  if (a.extra_idx != nullptr && t < a.max_iters) {
-    const unsigned n = (unsigned)a.n_eval * (unsigned)(t + 1);
-    int32_t* row = s_row[t];
-    unsigned ctr = 0;
-    U4 r{};
-    int have = 0;
-    for (int k = 0; k < a.n_extra; ++k) {
-      for (;;) {
-        if (have == 0) { r = philox4x32_10(U4{ctr++, (unsigned)t, 6u, 0u}, a.seed_lo, a.seed_hi); have = 4; }
-        const unsigned x = have == 4 ? r.x : have == 3 ? r.y : have == 2 ? r.z : r.w;
-        --have;
-        const int32_t c = (int32_t)(((unsigned long long)x * n) >> 32);
-        bool dup = false;
-        for (int j = 0; j < k; ++j) dup = dup || (row[j] == c);
-        if (!dup) { row[k] = c; break; }
+  // row r: n_extra distinct columns of [0, n_eval*(r+1)), random order, drawn by rejection.  The chain of a row is sequential, so a row
+  // is given to one WAVE of block 0: every lane runs the same Philox sequence, lane j keeps entries j and j+64 of the row in registers,
+  // and "is the candidate already in the row" is one ballot instead of a loop over the row (one thread per row with the row in LDS took
+  // 60 us -- the longest single item in front of the sampler; the sequence of accepted columns is unchanged).
+  if (a.extra_idx != nullptr && blockIdx.x == 0) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int row = wv; row < a.max_iters; row += 4) {
+      const unsigned n = (unsigned)a.n_eval * (unsigned)(row + 1);
+      unsigned ctr = 0;
+      U4 r{};
+      int have = 0;
+      int32_t mine0 = -1, mine1 = -1;
+      for (int k = 0; k < a.n_extra; ++k) {
+        for (;;) {
+          if (have == 0) { r = philox4x32_10(U4{ctr++, (unsigned)row, 6u, 0u}, a.seed_lo, a.seed_hi); have = 4; }
+          const unsigned x = have == 4 ? r.x : have == 3 ? r.y : have == 2 ? r.z : r.w;
+          --have;
+          const int32_t c = (int32_t)(((unsigned long long)x * n) >> 32);
+          if (__ballot(mine0 == c || mine1 == c) == 0ull) {
+            if ((k & 63) == lane) { if (k < 64) mine0 = c; else mine1 = c; }
+            break;
+          }
+        }
       }
+      if (lane < a.n_extra) a.extra_idx[row * a.n_extra + lane] = mine0;
+      if (lane + 64 < a.n_extra) a.extra_idx[row * a.n_extra + lane + 64] = mine1;
     }
-    for (int k = 0; k < a.n_extra; ++k) a.extra_idx[t * a.n_extra + k] = row[k];
   }
 }
 

@@ -38,7 +38,7 @@ inline int64_t split_bulk_points(int64_t M, int n_cu) {
 //   blocked      [Mp/32][16 k-chunks][32 points][16] row of point m at (m/32)*8192 + (m%32)*16, k-chunk kc at +512*kc
 // The K-outer bf16x3 kernels touch 16 floats of every point per k-chunk: in the point-major layout a wave instruction
 // (16 B per lane) lands in 32 different 1 KB rows, in the blocked layout in one contiguous 2 KB run -- 3.9 vs 5.0 TB/s at the
-// occupancy of these kernels (scripts/dev/layout_bench2.hip).  I2SDF_OPT_BLOCKED_SAVES stores the points handled by the bf16x3
+// occupancy of these kernels (a pure access-pattern microbenchmark, round 2).  I2SDF_OPT_BLOCKED_SAVES stores the points handled by the bf16x3
 // full workgroups blocked; the fp32 split-K tail workgroups (the points behind them) and the fp32 kernels keep point-major rows.
 // Both ranges are tile aligned, so one tensor holds both; every producer / consumer derives the blocked prefix from (plan, M).
 constexpr int KCS_PM = 16, KCS_BLK = 512;

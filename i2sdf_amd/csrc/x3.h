@@ -29,8 +29,16 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // global loads of the B-operand sources are issued X3_AHEAD k-chunks before their use (ring of X3_RING register slots):
 // measured: a distance of 1 is enough (3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
 // STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
+#ifndef X3_AHEAD
 #define X3_AHEAD 1
 #define X3_RING 2
+#endif
+#ifndef X3_PIECES_PER_GROUP
+#define X3_PIECES_PER_GROUP 2   // 2: the pieces are out after four groups, so more of a stage's operand loads are issued BEHIND them (X3_COUNTED)
+#endif
+#ifndef X3_COUNTED
+#define X3_COUNTED 1    // (needs X3_DMA_SPREAD) stage barriers wait vmcnt(n) for the DMA pieces only, not for the operand loads issued behind them
+#endif
 #ifndef X3_ORDER
 #define X3_ORDER 0      // (needs X3_DEFER and X3_DMA_SPREAD) DMA piece + first MFMA pair in front of the group's LDS reads: measured +0.05 ms with the buffer-form DMA (exact lgkmcnt waits make it moot), kept for A/B runs
 #endif
@@ -111,13 +119,18 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   float sv[2][8], sx[2][8];
   u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // X3_DEFER: the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
+  int vm_after = 0;                     // X3_COUNTED: VMEM instructions issued behind the last DMA piece of the next stage (compile-time)
+  bool counting = false;
   auto flush = [&]() __attribute__((always_inline)) {
     if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
     if (pk1 >= 0) { src.done(pk1, sv[1], sx[1]); pk1 = -1; }
   };
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
-    if (u == 0 && kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
+    if (u == 0 && kc + X3_AHEAD < KC16) {
+      src.ahead(kc + X3_AHEAD);
+      if (counting) vm_after += Src::nld(kc + X3_AHEAD);      // loads issued behind the last DMA piece of the stage (advance_barrier_n)
+    }
     if (u < 8) v[u] = src.value(kc, u, vx[u]);
     else {
       if (u == 8 && Src::STORES) {
@@ -145,7 +158,13 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
+#if X3_COUNTED
+    // the first barrier of an op follows another op's code: full drain; later ones let the loads issued behind the last piece fly on
+    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier_n((s > 0 && counting) ? vm_after : 0)) + lane;
+    counting = false; vm_after = 0;
+#else
     const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+#endif
     flush();
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
@@ -223,7 +242,12 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         }
 #endif
 #if X3_DMA_SPREAD
-        if (npiece < WStream::NPIECE) { ws.issue_piece(npiece, tid); ++npiece; }       // next stage's DMA: one piece per group
+#pragma unroll
+        for (int q = 0; q < X3_PIECES_PER_GROUP; ++q)
+          if (npiece < WStream::NPIECE) {       // next stage's DMA: X3_PIECES_PER_GROUP pieces per group, from the first group on
+            ws.issue_piece(npiece, tid); ++npiece;
+            if (npiece == WStream::NPIECE) { __builtin_amdgcn_sched_barrier(0); counting = true; vm_after = 0; }      // (no load may be moved in front of the last piece)
+          }
 #else
         if (!issued) { ws.advance_issue(tid); issued = true; }
 #endif
@@ -240,7 +264,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #if X3_DMA_SPREAD
 #pragma unroll
     for (int i = 0; i < WStream::NPIECE; ++i)
-      if (i >= npiece) ws.issue_piece(i, tid);
+      if (i >= npiece) { ws.issue_piece(i, tid); counting = false; }      // pieces issued at the stage end: nothing is behind them
     ws.advance_done();
 #else
     if (!issued) ws.advance_issue(tid);
@@ -273,6 +297,7 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
+  static constexpr int nld(int) { return 0; }    // vector-memory loads ahead(kc) issues for sure (a lower bound: dense_x3g, X3_COUNTED)
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) {
@@ -290,6 +315,7 @@ struct X3FwdSrc {
 template <int NREG>
 struct X3RegSrc {
   static constexpr bool STORES = false;
+  static constexpr int nld(int) { return 0; }
   const float (&r)[NREG];
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
@@ -299,6 +325,7 @@ struct X3RegSrc {
 template <int NT>
 struct X3RevSrc {
   static constexpr bool STORES = true;
+  static constexpr int nld(int) { return 2; }
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
@@ -333,6 +360,7 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
 template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
+  static constexpr int nld(int kc) { return kc < KACC ? 4 : 0; }
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2], aq[X3_RING][2];
@@ -355,6 +383,7 @@ struct X3Sweep1Src {
 template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
+  static constexpr int nld(int) { return TOP ? 6 : 4; }
   const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
@@ -378,6 +407,7 @@ struct X3Sweep2Src {
 // a point-major row in global memory (or zeros) as B operand
 struct X3RowSrc {
   static constexpr bool STORES = false;
+  static constexpr int nld(int) { return 0; }      // (loads only when `on`: a run-time condition, so none are counted)
   const float* row; int hi; bool on;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
@@ -393,6 +423,7 @@ struct X3RowSrc {
 template <int NT>
 struct X3ReluSrc {
   static constexpr bool STORES = true;
+  static constexpr int nld(int) { return 0; }
   const f32x16 (&accP)[NT]; float* rrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) { return relu0(accP[kc >> 1][8 * (kc & 1) + u]); }
@@ -404,6 +435,7 @@ struct X3ReluSrc {
 template <int NPV>
 struct X3PeRowSrc {
   static constexpr bool STORES = false;
+  static constexpr int nld(int kc) { return kc >= NPV ? 2 : 0; }
   const float (&pe)[NPV * 8]; const float* row; int hi;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3_load8(row, kc - NPV, hi, q[kc % X3_RING]); }
@@ -416,6 +448,7 @@ struct X3PeRowSrc {
 template <int NT>
 struct X3MaskSrc {
   static constexpr bool STORES = true;
+  static constexpr int nld(int) { return 2; }
   const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid; int kcs = 16;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) { x3_load8(rrow, kc, hi, q[kc % X3_RING], kcs); }

@@ -129,17 +129,26 @@ class _RenderFn(torch.autograd.Function):
         eng: RenderEngine = st["eng"]
         flat = net._flat
         dev = flat.device
-        gflat = torch.zeros_like(flat)
         M_sdf = fw["M"]
-        sbar = torch.zeros(M_sdf, device=dev)
-        nbar = torch.zeros(M_sdf, 3, device=dev)
+        off_beta = eng.layout.offset("density.beta")
+        want_normal = st["want_normal"]
         n_eik, n_pc = st["n_eik"], st["n_pc"]
-        if n_eik:                              # rows of the extra points (the compositing backward below fills the rays' rows)
+        # No whole-buffer fills: i2sdf_weight_grads writes every entry of the flat gradient except density.beta (accumulated by the
+        # compositing backward), and the compositing backward writes the rays' rows [0, M_main) of sbar / nbar; only the rows of the
+        # extra points are set here (eikonal points carry d loss / d grad, the bubble point cloud d loss / d sdf).
+        gflat = torch.empty_like(flat)
+        gflat[off_beta:].zero_()
+        sbar = torch.empty(M_sdf, device=dev)
+        nbar = torch.empty(M_sdf, 3, device=dev)
+        if M_sdf > M_main:
+            sbar[M_main:].zero_()
+            nbar[M_main:].zero_()
+        if not want_normal:
+            nbar[:M_main].zero_()
+        if n_eik:
             nbar[M_main:M_main + n_eik] = g_eik
         if n_pc:
             sbar[M_main + n_eik:M_main + n_eik + n_pc] = g_surf.reshape(-1)
-        off_beta = eng.layout.offset("density.beta")
-        want_normal = st["want_normal"]
         cb = eng.composite_backward(flat[off_beta:], st["z_all"], fw["sdf"], ctx.rgb, fw["grad"], st["dnorm"], comp["nsum"],
                                     g_rgb, g_depth, g_wsum.reshape(-1), g_normal if want_normal else None,
                                     g_lmask.reshape(-1) if net.use_light else None, beta_grad_accum=gflat[off_beta:],

@@ -1,5 +1,5 @@
 """Where does the production training path leave the restatement's curve?  (tests/test_gpu_training_curve_full.py diagnostics)
-usage: python scripts/dev/curve_probe.py STEPS parts fused_adam(0/1) [rays]"""
+usage: python scripts/ab/curve_probe.py STEPS parts fused_adam(0/1) [rays]"""
 import sys, os
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import torch

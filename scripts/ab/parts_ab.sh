@@ -1,6 +1,6 @@
 #!/bin/bash
 # on the GPU box: step time per configuration, spec = LIB:PARTS[:WEIGHTS[:HWQ]]  (LIB = NEW or an A/B build name, WEIGHTS e.g. 5,3 or -,
-# HWQ = GPU_MAX_HW_QUEUES):  scripts/dev/parts_ab.sh NEW:0 NEW:2 NEW:2:5,3 NEW:4:-:8
+# HWQ = GPU_MAX_HW_QUEUES):  scripts/ab/parts_ab.sh NEW:0 NEW:2 NEW:2:5,3 NEW:4:-:8
 one() { python bench.py --steps ${STEPS:-30} --warmup 5 --rays ${RAYS:-1024} --no-cpu-baseline --no-extras --scaling weak 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.readlines()[-1]); k=d['kernels']

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B build of SEVERAL source files with extra compiler flags:
-#   scripts/dev/variant_build.sh NAME "EXTRA FLAGS" file1.hip file2.hip ...
+#   scripts/ab/variant_build.sh NAME "EXTRA FLAGS" file1.hip file2.hip ...
 # -> i2sdf_amd/lib/ab/libi2sdf_NAME.so (the other objects come from the in-tree build; select with I2SDF_LIB_PATH)
 set -e
 cd "$(dirname "$0")/../../i2sdf_amd/csrc"

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Refresh profiles/: rocprofv3 kernel stats of the default bench command + PMC passes (counters only, separate runs).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r2}
-BARGS="--no-cpu-baseline --no-extras --scaling weak"     # the headline workload only (same kernels as the default command)
+R=${1:-r3}
+BARGS="--no-cpu-baseline --no-extras --scaling weak --windows 1 --profile-steps 0 --no-live-traffic"     # the headline workload only (same kernels and launch shapes as the timed windows of the default command)
 O=gpurun_out/profiles_$R
 mkdir -p $O
 PASSES=${PASSES:-"stats sq fetch write"}      # e.g. PASSES=sq for a quick look at one kernel's issue counters
@@ -34,4 +34,5 @@ for tag in ("sq","fetch","write"):
     for g in glob.glob(f"{O}/{R}_{tag}_counter_collection.csv")+glob.glob(f"{O}/{R}_{tag}_kernel_trace.csv")+glob.glob(f"{O}/{R}_{tag}_agent_info.csv"): os.remove(g)
 for g in glob.glob(f"{O}/{R}_bench_kernel_trace.csv")+glob.glob(f"{O}/{R}_bench_agent_info.csv"): os.remove(g)
 PY
+python -c "import sys; sys.path.insert(0, \".\"); import bench; open(\"$O/${R}_source_hash.txt\", \"w\").write(bench.source_hash() + \"  sha256[:16] over i2sdf_amd/csrc/*.h* *.cpp + include/i2sdf.h at the time of these passes (bench.py: profiled_traffic)\\n\")"
 ls $O

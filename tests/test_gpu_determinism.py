@@ -3,7 +3,7 @@
 Everything in the library is deterministic by construction (no atomics; split-M partials are reduced in a fixed order), so a
 mismatch between two runs on the same inputs means a synchronisation bug.  This test exists because one was found this way:
 hipcc does not reliably drain the LDS-DMA `vmcnt` in front of `s_barrier`, and the weight-gradient kernel read DMA pieces
-that had not landed about once in four launches (scripts/dev/wgrad_race.py)."""
+that had not landed about once in four launches (a repetition stress test, round 1)."""
 import pytest
 import torch
 

@@ -429,7 +429,7 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     """The same training step (identical depths and draws) with every bf16x3 kernel enabled (the default) and with the plain
     fp32-MFMA kernels (`bf16x3: false`): outputs agree to 1e-5, and outputs and all parameter gradients of BOTH are within the 1e-4
     parity bar of the fp64 oracle.  Seeds / batch as chosen here are well conditioned.  Two things make ANY fp32 evaluation (the
-    reference's included, bf16x3 or not) differ from fp64 by 1e-3 on unlucky batches, both measured with scripts/dev/*_probe.py:
+    reference's included, bf16x3 or not) differ from fp64 by 1e-3 on unlucky batches, both measured with one-off probes in round 2:
     a ray whose weighted normal sum nearly cancels, and radiance-net pre-activations within fp32 rounding of zero,
     where the ReLU mask of the backward flips (one point's contribution to a bias gradient appears or disappears).  The
     kernel-level tests in test_gpu_backward.py bound the arithmetic itself."""

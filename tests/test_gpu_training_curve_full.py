@@ -14,7 +14,7 @@ model/network/__init__.py:289-406, PSNR utils/rend_util.py:13-22).
 All runs see identical batches / draws.  The scene is learnable (a shaded sphere: colour a smooth function of the pixel, analytic depth
 and normals), so the curves actually move (8.6 -> ~24 dB).
 
-What can be asked of such a comparison was measured first (scripts/dev/curve_probe.py): this training loop amplifies rounding
+What can be asked of such a comparison was measured first (scripts/ab/curve_probe.py): this training loop amplifies rounding
 noise -- Adam with eps = 1e-15 turns a gradient entry of noise magnitude into a full +-lr step, so after ONE step two fp32 executions
 differ by 2 lr in some weights -- and after ~30 steps the per-batch PSNR of the restatement's own twins A / A' is 0.05 dB apart, after 50
 steps +-0.5 ... 1.5 dB (the curve itself fluctuates by +-1 dB from batch to batch).  "Within 0.1 dB at every one of 200 steps" is therefore
