@@ -65,6 +65,10 @@ struct i2sdf_comm {
 
 extern "C" const char* i2sdf_last_comm_error(void) { return g_comm_err.c_str(); }
 
+// 1 if librccl could be bound in this process (no communicator is created): lets the ranks of a job agree on the transport BEFORE any
+// of them enters the collective ncclCommInitRank, where a rank that cannot follow would leave the others waiting
+extern "C" int32_t i2sdf_comm_available(void) { return rccl().ok ? 1 : 0; }
+
 extern "C" int i2sdf_comm_unique_id(void* out, int64_t out_bytes) {
   if (!out || out_bytes < (int64_t)sizeof(ncclUniqueId)) return I2SDF_EINVAL;
   if (!rccl().ok) { g_comm_err = "librccl.so.1 could not be loaded"; return I2SDF_ECOMM; }

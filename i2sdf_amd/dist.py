@@ -30,7 +30,7 @@ class RcclComm:
     """`i2sdf_comm` of the C ABI: created collectively by all ranks of `group`; the 128-byte unique id travels through the
     torch.distributed group (any backend).  The calling thread's current device must be this rank's GPU."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, init_timeout_s: float = 180.0):
         self._lib = L.load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         # i2sdf_comm_init_rank binds the communicator to the calling thread's CURRENT device: pin it to the module's device, so a
@@ -41,14 +41,31 @@ class RcclComm:
         box = [None]
         if self.rank == 0:
             buf = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES)()
-            L.check(self._lib.i2sdf_comm_unique_id(buf, L.COMM_UNIQUE_ID_BYTES), "i2sdf_comm_unique_id")
-            box[0] = bytes(buf)
+            rc = self._lib.i2sdf_comm_unique_id(buf, L.COMM_UNIQUE_ID_BYTES)
+            box[0] = bytes(buf) if rc == 0 else ("error", self._lib.i2sdf_last_comm_error().decode())
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
+        if not isinstance(box[0], bytes):         # rank 0 could not make the id: EVERY rank stops here, none enters the collective init
+            raise L.I2SDFError(f"i2sdf_comm_unique_id failed on rank 0: {box[0]}")
         uid = (C.c_ubyte * L.COMM_UNIQUE_ID_BYTES).from_buffer_copy(box[0])
         h = C.c_void_p()
-        with torch.cuda.device(self.device):
-            L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
+        # ncclCommInitRank is collective: if a peer never arrives it does not return.  A job that cannot start must FAIL, not hang:
+        import os
+        import threading
+
+        def _abort():
+            print(f"[i2sdf_amd.dist] rank {self.rank}: i2sdf_comm_init_rank did not return within {init_timeout_s} s "
+                  "(a peer rank is missing or RCCL cannot reach it): aborting the process", flush=True)
+            os._exit(3)
+
+        timer = threading.Timer(init_timeout_s, _abort)
+        timer.daemon = True
+        timer.start()
+        try:
+            with torch.cuda.device(self.device):
+                L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
+        finally:
+            timer.cancel()
         self._h = h
         self._ex = L.Exchange()
         L.check(self._lib.i2sdf_comm_as_exchange(self._h, C.byref(self._ex)), "i2sdf_comm_as_exchange")
@@ -137,7 +154,19 @@ def attach_data_parallel(net, group=None, equivalent: bool = False, native=None)
         native = dist.get_backend(group) == "nccl"
     comm = None
     if native:
-        # all ranks must end up on the same transport: create the communicator, then agree on the outcome through the group
+        # all ranks must end up on the same transport.  First agree that RCCL can be bound on EVERY rank -- before anyone enters the
+        # collective init, where a rank that cannot follow would leave the others waiting -- then create the communicator, then agree
+        # on the outcome through the group
+        on_gpu = dist.get_backend(group) == "nccl"
+        avail = torch.tensor([float(L.load().i2sdf_comm_available())], device="cuda" if on_gpu else "cpu")
+        dist.all_reduce(avail, op=dist.ReduceOp.MIN, group=group)
+        if float(avail.item()) < 1.0:
+            if explicit:
+                raise RuntimeError("i2sdf_amd.dist: librccl could not be bound on every rank (i2sdf_comm_available)")
+            import warnings
+            warnings.warn("i2sdf_amd.dist: librccl not loadable on every rank; the gradient mean goes through torch.distributed.all_reduce")
+            native = False
+    if native:
         err = None
         try:
             dev = next((p.device for p in net.parameters() if p.is_cuda), None)

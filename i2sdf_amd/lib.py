@@ -111,6 +111,7 @@ SIGNATURES = {
     "i2sdf_sdf_backward": (C.c_int, [_P] * 6 + [_I64, _I32, _I64, _I64, _I64] + [_P] * 4 + [_I64] + [_P] * 7),
     "i2sdf_wgrad_chunk_points": (_I64, []),
     "i2sdf_weight_grads": (C.c_int, [_P, C.POINTER(TrainBuffers), _P, _P, _I64, _P, _P]),
+    "i2sdf_comm_available": (_I32, []),
     "i2sdf_comm_unique_id": (C.c_int, [_P, _I64]),
     "i2sdf_comm_init_rank": (C.c_int, [_P, _I32, _I32, C.POINTER(_P)]),
     "i2sdf_comm_destroy": (None, [_P]),

@@ -106,7 +106,9 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   layout [Mp/32][16 k-chunks][32 points][16 floats] for the points handled by the bf16x3 full workgroups (point-major for the
  *   rest): a wave instruction of the K-outer kernels then moves one contiguous 2 KB run instead of touching 32 rows 1 KB apart.
  *   Set it before the first i2sdf_sdf_forward_grad of a step and leave it unchanged through i2sdf_weight_grads; the tensors are
- *   opaque to the caller (i2sdf_saved_rows_to_point_major converts a copy for inspection).  Default 0. */
+ *   opaque to the caller (i2sdf_blocked_points below gives the address formula for inspecting a copy).  Plan default 0; the Python
+ *   engine (i2sdf_amd/engine.py) turns it ON for 256-wide nets, so C callers and Python callers see different layouts unless the C
+ *   caller sets the option too. */
 #define I2SDF_OPT_BLOCKED_SAVES 128
 /*   I2SDF_OPT_WGRAD_BF16X2 (needs I2SDF_OPT_WGRAD_BF16X3): the 256x256 weight-gradient blocks split every operand into TWO bf16
  *   terms and accumulate the three leading products a0b0 + a0b1 + a1b0 in fp32: per-product error <= 3 * 2^-18 (1.1e-5), i.e.
@@ -357,6 +359,7 @@ typedef struct i2sdf_exchange {
   int (*allreduce)(void* ctx, void* buf, int64_t n, int32_t dtype, int32_t op, void* stream);
   void* ctx;
 } i2sdf_exchange;
+int32_t i2sdf_comm_available(void);       /* 1 if RCCL could be bound in this process (creates nothing): agree on it across ranks before i2sdf_comm_init_rank */
 int i2sdf_comm_unique_id(void* out, int64_t out_bytes);
 int i2sdf_comm_init_rank(const void* unique_id, int32_t nranks, int32_t rank, i2sdf_comm** out);
 void i2sdf_comm_destroy(i2sdf_comm* comm);
