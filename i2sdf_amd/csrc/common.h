@@ -141,6 +141,10 @@ struct WStream {
 #endif
     return lds + cur * STAGE_FLOATS;
   }
+  // pieces of the X3_EARLY protocol (x3.h): the wait + barrier of advance_barrier_n() on its own, and the buffer the NEXT stage is in
+  // (the one the pieces issued during the current stage are filling)
+  __device__ __forceinline__ void barrier_n(int n_after) { (void)advance_barrier_n(n_after); }
+  __device__ __forceinline__ const float* next_stage() const { return lds + (cur ^ 1) * STAGE_FLOATS; }
   __device__ __forceinline__ void advance_issue(int tid) {
     if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
     cur ^= 1;

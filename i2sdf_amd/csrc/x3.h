@@ -36,11 +36,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef X3_PIECES_PER_GROUP
 #define X3_PIECES_PER_GROUP 2   // 2: the pieces are out after four groups, so more of a stage's operand loads are issued BEHIND them (X3_COUNTED)
 #endif
+#ifndef X3_EARLY
+#define X3_EARLY 0      // (needs X3_DMA_SPREAD) a stage's barrier taken PFP groups before the previous stage ends, see dense_x3g: measured +0.02 ms (no gain), off
+#endif
 #ifndef X3_COUNTED
 #define X3_COUNTED 1    // (needs X3_DMA_SPREAD) stage barriers wait vmcnt(n) for the DMA pieces only, not for the operand loads issued behind them
-#endif
-#ifndef X3_ORDER
-#define X3_ORDER 0      // (needs X3_DEFER and X3_DMA_SPREAD) DMA piece + first MFMA pair in front of the group's LDS reads: measured +0.05 ms with the buffer-form DMA (exact lgkmcnt waits make it moot), kept for A/B runs
 #endif
 #ifndef X3_DMA_SPREAD
 #define X3_DMA_SPREAD 1 // the weight DMA of the following stage as one piece per MFMA group (WStream::issue_piece) instead of one burst
@@ -156,15 +156,27 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     if (k0 < KC16) src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
+  // pairs [p0, p1) of stage s are weight chunks (the rest: bias chunks in front, padding behind) -- compile-time after unrolling
+  auto first_pair = [](int s) { return (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0; };
+  auto end_pair = [](int s) { return (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2; };
+  u32x4 ring[PFP][2];                   // A operands (one pair of tiles, one split plane) read PFP groups ahead of their MFMAs
+  bool early = false;                   // the barrier of this stage was already taken inside the previous one (X3_EARLY)
+  const u32x4* nxt = nullptr;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
+    const int p0 = first_pair(s), p1 = end_pair(s);
+    const u32x4* cur;
+    if (early) {
+      cur = nxt;                        // barrier taken, first PFP pairs already in `ring`
+    } else {
 #if X3_COUNTED
-    // the first barrier of an op follows another op's code: full drain; later ones let the loads issued behind the last piece fly on
-    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier_n((s > 0 && counting) ? vm_after : 0)) + lane;
-    counting = false; vm_after = 0;
+      // the first barrier of an op follows another op's code: full drain; later ones let the loads issued behind the last piece fly on
+      cur = reinterpret_cast<const u32x4*>(ws.advance_barrier_n((s > 0 && counting) ? vm_after : 0)) + lane;
+      counting = false; vm_after = 0;
 #else
-    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+      cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
 #endif
+    }
     flush();
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
@@ -175,13 +187,21 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
       }
     }
-    const int p0 = (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0;
-    const int p1 = (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2;
-    u32x4 ring[PFP][2];
+    if (!early) {
 #pragma unroll
-    for (int i = 0; i < PFP; ++i)
-      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
+      for (int i = 0; i < PFP; ++i)
+        if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
+    // X3_EARLY: the barrier of stage s+1 is taken PFP groups before stage s ends -- from there on this wave reads no more of stage s's
+    // buffer (the A operands of its last PFP groups are in `ring`), so the first reads of stage s+1 can be issued right behind the
+    // barrier and their LDS latency, like the barrier itself, is covered by the last 4 PFP MFMAs of stage s instead of standing
+    // bare at the head of stage s+1.  Needs: every DMA piece of stage s+1 issued before that point, an even group count (ring slots
+    // line up) and a next stage of the same op with at least PFP groups.
+    const int p0n = s + 1 < NS ? first_pair(s + 1) : 0, p1n = s + 1 < NS ? end_pair(s + 1) : 0;
+    const bool can_early = X3_EARLY && X3_DMA_SPREAD && s + 1 < NS && (p1 - p0) % PFP == 0 && p1n - p0n >= PFP &&
+                           (p1 - p0 - PFP) * X3_PIECES_PER_GROUP >= WStream::NPIECE;
+    early = false;
     bool issued = false;
     int npiece = 0;
     (void)issued; (void)npiece;
@@ -192,32 +212,21 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
         const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
         const u32x4 (&b)[3] = bq[kc & 1];
-#if X3_ORDER
-        // Order inside a group: [DMA piece, first MFMA pair] | [LDS reads of the group two ahead, second MFMA pair, B preparation].
-        // hipcc follows an LDS-DMA instruction with s_waitcnt lgkmcnt(0) at the next use of ANY ds_read result; with the reads of this
-        // group issued in front of it, that wait covered reads a few cycles old (a full LDS latency exposed every other group).  Behind
-        // the first pair, the only reads it can still wait for are a whole group old.
-        if (npiece < WStream::NPIECE) { ws.issue_piece(npiece, tid); ++npiece; }
-        acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
-        acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
-        __builtin_amdgcn_sched_barrier(0);
         if (jp + PFP < p1) {
           ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
           ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
-        }
-        if (sp < 2) {
-          acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
-          acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
-        }
-        if (sp == 0) { d0 = a0; d1 = a1; }
-        if (sp == 2) {
-          acc[nt] = mfma_bf16(d0, b[2], acc[nt]);
-          acc[nt + 1] = mfma_bf16(d1, b[2], acc[nt + 1]);
-        }
-#else
-        if (jp + PFP < p1) {
-          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
-          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
+        } else if (can_early) {
+          if (jp + PFP == p1) {         // first group without a refill from this stage: take the next stage's barrier now
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's last reads of the buffer about to be recycled have returned
+            ws.barrier_n(counting ? vm_after : 0);
+            counting = false; vm_after = 0;
+            nxt = reinterpret_cast<const u32x4*>(ws.next_stage()) + lane;
+            early = true;
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const int i2 = jp + PFP - p1;              // pair i2 of the next stage goes into the slot this group has just emptied
+          ring[(jp - p0) % PFP][0] = nxt[(2 * (p0n + i2)) * 64];
+          ring[(jp - p0) % PFP][1] = nxt[(2 * (p0n + i2) + 1) * 64];
         }
         acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
         acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
@@ -250,7 +259,6 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
           }
 #else
         if (!issued) { ws.advance_issue(tid); issued = true; }
-#endif
 #endif
         {
           const int pi = w % PPK;

@@ -33,7 +33,8 @@ def train_case(name, light, B, k):
     net.force_iters = k
     loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05,
                         light_mask_weight=0.5 if light else 0.0)
-    opt = torch.optim.Adam(net.get_param_groups(5e-4), eps=1e-15)
+    from i2sdf_amd import FusedAdam
+    opt = FusedAdam(net, lr=5e-4, eps=1e-15)              # the production optimizer (one launch), as bench.py
     inp, gt = cam_batch(B, dev)
 
     def step(i):
@@ -93,7 +94,8 @@ def dense128():
     with torch.no_grad():
         net.density.beta.fill_(0.02)
     loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
-    opt = torch.optim.Adam(net.get_param_groups(5e-4), eps=1e-15)
+    from i2sdf_amd import FusedAdam
+    opt = FusedAdam(net, lr=5e-4, eps=1e-15)              # the production optimizer (one launch), as bench.py
     B, n = 1024, 128
     inp, gt = cam_batch(B, dev)
     eng = net._engine_for(dev)
