@@ -155,8 +155,9 @@ def relu_flip_analysis(grads_fn, tau=1e-6, max_candidates=64):
     grads_fn() -> {name: grad} runs the fp32 oracle's training step (bitwise the reference's arithmetic, see
     test_oracle_vs_reference.py).  The derivative of relu at a pre-activation of +-1e-7 is 1 or 0 depending on the sign rounding
     noise left behind, so two correct fp32 evaluations (the reference's and any other) can legitimately differ by exactly such
-    flips; each flip changes the gradient by a fixed, computable vector.  Returns (candidates, deltas): candidates = list of
-    (layer, point, unit, pre_activation); deltas[i] = {name: grad with candidate i's mask flipped  -  base grad}."""
+    flips; each flip changes the gradient by a fixed, computable vector.  Returns (base, candidates, deltas): candidates = list of
+    (layer, point, unit, pre_activation); deltas[i] = {name: grad with candidate i's mask flipped  -  base grad}.
+    relu_flip_analysis.pre holds the oracle's pre-activations {layer: (points, units)} of the last call (hip_mask_flips below)."""
     rec = {}
 
     def record(a, l):
@@ -165,6 +166,7 @@ def relu_flip_analysis(grads_fn, tau=1e-6, max_candidates=64):
 
     with orc.relu_hook(record):
         base = grads_fn()
+    relu_flip_analysis.pre = dict(rec)
     cands = []
     for l, a in rec.items():
         idx = (a.abs() < tau).nonzero()
@@ -185,6 +187,22 @@ def relu_flip_analysis(grads_fn, tau=1e-6, max_candidates=64):
             g = grads_fn()
         deltas.append({k: g[k] - base[k] for k in base})
     return base, cands, deltas
+
+
+def hip_mask_flips(rs_point_major, pre, tau=1e-6):
+    """Which backward masks does the HIP path REALLY have differently from the fp32 oracle run?  rs_point_major: the library's saved
+    post-ReLU activations of the radiance net, (layers, points, units) in point-major order (relu(a) > 0 is the mask its backward
+    uses); pre: the oracle's pre-activations {layer: (points, units)}.  Returns (flips = set of (layer, point, unit) with different
+    masks, worst = the largest |oracle pre-activation| among them): a mask may only differ where rounding decides it."""
+    flips, worst = set(), 0.0
+    for l, a in pre.items():
+        a = a.detach().cpu()
+        hip = rs_point_major[l][: a.shape[0], : a.shape[1]].cpu() > 0
+        diff = (hip != (a > 0)).nonzero()
+        for m, u in diff.tolist():
+            flips.add((l, m, u))
+            worst = max(worst, abs(float(a[m, u])))
+    return flips, worst
 
 
 def explain_by_relu_flips(err, deltas, scale, max_flips=4):

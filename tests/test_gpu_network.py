@@ -349,6 +349,18 @@ def test_full_width_train_step_vs_reference_golden(golden, name, light):
         if r > tol:
             bad.append((n_, r, tol))
     assert len(chosen) <= 4 and not bad, (chosen, bad)
+    # ---- the explanation must be what the HIP path really did, not just a combination that happens to fit: read the library's own
+    # saved radiance activations back (relu(a) > 0 is the mask its backward used) and compare mask by mask with the fp32 oracle run --
+    # (i) masks differ ONLY at units whose pre-activation is zero within rounding, (ii) every flip the greedy search chose is one of them
+    from helpers import hip_mask_flips
+    node = out["rgb_values"].grad_fn                     # the autograd node of the render core keeps the saved tensors it used
+    M_main = node.M_main
+    rs_pm = eng.saved_to_point_major(node.rs, eng.blocked_points(1, M_main, node.rs.shape[1]))[:, :M_main]
+    flips, worst = hip_mask_flips(rs_pm, relu_flip_analysis.pre)
+    print(f"ReLU backward masks that differ between the HIP path and the fp32 oracle: {sorted(flips)} (largest |pre-activation| among them {worst:.1e})")
+    assert worst < 1e-6, f"a backward mask differs at a unit whose pre-activation is {worst:.2e}: not a rounding-level flip"
+    for i in chosen:
+        assert (cands[i][0], cands[i][1], cands[i][2]) in flips, f"flip {cands[i]} explains the gradient difference but the HIP mask of that unit equals the oracle's"
 
 
 def test_full_width_eval_vs_reference_golden(golden):
