@@ -133,3 +133,29 @@ def test_point_ranges_change_nothing():
         cur = run(chain)
         for k in cur:
             assert torch.equal(cur[k], ref[k]), f"{k}: parts={parts} chain={chain} differs from parts=2 ({int((cur[k] != ref[k]).sum())} entries)"
+
+
+def test_chain_protocol_errors():
+    """i2sdf_chain_begin / _end misuse is refused, not silently mis-ordered: chains do not nest, the range count cannot change inside a
+    chain, end without begin is a no-op, and a batch with fewer chunks than ranges simply runs as one launch."""
+    from i2sdf_amd.config import synthetic_conf
+    from i2sdf_amd import lib as L
+    ocfg = orc.synthetic_cfg(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=41), 0.05, seed=42)
+    eng = make_engine(dict(synthetic_conf(False)), sd, parts=2)
+    h, plan, st = L.load(), eng._plan, L.stream_ptr()
+    assert h.i2sdf_chain_end(plan, st) == 0                                   # nothing open: no-op
+    assert h.i2sdf_chain_begin(plan, 50000, st) == 0
+    assert h.i2sdf_chain_begin(plan, 50000, st) == -1                         # no nesting
+    assert h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 3) == -1                # not inside a chain
+    assert h.i2sdf_chain_fence(plan, st) == 0
+    assert h.i2sdf_chain_end(plan, st) == 0
+    assert h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 3) == 0 and h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 2) == 0
+    # a batch smaller than one chunk per range: one launch, same values as without ranges on the points of the full workgroups
+    x = ((torch.rand(1500, 3, generator=torch.Generator().manual_seed(3)) * 2 - 1) * 1.5).cuda()
+    with eng.chain(1500):
+        a = eng.sdf_forward_grad(points=x)
+    eng.set_parts(0)
+    b = eng.sdf_forward_grad(points=x)
+    assert torch.equal(a["sdf"], b["sdf"]) and torch.equal(a["grad"], b["grad"])
+    torch.cuda.synchronize()
