@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the dense128 / natural_k / eager_rocm_baseline sub-records")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to smoke-test the N>1 path)")
+    ap.add_argument("--dp-transport", default="auto", choices=["auto", "library", "torch"],
+                    help="N>1: who carries the gradient all-reduce -- the library's own RCCL communicator (i2sdf_allreduce_grads; auto = this when the "
+                         "backend is nccl, with fallback to torch if it cannot be created on every rank) or torch.distributed.all_reduce")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--fused-adam", type=int, default=1, help="1: i2sdf_amd.FusedAdam (one HIP launch over the flat buffer); 0: torch.optim.Adam")
@@ -154,7 +157,7 @@ class Workload:
         else:
             self.opt = torch.optim.Adam(self.net.get_param_groups(5.0e-4), eps=1e-15)
         if world > 1:
-            i2dist.attach_data_parallel(self.net)
+            i2dist.attach_data_parallel(self.net, native={"auto": None, "library": True, "torch": False}[args.dp_transport])
         self.step_no = 0
 
     def inputs(self, B, seed):

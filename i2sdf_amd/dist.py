@@ -151,7 +151,9 @@ def attach_data_parallel(net, group=None, equivalent: bool = False, native=None)
     world = dist.get_world_size(group)
     explicit = native is True
     if native is None:
-        native = dist.get_backend(group) == "nccl"
+        # I2SDF_DP_TRANSPORT=torch keeps the gradient mean on torch.distributed's own communicator (also RCCL under backend nccl)
+        import os
+        native = dist.get_backend(group) == "nccl" and os.environ.get("I2SDF_DP_TRANSPORT", "library") != "torch"
     comm = None
     if native:
         # all ranks must end up on the same transport.  First agree that RCCL can be bound on EVERY rank -- before anyone enters the
