@@ -1,0 +1,47 @@
+"""CPU: the bookkeeping of bench.py that does not need a GPU -- kernel-name shortening, per-entry-point traffic from a PMC table, the
+source-hash stamp that keeps a committed profile from describing other kernels, the bounded CPU-baseline child."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_short_kernel_names():
+    assert bench._short("void (anonymous namespace)::sdf_fwd3_kernel<256, 6>(float const*, int, int, int, i2sdf::PointSpec, int const*, long, float*)") == "sdf_fwd3_kernel"
+    assert bench._short("(anonymous namespace)::composite_fwd_kernel((anonymous namespace)::CompArgs)") == "composite_fwd_kernel"
+    assert bench._short("void (anonymous namespace)::sampler_beta_kernel<4>((anonymous namespace)::SamplerArgs)") == "sampler_beta_kernel"
+    assert bench._short("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"
+
+
+def test_entry_traffic_sums_every_kernel_of_the_entry_point_per_step():
+    live = {"void (anonymous namespace)::wgrad3p_kernel<3>((anonymous namespace)::WgLaunch)": {"fetch": 1000.0, "write": 100.0, "n": 2.0},
+            "(anonymous namespace)::wgrad_narrow_kernel((anonymous namespace)::WgLaunch)": {"fetch": 300.0, "write": 10.0, "n": 2.0},
+            "(anonymous namespace)::wn_backward_kernel(...)": {"fetch": 50.0, "write": 5.0, "n": 1.0},
+            "void (anonymous namespace)::sdf_bwd3_sweep1_kernel<256, 6>(SdfBwdArgs)": {"fetch": 7.0, "write": 7.0, "n": 2.0}}
+    assert bench.entry_traffic(live, "i2sdf_weight_grads") == 2 * 1100 + 2 * 310 + 55
+    assert bench.entry_traffic(live, "i2sdf_sdf_backward") == 28
+    assert bench.entry_traffic(live, "i2sdf_rgb_forward") is None and bench.entry_traffic(None, "i2sdf_weight_grads") is None
+
+
+def test_committed_profile_is_used_only_with_matching_sources():
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    val, src = bench.profiled_traffic("i2sdf_weight_grads")
+    stamp_file = os.path.join(ROOT, "profiles", "r3_source_hash.txt")
+    stamp = open(stamp_file).read().split()[0] if os.path.exists(stamp_file) else None
+    if stamp == h:
+        assert val is not None and val > 1e9 and "profiles/r3_pmc" in src        # GB-scale traffic of the weight gradients
+    else:
+        assert val is None and "other kernel sources" in src                      # stale profile: refused, and it says why
+
+
+def test_cpu_probe_child_reports_a_line_per_step():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-probe", "2,4,1,97"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                       timeout=300, cwd=ROOT)
+    lines = [json.loads(x) for x in r.stdout.decode().splitlines() if x.startswith("{")]
+    assert r.returncode == 0 and len(lines) >= 2 and lines[-1]["threads"] == 2 and lines[-1]["rays"] == 4
+    assert len(lines[-1]["times"]) == len(lines) and all(t > 0 for t in lines[-1]["times"])
