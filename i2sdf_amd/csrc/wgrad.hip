@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
+#ifndef W3_INTERLEAVE
+#define W3_INTERLEAVE 1                  // wgrad3p: lanes of the two 32-lane halves load the two points of one 128-B line (see vnext)
+#endif
 #ifndef W3_PREFETCH
 #define W3_PREFETCH 0                    // stages of L2 prefetch ahead of the operand loads of wgrad3p (0 = off)
 #endif
@@ -316,10 +319,17 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     const float* ubase = blk ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * wb) * 512
                              : (opB ? job.B : job.A) + m_lo * dld + 128 * wb;
     unsigned voff[4];                           // bytes, row 8*kg + 2i; the pair's second row is `vnext` further
+#if W3_INTERLEAVE
+    // the MFMA reduction index is the point, and any point <-> k-slot map will do as long as A and B use the same one: with the two
+    // 32-lane halves taking the two points of a 128-B line (rows 4i + kg and 4i + 2 + kg) every load instruction moves whole lines
+    // instead of half of each of twice as many
+    const unsigned vnext = 2u * 4u * (unsigned)(blk ? 16 : dld);
+#else
     const unsigned vnext = 4u * (unsigned)(blk ? 16 : dld);
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = 8 * kg + 2 * i;
+      const int r = W3_INTERLEAVE ? 4 * i + kg : 8 * kg + 2 * i;
       voff[i] = 4u * (unsigned)(blk ? r * 16 + (i32 >> 2) * 512 + 4 * (i32 & 3) : r * dld + 4 * i32);
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
@@ -350,9 +360,9 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
     auto prep = [&](int s, int i, float lo, float hi_, float& x0, float& x1) __attribute__((always_inline)) {
       if (PLAIN) { x0 = lo; x1 = hi_; return; }
-      const int p0 = s * W3_PTS + 8 * kg + 2 * i;
+      const int p0 = s * W3_PTS + (W3_INTERLEAVE ? 4 * i + kg : 8 * kg + 2 * i);
       x0 = p0 < rows ? fmaxf(lo, relu_lo) : 0.f;
-      x1 = p0 + 1 < rows ? fmaxf(hi_, relu_lo) : 0.f;
+      x1 = p0 + (W3_INTERLEAVE ? 2 : 1) < rows ? fmaxf(hi_, relu_lo) : 0.f;
     };
     auto write_tile = [&](int s, int tt, int p) __attribute__((always_inline)) {
       float* dst = plb + (s & 1) * W3P_PL + w * (4 * 3 * 256) + lane * 4;
