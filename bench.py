@@ -27,8 +27,9 @@ Per-entry-point times (`kernels`, `roofline`): the timed steps run the per-point
 streams (include/i2sdf.h: I2SDF_OPT_PARTS), where an entry point has no duration of its own.  They are therefore measured live in
 a second pass of --profile-steps steps right behind the timed windows, same process, same inputs, with every entry point joining its
 ranges (HIP events on the stream the entry points are given, which then bracket all of an entry point's kernels).
-`roofline.traffic` and `kernels_hbm` (HBM bytes and GB/s of the sampler / compositing kernels) come from two rocprofv3 --pmc passes
-(FETCH_SIZE, WRITE_SIZE: separate runs, counters only) that this script starts itself on a 3-step run of the same workload.
+`roofline.traffic`, `kernels_hbm` (HBM bytes and GB/s of the sampler / compositing kernels) and `kernels_mfma` (matrix-pipe occupancy of the
+MLP kernels) come from three rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters: separate runs, counters only) that this script
+starts itself on a 3-step run of the same workload.
 
 Sub-records of the same JSON line: `dense128` (BASELINE.json's metric convention: 128 shaded samples/ray, sampler bypassed),
 `strong` (fixed global batch of --strong-rays rays split over the ranks), `k1` / `k5` / `natural_k` (sampler iteration count fixed
@@ -465,6 +466,11 @@ def main():
             big = sorted(((v["us"] * v["n"], k, v) for k, v in live.items() if v.get("clock_ghz")), reverse=True)[:6]
             result["clocks_ghz"] = {_short(k): round(v["clock_ghz"], 3) for _, k, v in big}
             result["step_hbm_bytes"] = round(sum((v["fetch"] + v["write"]) * v.get("n", 0.0) for v in live.values()))
+            # north_star: "MFMA utilisation on the MLP GEMMs against gfx950 peak" -- matrix-pipe occupancy of every MFMA kernel from the SQ pass
+            # (kernels serialised; with point ranges a per-point kernel is a half-batch launch, 1.56 rounds of workgroups alone on the chip)
+            result["kernels_mfma"] = {_short(k): {"mfma_busy": round(v["mfma_busy"], 3), "waves_parked": round(v.get("waves_parked", 0.0), 3),
+                                                  "us_per_launch": round(v.get("us", 0.0), 1), "launches_per_step": round(v.get("n", 0.0), 2)}
+                                      for k, v in sorted(live.items(), key=lambda kv: -kv[1].get("us", 0.0) * kv[1].get("n", 0.0)) if v.get("mfma_busy", 0.0) > 0.01}
         if weak is not None and strong is not None:
             Bs = strong["rays_per_gpu"]
             result["strong"] = {"value": round(Bs * world * n_shaded / (strong["dt"] / K), 1), "unit": "ray-samples/s", "scaling": "strong",
@@ -513,7 +519,8 @@ def live_traffic(args):
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            for tag, counters in (("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]), ("write", ["WRITE_SIZE"])):
+            for tag, counters in (("fetch", ["FETCH_SIZE", "GRBM_GUI_ACTIVE"]), ("write", ["WRITE_SIZE"]),
+                                  ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"])):
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc"] + counters + ["-d", d, "-o", tag, "--output-format", "csv", "--", sys.executable,
                        os.path.join(here, "bench.py"), "--pmc-child", "--steps", "2", "--warmup", "1", "--rays", str(args.rays),
                        "--sampler-iters", str(args.sampler_iters), "--fused-adam", str(args.fused_adam), "--bf16x3", str(args.bf16x3)]
@@ -542,8 +549,14 @@ def live_traffic(args):
                         e["n"] = cnt[k] / steps
                         if e["us"] > 0 and a.get("GRBM_GUI_ACTIVE", 0.0) > 0:
                             e["clock_ghz"] = a["GRBM_GUI_ACTIVE"] / cnt[k] / 8.0 / (e["us"] * 1e3)
-                    else:
+                    elif tag == "write":
                         e["write"] = a.get("WRITE_SIZE", 0.0) * 1024.0 / cnt[k]
+                    elif a.get("GRBM_GUI_ACTIVE", 0.0) > 0 and a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) > 0:
+                        # matrix-pipe occupancy: busy cycles summed over the SIMDs / (1024 SIMDs x elapsed cycles); GRBM_GUI_ACTIVE is
+                        # the elapsed cycles summed over the 8 XCDs, so 1024 x cycles = 128 x GRBM_GUI_ACTIVE (PMC tables)
+                        e["mfma_busy"] = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (128.0 * a["GRBM_GUI_ACTIVE"])
+                        if a.get("SQ_WAVE_CYCLES", 0.0) > 0:
+                            e["waves_parked"] = a.get("SQ_WAIT_ANY", 0.0) / a["SQ_WAVE_CYCLES"]
         return out or None
     except Exception:
         return None
