@@ -245,6 +245,19 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
+#ifndef W3_DEEP
+#define W3_DEEP 0                        // wgrad3p: raw rows loaded two stages ahead of their split (two register sets, see rlo / rhi): 32 more
+                                         // VGPRs than the kernel has -> spills whose reloads wait with vmcnt(0); measured 2.2 ms against 1.63 ms
+#endif
+#ifndef W3_KO
+#define W3_KO 0                          // TIMING EXPERIMENTS ONLY (wrong results): knock out 1 epilogue stores, 2 loop loads, 4 split VALU, 8 stage barrier, 16 plane writes
+#endif
+#ifndef W3_TRACE
+#define W3_TRACE 0                       // development: per-workgroup timestamps of wgrad3p into g_w3_trace (i2sdf_debug_w3_trace reads them)
+#endif
+#ifndef W3_ASM_MFMA
+#define W3_ASM_MFMA 1                    // wgrad3p: the MFMA as inline asm with the accumulator tile constrained to AGPRs, see w3_mfma
+#endif
 #ifndef W3_INTERLEAVE
 #define W3_INTERLEAVE 1                  // wgrad3p: lanes of the two 32-lane halves load the two points of one 128-B line (see vnext)
 #endif
@@ -279,14 +292,61 @@ constexpr int W3P_LDS_BYTES = 2 * W3P_PL * 4;
 // sched_barrier(0): the MFMA, one sixth of a split item (2 values -> 3 planes, 11-17 VALU over 6 units; the 16 items of a
 // quarter fill the 96 units exactly) and at most one LDS / global-memory instruction, each well ahead of its consumer.  (Build flags: -fno-slp-vectorize keeps the units' scalar ops from being merged into packed ops at one place,
 // and packed f32 VALU is slow beside MFMAs anyway; the lifted pragma-unroll cap keeps the 96-unit loop unrolled.)
+// The accumulator of wgrad3p is 16 tiles x 16 registers = all 256 AGPRs.  Left to itself the register allocator keeps three of the
+// tiles in VGPRs across the stage loop's back edge and moves each into AGPRs at the head of an iteration and back at its end (48
+// v_accvgpr_write + 48 v_accvgpr_read per two stages, in clusters of 16 to 48 that no MFMA can hide; many more around the last stage
+// and the epilogue -- ISA of the round-2 kernel).  Neither an "a" constraint on the tile (the copies then feed the asm operand)
+// nor naming the physical tuple in the constraint (the allocator spills the tiles to scratch between phases) changes that.  So with
+// W3_ASM_MFMA the accumulator is STATE THE COMPILER DOES NOT SEE: tile (ta, tb) is a[16 k : 16 k + 15], k = ta + 4 tb, zero-filled,
+// accumulated into and read out by inline asm that names the registers itself; every such statement clobbers all 256 AGPRs, so the
+// compiler can keep nothing of its own in them across one (and its VGPR spills go to scratch, not to AGPRs).
+// What the hazard recognizer does not see and this code provides: (1) a tile is the srcC of an MFMA again four MFMAs (128 cycles) after it
+// was written -- more than the 8 passes of the instruction; (2) the epilogue's reads come behind w3_mfma_drain(); (3) the zero fill is
+// separated from the first MFMA by the whole job prologue.  (s_waitcnt for the LDS-loaded A / B operands is the compiler's, as before.)
+#define W3_ALL_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+__device__ __forceinline__ void w3_mfma(int k, f32x16& c, u32x4 a, u32x4 b) {
+#if W3_ASM_MFMA
+  (void)c;                                         // k is a constant after unrolling
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" :: "n"(16 * k), "n"(16 * k + 15), "v"(a), "v"(b) : W3_ALL_AGPRS);
+#else
+  c = mfma_bf16(a, b, c);
+#endif
+}
+#if W3_ASM_MFMA
+__device__ __forceinline__ void w3_acc_zero() {
+  asm volatile(".set w3i, 0\n.rept 256\n\tv_accvgpr_write_b32 a[w3i], 0\n\t.set w3i, w3i+1\n.endr" ::: W3_ALL_AGPRS);
+}
+__device__ __forceinline__ float w3_acc_read(int n) {       // element n & 15 of tile n >> 4
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(n));
+  return x;
+}
+#endif
+__device__ __forceinline__ void w3_mfma_drain() {
+#if W3_ASM_MFMA
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#endif
+}
+#if W3_TRACE
+constexpr int W3_TRACE_MAX = 32768;
+__device__ unsigned long long g_w3_trace[W3_TRACE_MAX * 8];
+__device__ unsigned g_w3_trace_n;
+#define W3_STAMP(k) do { if (tr) tr[k] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define W3_STAMP(k) do { } while (0)
+#endif
 template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
-__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
+__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsigned long long* tr = nullptr) {
   float* plb = lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x + L.chunk0;
+#if W3_ASM_MFMA
+  f32x16 acc_unused;                       // (the tiles are in a[0:255], see w3_mfma)
+  w3_acc_zero();
+#else
   f32x16 acc[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -294,6 +354,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#endif
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 #if W3_PREFETCH > 0
   unsigned pf_sink = 0u;
@@ -334,13 +395,18 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    f32x4 rlo[4], rhi[4];
-    auto gload = [&](int s, int i, int half) __attribute__((always_inline)) {
-      const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches two stages ahead without a branch)
+    // W3_DEEP: TWO register sets of raw rows -- set (s+1)&1 holds the rows of stage s+1 (split during stage s) and is refilled, pair by
+    // pair as it is consumed, with the rows of stage s+3; the other set holds the rows of stage s+2, already on their way for a whole
+    // stage.  Load-to-use distance: two stages (~6 k cycles, 3 us) instead of one; the stage body exists once per set (the set index
+    // must be a compile-time constant: register arrays cannot be indexed dynamically).  Without W3_DEEP: one set, one stage of distance.
+    constexpr int NSET = W3_DEEP ? 2 : 1;
+    f32x4 rlo[NSET][4], rhi[NSET][4];
+    auto gload = [&](int s, int i, int half, int set) __attribute__((always_inline)) {
+      const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches ahead without a branch)
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
-      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
-      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
+      if (half == 0) rlo[set][i] = *reinterpret_cast<const f32x4*>(src);
+      else rhi[set][i] = *reinterpret_cast<const f32x4*>(src + vnext);
     };
 #if W3_PREFETCH > 0
     // L2 prefetch of the raw rows W3_PREFETCH stages ahead: ONE 4-byte load per lane, every lane in a different 128-B line of this
@@ -372,32 +438,37 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       return *reinterpret_cast<const u32x4*>(plb + (s & 1) * W3P_PL + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
     };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { gload(0, i, 0); gload(0, i, 1); }
+    for (int i = 0; i < 4; ++i) { gload(0, i, 0, 0); gload(0, i, 1, 0); }
     __syncthreads();                       // the previous job is done with LDS
 #pragma unroll
     for (int i = 0; i < 4; ++i) {          // stage 0 is split up front
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt) {
         float x0, x1;
-        prep(0, i, rlo[i][tt], rhi[i][tt], x0, x1);
+        prep(0, i, rlo[0][i][tt], rhi[0][i][tt], x0, x1);
         bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
         if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
         else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { gload(1, i, 0); gload(1, i, 1); }
+    for (int i = 0; i < 4; ++i) { gload(1, i, 0, NSET - 1); gload(1, i, 1, NSET - 1); }        // rows(1) -> the set stage 0 consumes
+    if (W3_DEEP) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { gload(2, i, 0, 0); gload(2, i, 1, 0); }                    // rows(2) -> the set stage 1 consumes
+    }
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
       for (int p = 0; p < NPL; ++p) write_tile(0, tt, p);
     // one stage.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
     // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use; a second
-    // register set for two stages of distance needs the stage body twice, by parity, and then spills)
-    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
+    // register set for two stages of distance, W3_DEEP, needs the stage body twice, by parity, and then spills)
+    auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
+      constexpr int SET = W3_DEEP ? decltype(Pc)::value : 0;      // the register set this stage splits and refills: (s+1)&1
       constexpr int NQ = (NPL == 3 ? 6 : 3), PH = 4 * NQ, NM = 4 * PH, GPI = NM / 16;     // MFMAs per phase / stage, units per item
-      __syncthreads();                     // planes(s) written, everyone done with stage s-1
+      if (!(W3_KO & 8)) __syncthreads();   // planes(s) written, everyone done with stage s-1
       u32x4 ap[4][NPL], bp[2][NPL];
       // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
       // waits for two loads, not for fifteen
@@ -415,11 +486,15 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
         // (sa, sb): NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
         const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
         const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
-        acc[ta][tb] = mfma_bf16(ap[ta][sa], bp[tb & 1][sb], acc[ta][tb]);
-        if (MORE) {
+#if W3_ASM_MFMA
+        w3_mfma(ta + 4 * tb, acc_unused, ap[ta][sa], bp[tb & 1][sb]);
+#else
+        w3_mfma(ta + 4 * tb, acc[ta][tb], ap[ta][sa], bp[tb & 1][sb]);
+#endif
+        if (MORE && !(W3_KO & 4)) {
           // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
           const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
-          if (st == 0) prep(s + 1, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          if (st == 0) prep(s + 1, i, rlo[SET][i][tt], rhi[SET][i][tt], x0, x1);
           if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
           if (NPL == 3) {
             if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
@@ -430,9 +505,9 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
             if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
           }
           // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
-          if (it >= 13 && st < NPL) write_tile(s + 1, tt - 1, st);
-          if (tt == 3 && st == 1) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
-          if (tt == 3 && st == 2) gload(s + 2, i, 1);
+          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(s + 1, tt - 1, st);
+          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 2 + W3_DEEP, i, 0, SET);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 2 + W3_DEEP, i, 1, SET);
 #if W3_PREFETCH > 0
           if (g == 3) prefetch(s + 2 + W3_PREFETCH, pf_sink);
 #endif
@@ -441,31 +516,44 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
         if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(s, 2 + wb, tb + 1, gg - PH / 2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (MORE) {
+      if (MORE && !(W3_KO & 16)) {
 #pragma unroll
         for (int p = 0; p < NPL; ++p) write_tile(s + 1, 3, p);
       }
     };
     using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
+    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
 #if W3_PREFETCH > 0
 #pragma unroll
     for (int k = 0; k < W3_PREFETCH; ++k) prefetch(2 + k, pf_sink);
 #endif
-    for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
-    stage(nst - 1, BF{});
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+    {
+      int s = 0;                              // stage s works on set (s+1)&1: even stages on set 1, odd ones on set 0
+      for (; s + 2 < nst; s += 2) { stage(s, BT{}, P1{}); stage(s + 1, BT{}, P0{}); }
+      if (s + 1 < nst) { stage(s, BT{}, P1{}); stage(s + 1, BF{}, P0{}); }
+      else stage(s, BF{}, P1{});
+    }
   }
 #if W3_PREFETCH > 0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (pf_sink == 0x7f123457u && L.n < 0) bsum[0] += 1.0f;      // (never true: keeps pf_sink alive to here)
 #endif
+  w3_mfma_drain();
+  W3_STAMP(2);
   float* out = L.partials + chunk * L.chunk_stride;
   const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
+  if ((W3_KO & 1) && L.n >= 0) return;
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ri = (r & 3) + 8 * (r >> 2) + 4 * kg;
+#if W3_ASM_MFMA
+      const f32x4 v = {w3_acc_read(16 * ta + r), w3_acc_read(16 * (ta + 4) + r), w3_acc_read(16 * (ta + 8) + r), w3_acc_read(16 * (ta + 12) + r)};
+#else
       const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
+#endif
       *reinterpret_cast<f32x4*>(out + toff + (int64_t)(4 * ri + ta) * t.ldo + 4 * i32) = v;
     }
   if (t.has_bias != 0 && !opB) {           // waves 0 / 1 hold the column sums of A half 0 / 1
@@ -486,17 +574,36 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     const int64_t left = t.j[jb].m_count - m_lo;
     plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
   }
+#if W3_TRACE
+  unsigned long long trbuf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long* tr = threadIdx.x == 0 ? trbuf : nullptr;
+  W3_STAMP(0);
+#else
+  unsigned long long* tr = nullptr;
+#endif
   if (plain) {
-    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
-    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
-    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
-    else wgrad3p_body<false, false, NPL, true>(L, lds);
+    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds, tr);
+    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds, tr);
+    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds, tr);
+    else wgrad3p_body<false, false, NPL, true>(L, lds, tr);
   } else {
-    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
-    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
-    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
-    else wgrad3p_body<false, false, NPL, false>(L, lds);
+    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds, tr);
+    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds, tr);
+    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds, tr);
+    else wgrad3p_body<false, false, NPL, false>(L, lds, tr);
   }
+#if W3_TRACE
+  if (threadIdx.x == 0) {
+    __threadfence();
+    trbuf[3] = (unsigned long long)wall_clock64();
+    trbuf[4] = ((unsigned long long)blockIdx.y << 32) | (unsigned long long)(blockIdx.x + L.chunk0);
+    trbuf[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    trbuf[7] = ((unsigned long long)(plain ? 1 : 0) << 8) | (unsigned long long)((ba ? 1 : 0) | (bb ? 2 : 0)) | ((unsigned long long)t.njobs << 16);
+    const unsigned slot = atomicAdd(&g_w3_trace_n, 1u);
+    if (slot < (unsigned)W3_TRACE_MAX)
+      for (int k = 0; k < 8; ++k) g_w3_trace[(size_t)slot * 8 + k] = trbuf[k];
+  }
+#endif
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
@@ -795,3 +902,19 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   wn_backward_kernel<<<row0, 256, 0, st>>>(tab, params, partials, n_chunks, p->wgrad_floats, grad_flat);
   return i2sdf_hip_check(hipGetLastError(), "weight_grads launch");
 }
+
+#if W3_TRACE
+// development only (variant builds with -DW3_TRACE=1): copy out and reset the per-workgroup records of wgrad3p.
+// record = {t_start, t_first_job_prologue_done, t_loop_done, t_end (100 MHz ticks), task<<32 | chunk, stages of job 0, xcc<<32 | HW_ID, flags}
+extern "C" int i2sdf_debug_w3_trace(unsigned long long* dst, int max_records) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_w3_trace_n), sizeof(n)) != hipSuccess) return -1;
+  if (n > (unsigned)W3_TRACE_MAX) n = W3_TRACE_MAX;
+  if ((int)n > max_records) n = (unsigned)max_records;
+  if (dst != nullptr && n > 0 && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_w3_trace), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  const unsigned zero = 0;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_w3_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+  return (int)n;
+}
+#endif
