@@ -245,10 +245,6 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
-#ifndef W3_DEEP
-#define W3_DEEP 0                        // wgrad3p: raw rows loaded two stages ahead of their split (two register sets, see rlo / rhi): 32 more
-                                         // VGPRs than the kernel has -> spills whose reloads wait with vmcnt(0); measured 2.2 ms against 1.63 ms
-#endif
 #ifndef W3_KO
 #define W3_KO 0                          // TIMING EXPERIMENTS ONLY (wrong results): knock out 1 epilogue stores, 2 loop loads, 4 split VALU, 8 stage barrier, 16 plane writes
 #endif
@@ -258,11 +254,14 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 #ifndef W3_ASM_MFMA
 #define W3_ASM_MFMA 1                    // wgrad3p: the MFMA as inline asm with the accumulator tile constrained to AGPRs, see w3_mfma
 #endif
+#ifndef W3_RING3
+#define W3_RING3 0                       // wgrad3p: three plane slots, rows split TWO stages ahead, the next stage's operands fetched from LDS
+#endif                                   // during the last phase -> no read burst behind the stage barrier (see the stage lambda).  Measured
+                                         // (round 3, same box, alternating): with the counters serialising the kernels 633 vs 651 us per
+                                         // launch, but in the production step, where the point ranges' kernels overlap, the step is 1.3-1.7 %
+                                         // SLOWER (6.22 vs 6.14 ms, 6.32 vs 6.21 ms): off
 #ifndef W3_INTERLEAVE
 #define W3_INTERLEAVE 1                  // wgrad3p: lanes of the two 32-lane halves load the two points of one 128-B line (see vnext)
-#endif
-#ifndef W3_PREFETCH
-#define W3_PREFETCH 0                    // stages of L2 prefetch ahead of the operand loads of wgrad3p (0 = off)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -276,7 +275,8 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 //   LDS: plane ring 2 x 48 KB = 96 KB.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
-constexpr int W3P_LDS_BYTES = 2 * W3P_PL * 4;
+constexpr int W3P_SLOTS = W3_RING3 ? 3 : 2;
+constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 144 KB (96 KB without W3_RING3) of the CU's 160 KB
 
 // BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time: a runtime select inside the
 // stage costs 5 % through a worse instruction stream).
@@ -356,9 +356,6 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #endif
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-#if W3_PREFETCH > 0
-  unsigned pf_sink = 0u;
-#endif
   const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
   for (int jb = 0; jb < t.njobs; ++jb) {
     const WgJob job = t.j[jb];
@@ -395,33 +392,14 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    // W3_DEEP: TWO register sets of raw rows -- set (s+1)&1 holds the rows of stage s+1 (split during stage s) and is refilled, pair by
-    // pair as it is consumed, with the rows of stage s+3; the other set holds the rows of stage s+2, already on their way for a whole
-    // stage.  Load-to-use distance: two stages (~6 k cycles, 3 us) instead of one; the stage body exists once per set (the set index
-    // must be a compile-time constant: register arrays cannot be indexed dynamically).  Without W3_DEEP: one set, one stage of distance.
-    constexpr int NSET = W3_DEEP ? 2 : 1;
-    f32x4 rlo[NSET][4], rhi[NSET][4];
-    auto gload = [&](int s, int i, int half, int set) __attribute__((always_inline)) {
+    f32x4 rlo[4], rhi[4];
+    auto gload = [&](int s, int i, int half) __attribute__((always_inline)) {
       const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches ahead without a branch)
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
-      if (half == 0) rlo[set][i] = *reinterpret_cast<const f32x4*>(src);
-      else rhi[set][i] = *reinterpret_cast<const f32x4*>(src + vnext);
+      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
+      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
     };
-#if W3_PREFETCH > 0
-    // L2 prefetch of the raw rows W3_PREFETCH stages ahead: ONE 4-byte load per lane, every lane in a different 128-B line of this
-    // wave's quarter of that stage (64 lines = 8 KB).  The result is never used; the line is on its way into the XCD's L2 when the
-    // operand loads of that stage are issued (one stage ahead of their use), so they pay an L2 hit instead of an HBM round trip under
-    // load.  `pf_sink` stays live through the loop (it is an in/out operand of every prefetch) so that its register is not handed to
-    // another value while a load into it is still in flight.
-    const unsigned pf_off = blk ? 4u * (unsigned)((lane >> 3) * 512 + (lane & 7) * 32) : 4u * (unsigned)((lane >> 2) * dld + (lane & 3) * 32);
-    auto prefetch = [&](int s, unsigned& sink) __attribute__((always_inline)) {
-      const int sc = s < nst ? s : nst - 1;
-      const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
-      const char* src = reinterpret_cast<const char*>(ubase + soff) + pf_off;
-      asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(src) : "memory");
-    };
-#endif
     unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
     auto prep = [&](int s, int i, float lo, float hi_, float& x0, float& x1) __attribute__((always_inline)) {
@@ -430,53 +408,148 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
       x0 = p0 < rows ? fmaxf(lo, relu_lo) : 0.f;
       x1 = p0 + (W3_INTERLEAVE ? 2 : 1) < rows ? fmaxf(hi_, relu_lo) : 0.f;
     };
-    auto write_tile = [&](int s, int tt, int p) __attribute__((always_inline)) {
-      float* dst = plb + (s & 1) * W3P_PL + w * (4 * 3 * 256) + lane * 4;
+    // (the first argument of write_tile / plane is the slot's offset in floats: slot * W3P_PL)
+    auto write_tile = [&](int so, int tt, int p) __attribute__((always_inline)) {
+      float* dst = plb + so + w * (4 * 3 * 256) + lane * 4;
       *reinterpret_cast<u32x4*>(dst + (tt * 3 + p) * 256) = u32x4{pl[tt][p][0], pl[tt][p][1], pl[tt][p][2], pl[tt][p][3]};
     };
-    auto plane = [&](int s, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
-      return *reinterpret_cast<const u32x4*>(plb + (s & 1) * W3P_PL + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
+    auto plane = [&](int so, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
+      return *reinterpret_cast<const u32x4*>(plb + so + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
     };
+    auto load_all = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { gload(0, i, 0, 0); gload(0, i, 1, 0); }
-    __syncthreads();                       // the previous job is done with LDS
+      for (int i = 0; i < 4; ++i) { gload(s, i, 0); gload(s, i, 1); }
+    };
+    auto split_all = [&](int s) __attribute__((always_inline)) {          // rows of stage s (in rlo / rhi) -> pl, up front (job prologue)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {          // stage 0 is split up front
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        float x0, x1;
-        prep(0, i, rlo[0][i][tt], rhi[0][i][tt], x0, x1);
-        bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
-        if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
-        else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
+        for (int tt = 0; tt < 4; ++tt) {
+          float x0, x1;
+          prep(s, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
+          if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
+          else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
+        }
       }
+    };
+    auto write_all = [&](int so) __attribute__((always_inline)) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) write_tile(so, tt, p);
+    };
+    constexpr int NQ = (NPL == 3 ? 6 : 3), PH = 4 * NQ, NM = 4 * PH, GPI = NM / 16;     // MFMAs per phase / stage, units per item
+    using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
+    load_all(0);
+    __syncthreads();                       // the previous job is done with LDS
+    split_all(0);                          // stage 0 is split up front
+    load_all(1);
+    write_all(0);
+#if W3_RING3
+    // ---- three plane slots: stage s multiplies planes(s) (slot s % 3), splits the rows of stage s+2 into slot (s+2) % 3 and, in its
+    // last phase, fetches the operands of stage s+1 (slot (s+1) % 3) into the registers its own products have released; the one A plane
+    // that is in use to the end follows in the first units of stage s+1.  ONE barrier per stage, in unit 8: by then every wave has
+    // finished stage s-1, so planes(s+1) are complete (read from the last phase of this stage on) and nobody reads planes(s-1) any more
+    // (their slot is overwritten from unit 78 of this stage on).  The MFMAs on both sides of the barrier have their operands in registers
+    // -- with two slots the barrier sat at the head of the stage, followed by a burst of 15 LDS reads per wave, all four waves at once,
+    // before the first MFMA could issue.
+    if (nst > 1) split_all(1);
+    load_all(2);
+    if (nst > 1) write_all(W3P_PL);
+    __syncthreads();
+    u32x4 ap[4][NPL], bp[2][NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) {        // the opening plane loads in the order of their first use
+      bp[0][p] = plane(0, 2 + wb, 0, p);
+#pragma unroll
+      for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(0, wa, ta, p);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { gload(1, i, 0, NSET - 1); gload(1, i, 1, NSET - 1); }        // rows(1) -> the set stage 0 consumes
-    if (W3_DEEP) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { gload(2, i, 0, 0); gload(2, i, 1, 0); }                    // rows(2) -> the set stage 1 consumes
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-      for (int p = 0; p < NPL; ++p) write_tile(0, tt, p);
-    // one stage.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
-    // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use; a second
-    // register set for two stages of distance, W3_DEEP, needs the stage body twice, by parity, and then spills)
-    auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
+    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
+    int so0 = 0, so1 = W3P_PL, so2 = 2 * W3P_PL;      // slot offsets of stages s, s+1, s+2
+    // MORE: stage s+2 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are refilled with the rows
+    // of stage s+3 as soon as the pair has been consumed (most of a stage ahead of their use)
+    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
-      constexpr int SET = W3_DEEP ? decltype(Pc)::value : 0;      // the register set this stage splits and refills: (s+1)&1
-      constexpr int NQ = (NPL == 3 ? 6 : 3), PH = 4 * NQ, NM = 4 * PH, GPI = NM / 16;     // MFMAs per phase / stage, units per item
+      // the product (sa, sb) of unit group q:  NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
+      // -> A plane p is last used in group LASTQ(p)
+      auto LASTQ = [](int p) constexpr { return NPL == 3 ? (p == 0 ? 3 : (p == 1 ? 5 : 4)) : (p == 0 ? 1 : 2); };
+      float x0 = 0.f, x1 = 0.f, ra = 0.f, rb = 0.f;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < NM; ++g) {
+        const int tb = g / PH, gg = g % PH, q = gg / 4, ta = g % 4;
+        const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
+        const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
+        if (g == 8 && !(W3_KO & 8)) __syncthreads();
+#if W3_ASM_MFMA
+        w3_mfma(ta + 4 * tb, acc_unused, ap[ta][sa], bp[tb & 1][sb]);
+#else
+        w3_mfma(ta + 4 * tb, acc[ta][tb], ap[ta][sa], bp[tb & 1][sb]);
+#endif
+        if (g < 4) {                       // the A plane that was in use to the end of the previous stage (first needed in unit 8)
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            if (LASTQ(p) + 1 == NQ) ap[ta][p] = plane(so0, wa, ta, p);
+        }
+        if (MORE && !(W3_KO & 4)) {
+          // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched a stage earlier
+          const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
+          if (st == 0) prep(s + 2, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
+          if (NPL == 3) {
+            if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
+            if (st == 3) pl[tt][1][i] = pk_bf16(ra, rb);
+            if (st == 4) { ra -= bf16_lo(pl[tt][1][i]); rb -= bf16_hi(pl[tt][1][i]); }
+            if (st == 5) pl[tt][2][i] = pk_bf16(ra, rb);
+          } else {
+            if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
+          }
+          // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
+          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(so2, tt - 1, st);
+          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 3, i, 0);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 3, i, 1);
+        }
+        // LDS reads, one instruction per unit.  B planes of the next phase, half a phase ahead (behind the last phase: tile 0 of the
+        // next stage) ...
+        if (gg >= PH / 2 && gg < PH / 2 + NPL)
+          bp[(tb + 1) & 1][gg - PH / 2] = tb < 3 ? plane(so0, 2 + wb, tb + 1, gg - PH / 2) : plane(so1, 2 + wb, 0, gg - PH / 2);
+        // ... and in the last phase the next stage's A planes, each four units after the last MFMA that reads the register
+        if (tb == 3) {
+#pragma unroll
+          for (int p = 0; p < NPL; ++p)
+            if (LASTQ(p) + 1 < NQ && gg == 4 * (LASTQ(p) + 1) + ta) ap[ta][p] = plane(so1, wa, ta, p);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (MORE && !(W3_KO & 16)) {
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) write_tile(so2, 3, p);
+      }
+      const int t_ = so0; so0 = so1; so1 = so2; so2 = t_;
+    };
+    {
+      int s = 0;
+      for (; s + 2 < nst; ++s) stage(s, BT{});
+      if (nst >= 2) stage(nst - 2, BF{});
+      stage(nst - 1, BF{});
+    }
+#else
+    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
+    // ---- two plane slots.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
+    // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use)
+    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
+      constexpr bool MORE = decltype(Mc)::value;
+      const int so0 = (s & 1) * W3P_PL, so1 = W3P_PL - so0;
       if (!(W3_KO & 8)) __syncthreads();   // planes(s) written, everyone done with stage s-1
       u32x4 ap[4][NPL], bp[2][NPL];
       // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
       // waits for two loads, not for fifteen
 #pragma unroll
       for (int p = 0; p < NPL; ++p) {
-        bp[0][p] = plane(s, 2 + wb, 0, p);
+        bp[0][p] = plane(so0, 2 + wb, 0, p);
 #pragma unroll
-        for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(s, wa, ta, p);
+        for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(so0, wa, ta, p);
       }
       float x0 = 0.f, x1 = 0.f, ra = 0.f, rb = 0.f;
       __builtin_amdgcn_sched_barrier(0);
@@ -494,7 +567,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
         if (MORE && !(W3_KO & 4)) {
           // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
           const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
-          if (st == 0) prep(s + 1, i, rlo[SET][i][tt], rhi[SET][i][tt], x0, x1);
+          if (st == 0) prep(s + 1, i, rlo[i][tt], rhi[i][tt], x0, x1);
           if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
           if (NPL == 3) {
             if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
@@ -505,40 +578,23 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
             if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
           }
           // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
-          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(s + 1, tt - 1, st);
-          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 2 + W3_DEEP, i, 0, SET);          // the pair's last value was taken in the previous unit
-          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 2 + W3_DEEP, i, 1, SET);
-#if W3_PREFETCH > 0
-          if (g == 3) prefetch(s + 2 + W3_PREFETCH, pf_sink);
-#endif
+          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(so1, tt - 1, st);
+          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 2, i, 1);
         }
         // LDS reads of the next phase, one instruction per unit, half a phase ahead
-        if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(s, 2 + wb, tb + 1, gg - PH / 2);
+        if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(so0, 2 + wb, tb + 1, gg - PH / 2);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (MORE && !(W3_KO & 16)) {
 #pragma unroll
-        for (int p = 0; p < NPL; ++p) write_tile(s + 1, 3, p);
+        for (int p = 0; p < NPL; ++p) write_tile(so1, 3, p);
       }
     };
-    using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
-    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
-#if W3_PREFETCH > 0
-#pragma unroll
-    for (int k = 0; k < W3_PREFETCH; ++k) prefetch(2 + k, pf_sink);
+    for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
+    stage(nst - 1, BF{});
 #endif
-    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-    {
-      int s = 0;                              // stage s works on set (s+1)&1: even stages on set 1, odd ones on set 0
-      for (; s + 2 < nst; s += 2) { stage(s, BT{}, P1{}); stage(s + 1, BT{}, P0{}); }
-      if (s + 1 < nst) { stage(s, BT{}, P1{}); stage(s + 1, BF{}, P0{}); }
-      else stage(s, BF{}, P1{});
-    }
   }
-#if W3_PREFETCH > 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (pf_sink == 0x7f123457u && L.n < 0) bsum[0] += 1.0f;      // (never true: keeps pf_sink alive to here)
-#endif
   w3_mfma_drain();
   W3_STAMP(2);
   float* out = L.partials + chunk * L.chunk_stride;
