@@ -257,9 +257,9 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 #ifndef W3_RING3
 #define W3_RING3 0                       // wgrad3p: three plane slots, rows split TWO stages ahead, the next stage's operands fetched from LDS
 #endif                                   // during the last phase -> no read burst behind the stage barrier (see the stage lambda).  Measured
-                                         // (round 3, same box, alternating): with the counters serialising the kernels 633 vs 651 us per
-                                         // launch, but in the production step, where the point ranges' kernels overlap, the step is 1.3-1.7 %
-                                         // SLOWER (6.22 vs 6.14 ms, 6.32 vs 6.21 ms): off
+                                         // (round 3, same box, alternating): 660 vs 604 us per launch, 20 vs 11.5 % parked wave cycles --
+                                         // the LDS traffic of a stage (11 operand reads + 12 plane writes per wave) is squeezed into its last
+                                         // phase; off.  DESIGN.md
 #ifndef W3_INTERLEAVE
 #define W3_INTERLEAVE 1                  // wgrad3p: lanes of the two 32-lane halves load the two points of one 128-B line (see vnext)
 #endif
@@ -466,11 +466,13 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
       for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(0, wa, ta, p);
     }
     if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
-    int so0 = 0, so1 = W3P_PL, so2 = 2 * W3P_PL;      // slot offsets of stages s, s+1, s+2
     // MORE: stage s+2 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are refilled with the rows
-    // of stage s+3 as soon as the pair has been consumed (most of a stage ahead of their use)
-    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
+    // of stage s+3 as soon as the pair has been consumed (most of a stage ahead of their use).  Pc = s % 3: the slots are compile-time
+    // constants and the loop below is written out for three stages (no copies of in-flight rows at the back edge, see the two-slot version)
+    auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
+      constexpr int P = decltype(Pc)::value;
+      constexpr int so0 = P * W3P_PL, so1 = ((P + 1) % 3) * W3P_PL, so2 = ((P + 2) % 3) * W3P_PL;      // slot offsets of stages s, s+1, s+2
       // the product (sa, sb) of unit group q:  NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
       // -> A plane p is last used in group LASTQ(p)
       auto LASTQ = [](int p) constexpr { return NPL == 3 ? (p == 0 ? 3 : (p == 1 ? 5 : 4)) : (p == 0 ? 1 : 2); };
@@ -526,21 +528,28 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
 #pragma unroll
         for (int p = 0; p < NPL; ++p) write_tile(so2, 3, p);
       }
-      const int t_ = so0; so0 = so1; so1 = so2; so2 = t_;
     };
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>; using P2 = std::integral_constant<int, 2>;
     {
       int s = 0;
-      for (; s + 2 < nst; ++s) stage(s, BT{});
-      if (nst >= 2) stage(nst - 2, BF{});
-      stage(nst - 1, BF{});
+      for (; s + 4 < nst; s += 3) { stage(s, BT{}, P0{}); stage(s + 1, BT{}, P1{}); stage(s + 2, BT{}, P2{}); }
+      const int r = nst - s;               // 1 ... 4 stages left, s % 3 == 0; stage s+k still splits iff k < r - 2
+      if (r == 1) stage(s, BF{}, P0{});
+      else if (r == 2) { stage(s, BF{}, P0{}); stage(s + 1, BF{}, P1{}); }
+      else if (r == 3) { stage(s, BT{}, P0{}); stage(s + 1, BF{}, P1{}); stage(s + 2, BF{}, P2{}); }
+      else { stage(s, BT{}, P0{}); stage(s + 1, BT{}, P1{}); stage(s + 2, BF{}, P2{}); stage(s + 3, BF{}, P0{}); }
     }
 #else
     if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
     // ---- two plane slots.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
     // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use)
-    auto stage = [&](int s, auto Mc) __attribute__((always_inline)) {
+    // (Pc = s & 1 and the loop below is written out for two stages: with ONE stage per loop iteration the rows loaded for the next stage
+    // land in fresh registers and are copied into the loop-carried ones at the back edge -- eight v_mov_b64 behind an s_waitcnt vmcnt(1),
+    // i.e. the loads are waited for in the stage that issues them: 658-695 vs 596-605 us per launch, 22-25 vs 11 % parked wave cycles.
+    // Over two stages the registers line up without copies.)
+    auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
-      const int so0 = (s & 1) * W3P_PL, so1 = W3P_PL - so0;
+      constexpr int so0 = decltype(Pc)::value * W3P_PL, so1 = W3P_PL - so0;
       if (!(W3_KO & 8)) __syncthreads();   // planes(s) written, everyone done with stage s-1
       u32x4 ap[4][NPL], bp[2][NPL];
       // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
@@ -591,8 +600,13 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
         for (int p = 0; p < NPL; ++p) write_tile(so1, 3, p);
       }
     };
-    for (int s = 0; s + 1 < nst; ++s) stage(s, BT{});
-    stage(nst - 1, BF{});
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+    {
+      int s = 0;
+      for (; s + 2 < nst; s += 2) { stage(s, BT{}, P0{}); stage(s + 1, BT{}, P1{}); }
+      if (s + 1 < nst) { stage(s, BT{}, P0{}); stage(s + 1, BF{}, P1{}); }
+      else stage(s, BF{}, P0{});
+    }
 #endif
   }
   w3_mfma_drain();
