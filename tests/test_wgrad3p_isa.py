@@ -1,0 +1,95 @@
+"""CPU (hipcc cross-compiles gfx950 without a GPU): the contract between wgrad3p's inline asm and the compiler, checked on the ISA.
+
+`wgrad3p_kernel` keeps its sixteen accumulator tiles in a[0:255] as state the compiler does not see (i2sdf_amd/csrc/wgrad.hip,
+W3_ASM_MFMA: inline-asm zero fill / MFMA / read-out that name the registers themselves, every statement clobbering all AGPRs).  That is
+only sound -- and only pays -- while the compiler
+  1. references no AGPR of its own inside those kernels (it would overwrite, or be overwritten by, a tile),
+  2. spills nothing to scratch there (a spill's reload waits with vmcnt(0) for the operand loads in flight), and
+  3. does not copy in-flight rows between registers in the stage loops (v_mov behind a low vmcnt: the load-to-use distance collapses;
+     this is what a one-stage-per-iteration loop compiled to, DESIGN.md "wgrad3p under the microscope").
+A compiler update or an edit of the stage can break any of the three without failing a numerics test on small inputs."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "i2sdf_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    out = tmp_path_factory.mktemp("isa") / "wgrad.s"
+    # the flags of i2sdf_amd/csrc/build.sh for wgrad.hip
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-result",
+           "-mllvm", "-pragma-unroll-threshold=1000000", "-fno-slp-vectorize", "-x", "hip", "--cuda-device-only", "-S",
+           os.path.join(CSRC, "wgrad.hip"), "-o", str(out), "-Rpass-analysis=kernel-resource-usage"]
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().splitlines(), r.stderr
+
+
+def _kernels(lines):
+    """{mangled name: lines} of the wgrad3p kernels"""
+    out, cur = {}, None
+    for ln in lines:
+        m = re.match(r"^(_Z\w*wgrad3p_kernel\w*):", ln)
+        if m:
+            cur = m.group(1); out[cur] = []
+        elif cur is not None:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                out[cur].append(ln)
+    return out
+
+
+def test_wgrad3p_accumulator_is_hidden_state(isa):
+    lines, remarks = isa
+    ks = _kernels(lines)
+    assert len(ks) == 2, list(ks)                       # bf16x3 and bf16x2
+    for name, body in ks.items():
+        in_asm, n_mfma, foreign = False, 0, []
+        for ln in body:
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            code = ln.split(";")[0]
+            if "v_mfma" in code:
+                n_mfma += 1
+                assert in_asm, f"{name}: an MFMA outside the inline asm: {ln.strip()}"
+            if not in_asm and re.search(r"[ ,]a(\[\d+|\d+)", code) and not code.lstrip().startswith("."):
+                foreign.append(ln.strip())
+        assert n_mfma >= 8 * 96, (name, n_mfma)          # eight specialisations of the body, at least one stage each
+        assert not foreign, f"{name}: the compiler uses AGPRs of its own: {foreign[:5]}"
+    # resource remarks: no scratch, all 256 AGPRs accounted to the kernels (the clobber lists)
+    for m in re.finditer(r"Function Name: (\S*wgrad3p_kernel\S*)(.*?)Occupancy", remarks, re.S):
+        blk = m.group(2)
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", blk), (m.group(1), blk)
+        assert re.search(r"AGPRs: 256\b", blk), (m.group(1), blk)
+
+
+def test_wgrad3p_stage_loops_do_not_copy_rows_in_flight(isa):
+    lines, _ = isa
+    for name, body in _kernels(lines).items():
+        # basic blocks that branch back to themselves and carry MFMAs = the stage loops
+        blocks, cur = {}, None
+        for ln in body:
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                cur = m.group(1); blocks[cur] = []
+            elif cur is not None:
+                blocks[cur].append(ln.split(";")[0])
+        loops = {k: v for k, v in blocks.items() if sum("v_mfma" in x for x in v) >= 96 and any(re.search(r"s_cbranch\w+ " + re.escape(k) + r"\b", x) for x in v)}
+        assert loops, name
+        for k, v in loops.items():
+            assert not any("scratch_" in x for x in v), (name, k)
+            assert not any(re.search(r"\bv_mov_b(32|64)", x) for x in v), (name, k, [x.strip() for x in v if "v_mov_b" in x][:4])
+            assert not any(re.search(r"v_accvgpr", x) for x in v), (name, k)
+            low = [x.strip() for x in v if re.search(r"s_waitcnt vmcnt\([0-3]\)", x)]
+            assert not low, (name, k, low)               # eight row loads per stage in flight: the waits are vmcnt(5) ... vmcnt(7)
