@@ -265,6 +265,66 @@ extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B,
   return i2sdf_hip_check(hipGetLastError(), "loss_forward_backward launch");
 }
 
+// ---- glue of a training step as single launches (include/i2sdf.h: i2sdf_extra_points, i2sdf_backward_seeds) ----------------------
+namespace {
+__global__ __launch_bounds__(256) void extra_points_kernel(const float* __restrict__ cam, const float* __restrict__ dirs,
+                                                           const float* __restrict__ z, const float* __restrict__ eik,
+                                                           const float* __restrict__ off, int64_t B, float* __restrict__ out) {
+#pragma clang fp contract(off)                                     // the reference's two roundings (cam + z * dirs): no fused multiply-add
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;       // element of a (B,3) block
+  if (e >= 3 * B) return;
+  const int64_t i = e / 3;
+  const float prod = z[i] * dirs[e];
+  const float near = cam[e] + prod;
+  out[e] = eik[e];
+  out[3 * B + e] = near;
+  out[6 * B + e] = near + off[e];
+}
+
+__global__ __launch_bounds__(256) void backward_seeds_kernel(float* __restrict__ beta_grad, int64_t n_beta, float* __restrict__ sbar,
+                                                             float* __restrict__ nbar, int64_t Mm, int64_t Ms,
+                                                             const float* __restrict__ g_eik, int64_t n_eik,
+                                                             const float* __restrict__ g_surf, int64_t n_pc, int64_t n_main) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n_beta) { beta_grad[e] = 0.f; return; }
+  e -= n_beta;
+  const int64_t X = Ms - Mm;                                       // extra rows
+  if (e < X) {                                                     // sdf_bar rows [Mm, Ms)
+    const int64_t k = e - n_eik;
+    sbar[Mm + e] = (g_surf && k >= 0 && k < n_pc) ? g_surf[k] : 0.f;
+    return;
+  }
+  e -= X;
+  if (e < 3 * X) {                                                 // grad_bar rows [Mm, Ms)
+    nbar[3 * Mm + e] = (g_eik && e < 3 * n_eik) ? g_eik[e] : 0.f;
+    return;
+  }
+  e -= 3 * X;
+  if (e < n_main) nbar[e] = 0.f;                                   // grad_bar rows [0, Mm) when nobody else writes them
+}
+}  // namespace
+
+extern "C" int i2sdf_extra_points(const float* cam, const float* dirs, const float* z_eik, const float* eik_pts, const float* nbr_off,
+                                  int64_t B, float* out, void* stream) {
+  if (B == 0) return I2SDF_OK;
+  if (!cam || !dirs || !z_eik || !eik_pts || !nbr_off || !out || B < 0) return I2SDF_EINVAL;
+  extra_points_kernel<<<(unsigned)((3 * B + 255) / 256), 256, 0, (hipStream_t)stream>>>(cam, dirs, z_eik, eik_pts, nbr_off, B, out);
+  return i2sdf_hip_check(hipGetLastError(), "extra_points launch");
+}
+
+extern "C" int i2sdf_backward_seeds(float* beta_grad, int64_t n_beta, float* sdf_bar, float* grad_bar, int64_t M_main, int64_t M_sdf,
+                                    const float* g_eik, int64_t n_eik, const float* g_surf, int64_t n_pc, int32_t zero_main_grad,
+                                    void* stream) {
+  if (n_beta < 0 || M_main < 0 || M_sdf < M_main || n_eik < 0 || n_pc < 0 || n_eik + n_pc > M_sdf - M_main) return I2SDF_EINVAL;
+  if ((n_beta > 0 && !beta_grad) || (M_sdf > 0 && (!sdf_bar || !grad_bar))) return I2SDF_EINVAL;
+  const int64_t n_main = zero_main_grad ? 3 * M_main : 0;
+  const int64_t total = n_beta + 4 * (M_sdf - M_main) + n_main;
+  if (total == 0) return I2SDF_OK;
+  backward_seeds_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(beta_grad, n_beta, sdf_bar, grad_bar, M_main, M_sdf,
+                                                                                           g_eik, n_eik, g_surf, n_pc, n_main);
+  return i2sdf_hip_check(hipGetLastError(), "backward_seeds launch");
+}
+
 extern "C" int i2sdf_eikonal_outputs_forward(const float* grad_all, int64_t B, float* grad_theta, float* diff_norm, void* stream) {
   if (B == 0) return I2SDF_OK;
   if (!grad_all || !diff_norm || B < 0) return I2SDF_EINVAL;

@@ -146,6 +146,8 @@ SIGNATURES = {
     "i2sdf_loss_scratch_floats": (_I64, []),
     "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 26),
     "i2sdf_eikonal_outputs_forward": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "i2sdf_extra_points": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "i2sdf_backward_seeds": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P]),
     "i2sdf_eikonal_outputs_backward": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "i2sdf_ray_setup_ex": (C.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P]),

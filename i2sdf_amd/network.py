@@ -136,19 +136,17 @@ class _RenderFn(torch.autograd.Function):
         # No whole-buffer fills: i2sdf_weight_grads writes every entry of the flat gradient except density.beta (accumulated by the
         # compositing backward), and the compositing backward writes the rays' rows [0, M_main) of sbar / nbar; only the rows of the
         # extra points are set here (eikonal points carry d loss / d grad, the bubble point cloud d loss / d sdf).
+        # One launch (i2sdf_backward_seeds) instead of three fills and two copies.
         gflat = torch.empty_like(flat)
-        gflat[off_beta:].zero_()
         sbar = torch.empty(M_sdf, device=dev)
         nbar = torch.empty(M_sdf, 3, device=dev)
-        if M_sdf > M_main:
-            sbar[M_main:].zero_()
-            nbar[M_main:].zero_()
-        if not want_normal:
-            nbar[:M_main].zero_()
-        if n_eik:
-            nbar[M_main:M_main + n_eik] = g_eik
-        if n_pc:
-            sbar[M_main + n_eik:M_main + n_eik + n_pc] = g_surf.reshape(-1)
+        from . import lib as L_
+        ge = g_eik.contiguous() if n_eik else None
+        gs = g_surf.reshape(-1).contiguous() if n_pc else None
+        with torch.cuda.device(dev):
+            L_.check(L_.load().i2sdf_backward_seeds(L_.ptr(gflat[off_beta:]), flat.numel() - off_beta, L_.ptr(sbar), L_.ptr(nbar), M_main, M_sdf,
+                                                   L_.ptr(ge) if ge is not None else None, n_eik, L_.ptr(gs) if gs is not None else None, n_pc,
+                                                   0 if want_normal else 1, L_.stream_ptr()), "i2sdf_backward_seeds")
         cb = eng.composite_backward(flat[off_beta:], st["z_all"], fw["sdf"], ctx.rgb, fw["grad"], st["dnorm"], comp["nsum"],
                                     g_rgb, g_depth, g_wsum.reshape(-1), g_normal if want_normal else None,
                                     g_lmask.reshape(-1) if net.use_light else None, beta_grad_accum=gflat[off_beta:],
@@ -485,16 +483,21 @@ class I2SDFNetwork(nn.Module):
             eik = draws.get("eik_pts")
             if eik is None:
                 eik = torch.empty(N, 3, device=dev).uniform_(-R, R)
-            near = cam + z_eik * dirs
             off = draws.get("nbr_off")
             if off is None:
-                off = torch.empty_like(near).uniform_(-0.005, 0.005)
-            pts = [eik, near, near + off]
-            n_pc = 0
-            if "pointcloud" in input:
-                pts.append(input["pointcloud"].to(torch.float32))
-                n_pc = input["pointcloud"].shape[0]
-            return torch.cat(pts, 0).contiguous(), 3 * N, n_pc
+                off = torch.empty(N, 3, device=dev).uniform_(-0.005, 0.005)
+            pc = input["pointcloud"].to(torch.float32) if "pointcloud" in input else None
+            n_pc = 0 if pc is None else pc.shape[0]
+            # [uniform | cam + z_eik * dirs | that + offset] by one launch (i2sdf_extra_points) instead of a multiply, two adds and a cat
+            pts = torch.empty(3 * N + n_pc, 3, device=dev)
+            from . import lib as L_
+            c = lambda t: t.to(torch.float32).contiguous()
+            with torch.cuda.device(dev):
+                L_.check(L_.load().i2sdf_extra_points(L_.ptr(c(cam)), L_.ptr(c(dirs)), L_.ptr(c(z_eik)), L_.ptr(c(eik)), L_.ptr(c(off)), N,
+                                                     L_.ptr(pts), L_.stream_ptr()), "i2sdf_extra_points")
+            if n_pc:
+                pts[3 * N:] = pc
+            return pts, 3 * N, n_pc
 
     @staticmethod
     def _eikonal_outputs(out, g_all, surf, N, n_pc):

@@ -468,6 +468,25 @@ int i2sdf_eikonal_outputs_backward(const float* grad_all, const float* grad_thet
                                    float* grad_all_bar, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * The extra points of a training step -- model/network/__init__.py:175-186 -- in one launch instead of a multiply, two adds and a
+ * concatenation:  out (3B,3) = [ eik_pts (B,3) | cam + z_eik * dirs (B,3) | the same + nbr_off (B,3) ],  z_eik (B) the per-ray depth
+ * i2sdf_sample_rays returned, the sum rounded as the reference's two fp32 operations (product, then sum; no fused multiply-add).
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_extra_points(const float* cam, const float* dirs, const float* z_eik, const float* eik_pts, const float* nbr_off, int64_t B,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Seeds of the backward pass (what autograd's accumulation does with a handful of fills and copies), one launch:
+ *   beta_grad[0, n_beta) = 0                                   (i2sdf_composite_backward accumulates d loss / d beta into it)
+ *   sdf_bar (M_sdf)    : rows [M_main, M_sdf) = 0, except rows [M_main + n_eik, M_main + n_eik + n_pc) = g_surf (n_pc)|NULL
+ *   grad_bar (M_sdf,3) : rows [M_main, M_sdf) = 0, except rows [M_main, M_main + n_eik) = g_eik (n_eik,3)|NULL;
+ *                        rows [0, M_main) = 0 too iff zero_main_grad (no normal output: the compositing backward does not write them)
+ * The rays' rows [0, M_main) of sdf_bar (and of grad_bar otherwise) are left to i2sdf_composite_backward, which writes all of them.
+ * ---------------------------------------------------------------------------------------------- */
+int i2sdf_backward_seeds(float* beta_grad, int64_t n_beta, float* sdf_bar, float* grad_bar, int64_t M_main, int64_t M_sdf,
+                         const float* g_eik, int64_t n_eik, const float* g_surf, int64_t n_pc, int32_t zero_main_grad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Full-image inference in one call -- the chunk loop of utils.split_input / model(chunk) /
  * utils.merge_output (utils/__init__.py:35-84) as used by model/eval/recon.py:161-182 and the plotting callbacks: eval mode,
  * `chunk` = split_n_pixels rays at a time, every chunk rendered exactly as the reference renders it (the sampler's convergence

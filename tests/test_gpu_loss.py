@@ -66,3 +66,46 @@ def test_fused_loss_golden(golden):
     for k in l1:
         assert_close(l1[k].cpu(), z["synthetic." + k], 2e-6, "synthetic." + k)
         assert_close(l2[k].cpu(), z["light." + k], 2e-6, "light." + k)
+
+
+def test_extra_points_and_backward_seeds_match_the_torch_glue_bitwise():
+    """i2sdf_extra_points / i2sdf_backward_seeds replace a multiply, two adds, a concatenation / three fills and two copies of torch
+    glue (model/network/__init__.py:175-186 and autograd's accumulation): same bits."""
+    import torch
+    from i2sdf_amd import lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for B in (1, 77, 1024):
+        cam, dirs = torch.randn(B, 3, generator=g).to(dev), torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).to(dev)
+        z, eik, off = (torch.rand(B, 1, generator=g) * 5).to(dev), (torch.rand(B, 3, generator=g) * 6 - 3).to(dev), ((torch.rand(B, 3, generator=g) - 0.5) * 0.01).to(dev)
+        out = torch.full((3 * B + 5, 3), 7.0, device=dev)
+        L.check(lib.i2sdf_extra_points(L.ptr(cam), L.ptr(dirs), L.ptr(z), L.ptr(eik), L.ptr(off), B, L.ptr(out), L.stream_ptr()), "extra_points")
+        near = cam + z * dirs
+        assert torch.equal(out[:3 * B], torch.cat([eik, near, near + off], 0))
+        assert torch.equal(out[3 * B:], torch.full((5, 3), 7.0, device=dev)), "rows beyond 3B must be left alone"
+    for (Mm, n_eik, n_pc, tail, n_beta, zero_main, with_e, with_s) in ((0, 0, 0, 0, 1, 0, False, False), (640, 96, 0, 32, 3, 0, True, False),
+                                                                         (640, 96, 17, 15, 1, 1, True, True), (99328, 3072, 0, 0, 1, 0, True, False),
+                                                                         (256, 30, 9, 3, 2, 1, False, True)):
+        Ms = Mm + n_eik + n_pc + tail
+        beta = torch.full((n_beta + 2,), 5.0, device=dev)
+        sbar, nbar = torch.full((max(Ms, 1),), 3.0, device=dev), torch.full((max(Ms, 1), 3), 4.0, device=dev)
+        ge = torch.randn(n_eik, 3, generator=g).to(dev) if with_e else None
+        gs = torch.randn(n_pc, generator=g).to(dev) if with_s else None
+        L.check(lib.i2sdf_backward_seeds(L.ptr(beta), n_beta, L.ptr(sbar), L.ptr(nbar), Mm, Ms, L.ptr(ge), n_eik, L.ptr(gs), n_pc, zero_main,
+                                         L.stream_ptr()), "backward_seeds")
+        assert torch.equal(beta, torch.cat([torch.zeros(n_beta, device=dev), torch.full((2,), 5.0, device=dev)]))
+        es, en = torch.full((max(Ms, 1),), 3.0, device=dev), torch.full((max(Ms, 1), 3), 4.0, device=dev)
+        if Ms > 0:
+            es[Mm:Ms] = 0.0
+            en[Mm:Ms] = 0.0
+            if zero_main:
+                en[:Mm] = 0.0
+            if with_e:
+                en[Mm:Mm + n_eik] = ge
+            if with_s:
+                es[Mm + n_eik:Mm + n_eik + n_pc] = gs
+        assert torch.equal(sbar, es) and torch.equal(nbar, en), (Mm, n_eik, n_pc)
+    # argument checks
+    assert lib.i2sdf_backward_seeds(None, 1, None, None, 0, 0, None, 0, None, 0, 0, L.stream_ptr()) != 0
+    assert lib.i2sdf_backward_seeds(L.ptr(beta), 1, L.ptr(sbar), L.ptr(nbar), 10, 12, None, 3, None, 0, 0, L.stream_ptr()) != 0      # n_eik > extra rows
