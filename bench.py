@@ -421,6 +421,13 @@ def main():
                     "hbm_view": {"design_bytes": int(design_bytes), "gbs": round(design_bytes / t_launch / 1e9, 1), "peak_gbs": 8000.0,
                                  "frac": round(design_bytes / t_launch / 8.0e12, 4)},
                     "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
+                    # every MFMA-bound entry point against the same kind of peak (the dominant one above is simply the longest of them)
+                    "entry_points": {n: {"ms": round(kern[n]["ms_per_step"], 4), "tflops": round(kern[n]["tflops"], 2),
+                                         "frac": round(kern[n]["tflops"] / (PEAK_X3 if x3.get(n) else PEAK), 4)} for n in mfma_names},
+                    # what the power limit leaves of the nominal peak: a pure v_mfma_f32_32x32x16_bf16 loop on random operands holds
+                    # 1.95 GHz at 95 % matrix-pipe occupancy on this chip = 1933 TFLOP/s (scripts/ubench, profiles/r3_ubench_mfma_stage.txt)
+                    "power_limited_bf16_peak_measured": {"tflops": 1933.0, "frac_of_nominal": 0.773,
+                                                         "frac_of_it": round(ach * 6 / 1933.0, 4) if x3.get(dom) else None},
                     "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
                                                      / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
         total_flops = sum(launch_flops.values())
