@@ -54,29 +54,32 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 // ---------------------------------------------------------------------------------------------
 // Weight stream: linear walk over a packed buffer, global -> LDS by DMA, double buffered.
 // ---------------------------------------------------------------------------------------------
-struct WStream {
+// NTHR = threads of the workgroup, SCS = chunks (KB) per LDS stage
+template <int NTHR, int SCS = SC>
+struct WStreamT {
+  static constexpr int STG = SCS * CHUNK_FLOATS;      // floats per stage
   // The DMA is `buffer_load_dwordx4 ... lds` (address = descriptor base + scalar byte offset + per-lane offset tid*16), not
   // `global_load_lds`: hipcc counts the global form as a FLAT access (it may touch LDS out of order), and while one is pending every
   // wait for an LDS READ result becomes s_waitcnt lgkmcnt(0) -- also for reads issued a few cycles earlier, so the read-ahead of the
   // MFMA loops was worth nothing.  Behind the buffer form the waits carry exact counts (lgkmcnt(2), (4) ...).
   __amdgpu_buffer_rsrc_t rs;   // the packed stream this kernel walks, from its first stage
   unsigned goff;      // byte offset (from the descriptor base) of the next stage to fetch
-  float* lds;         // two STAGE_FLOATS buffers
+  float* lds;         // two stage buffers
   int cur;            // buffer that the NEXT advance() returns
   int left;           // stages still to be fetched
   int wv;             // this wave's index in the workgroup as a scalar (M0, the LDS address of a piece, is computed on the scalar unit)
 
   __device__ __forceinline__ void piece(float* dst_stage, unsigned stage_off, int i, int tid) {
-    float* d = dst_stage + wv * 256 + i * WG_THREADS * 4;     // wave-uniform LDS base; the hardware adds lane*16 B
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16, tid * 16, stage_off + i * (WG_THREADS * 16), 0, 0);
+    float* d = dst_stage + wv * 256 + i * NTHR * 4;     // wave-uniform LDS base; the hardware adds lane*16 B
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16, tid * 16, stage_off + i * (NTHR * 16), 0, 0);
   }
   __device__ __forceinline__ void issue(float* dst, int tid) {
 #ifdef I2SDF_ABL_NODMA
-    goff += STAGE_FLOATS * 4; (void)dst; return;
+    goff += STG * 4; (void)dst; return;
 #endif
 #pragma unroll
-    for (int i = 0; i < STAGE_FLOATS / (WG_THREADS * 4); ++i) piece(dst, goff, i, tid);
-    goff += STAGE_FLOATS * 4;
+    for (int i = 0; i < STG / (NTHR * 4); ++i) piece(dst, goff, i, tid);
+    goff += STG * 4;
   }
   // n_stages = total stages this kernel will consume from `base`
   __device__ __forceinline__ void begin(const float* base, float* lds_, int n_stages, int tid) {
@@ -95,23 +98,23 @@ struct WStream {
 #endif
     // 
                           // (b) every wave's did, (c) every wave finished reading the other buffer
-    const float* ret = lds + cur * STAGE_FLOATS;
-    if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
+    const float* ret = lds + cur * STG;
+    if (left > 0) { issue(lds + (cur ^ 1) * STG, tid); --left; }
     cur ^= 1;
     return ret;
   }
   // piecewise form of advance_issue(): the NPIECE 4 KB pieces of the following stage one at a time (i = 0..NPIECE-1, each wave moves
   // 1 KB per piece), then advance_done() -- a piece costs the wave 60-180 cycles of issue (MI355X_MICROARCH.md), so the K-outer
   // bf16x3 ops put ONE piece behind each group of MFMAs instead of all eight behind the first group
-  static constexpr int NPIECE = STAGE_FLOATS / (WG_THREADS * 4);
+  static constexpr int NPIECE = STG / (NTHR * 4);
   // Branch-free on purpose: a scalar branch around the DMA would cut the surrounding MFMA stream into basic blocks, and the
   // scheduling fences (sched_barrier) that deal the VALU work into the MFMA shadows only act inside one block.  When no stage is left
   // the piece re-reads the stage fetched last (valid memory) into the buffer nobody reads any more.
   __device__ __forceinline__ void issue_piece(int i, int tid) {
-    piece(lds + (cur ^ 1) * STAGE_FLOATS, left > 0 ? goff : goff - STAGE_FLOATS * 4u, i, tid);
+    piece(lds + (cur ^ 1) * STG, left > 0 ? goff : goff - STG * 4u, i, tid);
   }
   __device__ __forceinline__ void advance_done() {
-    if (left > 0) { goff += STAGE_FLOATS * 4; --left; }
+    if (left > 0) { goff += STG * 4; --left; }
     cur ^= 1;
   }
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
@@ -120,7 +123,7 @@ struct WStream {
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), see advance()
     __syncthreads();
 #endif
-    return lds + cur * STAGE_FLOATS;
+    return lds + cur * STG;
   }
   // Counted form: the DMA pieces of the stage about to be read were issued in the FIRST groups of the previous stage (issue_piece),
   // and at most `n_after` vector-memory instructions were issued behind the last of them.  VMEM operations retire in order, so
@@ -139,14 +142,14 @@ struct WStream {
 #undef I2SDF_VMCNT
     __syncthreads();
 #endif
-    return lds + cur * STAGE_FLOATS;
+    return lds + cur * STG;
   }
   // pieces of the X3_EARLY protocol (x3.h): the wait + barrier of advance_barrier_n() on its own, and the buffer the NEXT stage is in
   // (the one the pieces issued during the current stage are filling)
   __device__ __forceinline__ void barrier_n(int n_after) { (void)advance_barrier_n(n_after); }
-  __device__ __forceinline__ const float* next_stage() const { return lds + (cur ^ 1) * STAGE_FLOATS; }
+  __device__ __forceinline__ const float* next_stage() const { return lds + (cur ^ 1) * STG; }
   __device__ __forceinline__ void advance_issue(int tid) {
-    if (left > 0) { issue(lds + (cur ^ 1) * STAGE_FLOATS, tid); --left; }
+    if (left > 0) { issue(lds + (cur ^ 1) * STG, tid); --left; }
     cur ^= 1;
   }
   // skip `n` stages without computing (still in lock step)
@@ -154,6 +157,7 @@ struct WStream {
     for (int i = 0; i < n; ++i) (void)advance(tid);
   }
 };
+using WStream = WStreamT<WG_THREADS>;      // 4 waves per workgroup (every kernel but the 16-point-wave family, x3h.h)
 
 // ---------------------------------------------------------------------------------------------
 // One dense op:  acc[NT] (+)= bias + W * in     (32 points per wave, all in registers)

@@ -62,12 +62,12 @@ struct RgbBwdArgs {
   int wg0 = 0;              // first 128-point workgroup of this launch
 };
 
-// bf16x3 twins (mlp_x3.hip): launch over `grid` workgroups of 128 points
-// `ring`: the kernels that re-read saved tensors take them through the per-wave LDS ring (x3r.h, mlp_x3r.hip)
-void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st, bool ring);
-void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st, bool ring);
+// bf16x3 twins: launch over `grid` workgroups of 128 points -- four 32-point waves (mlp_x3.hip) or eight 16-point waves (mlp_x3h.hip)
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st);
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st, bool ring);
-void i2sdf_launch_igrad3r(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_sdf_bwd3r(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_rgb_bwd3r(const RgbBwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st, int nw);
+void i2sdf_launch_sdf_bwd3h(const SdfBwdArgs& a, unsigned grid, hipStream_t st, int nw);
+void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
+void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st);

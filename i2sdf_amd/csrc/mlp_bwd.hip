@@ -411,7 +411,13 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       a3.n_fwd = sdf_fwd3_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
       a3.n_rev = sdf_rev3_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
       a3.kcs = sdf_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
-      i2sdf_launch_sdf_bwd3(a3, g, st, p->src_ring != 0);
+      if (p->wave16 & I2SDF_W16_SWEEPS) {          // 16-point waves (x3h.h): their own streams, same tensors
+        a3.fwd = base + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;
+        a3.rev = base + p->sdf.rev3h_chunk0 * CHUNK_FLOATS;
+        a3.n_fwd = sdf_fwd3h_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
+        a3.n_rev = sdf_rev3h_bwd_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip);
+        i2sdf_launch_sdf_bwd3h(a3, g, st, (p->wave16 & I2SDF_W16_WG4) ? 4 : 8);
+      } else i2sdf_launch_sdf_bwd3(a3, g, st);
     };
     if (x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun): both sweeps of a range on the range's stream
       PartRun pr;
@@ -466,7 +472,11 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
         x3.rev = packed + p->scale_floats + p->rgb.rev3_chunk0 * CHUNK_FLOATS;
         x3.n_rev = rgb_rev3_stages(256, 256, d.n_lin);
         x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
-        i2sdf_launch_rgb_bwd3(x3, g, st, p->src_ring != 0);
+        if (p->wave16 & I2SDF_W16_RGB_BWD) {         // 16-point waves (x3h.h)
+          x3.rev = packed + p->scale_floats + p->rgb.rev3h_chunk0 * CHUNK_FLOATS;
+          x3.n_rev = rgb_rev3h_stages(256, 256, d.n_lin);
+          i2sdf_launch_rgb_bwd3h(x3, g, st);
+        } else i2sdf_launch_rgb_bwd3(x3, g, st);
       } else {
         launch_lds(rgb_bwd_kernel<256, 256>, g, st, x);
       }

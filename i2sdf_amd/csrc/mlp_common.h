@@ -23,6 +23,20 @@ inline void launch_lds_bytes(int lds_bytes, K kern, unsigned grid, hipStream_t s
 }
 template <class K, class... A>
 inline void launch_lds(K kern, unsigned grid, hipStream_t st, A... args) { launch_lds_bytes(LDS_BYTES, kern, grid, st, args...); }
+// the same for a kernel of `threads` threads per workgroup (16-point-wave kernels, x3h.h: 512 = 8 waves, 256 = 4 waves)
+template <class K, class... A>
+inline void launch_lds_threads(int threads, K kern, unsigned grid, hipStream_t st, A... args) {
+  static std::mutex mu;
+  static std::unordered_set<const void*> done;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.count((const void*)kern)) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES_H);
+      done.insert((const void*)kern);
+    }
+  }
+  kern<<<grid, threads, LDS_BYTES_H, st>>>(args...);
+}
 
 // Split of a launch over M points into full rounds of 128-point workgroups (one per CU) and a short tail that is run by
 // the split-K kernels (ksplit.h): returns the number of points of the bulk part (0 = no split).
@@ -117,6 +131,43 @@ __host__ __device__ constexpr int rgb_fwd3_stages(int H, int F, int PEDV, int L)
 }
 __host__ __device__ constexpr int rgb_rev3_stages(int H, int F, int L) {
   return (rowvec_chunks(H / 8, 3) + (L - 2) * x3_bwd_chunks(H / 32, H / 16) + x3_bwd_chunks(F / 32, H / 16)) / SC;
+}
+// ---- 16-point-wave family (x3h.h): same ops, 16-row tiles / 32-wide k-chunks -- must mirror plan.cpp
+__host__ __device__ constexpr int sdf_fwd3h_stages(int H, int PED, int L, bool has_skip) {
+  const int PE32 = cdiv(PED, 32);
+  int c = x3h_op_chunks(H / 16, PE32);
+  for (int l = 1; l < L - 1; ++l) c += x3h_op_chunks(H / 16, H / 32);
+  if (has_skip) c += x3h_op_chunks(H / 16, H / 32 + PE32) - x3h_op_chunks(H / 16, H / 32);
+  c += rowvec_h_chunks(H / 16, 1);
+  return c / SCH;
+}
+__host__ __device__ constexpr int sdf_fwd3h_train_stages(int H, int F, int PED, int L, bool has_skip, bool full) {
+  return sdf_fwd3h_stages(H, PED, L, has_skip) + (full ? x3h_op_chunks(F / 16, H / 32) / SCH : 0);
+}
+__host__ __device__ constexpr int sdf_fwd3h_hidden_stages(int H, int PED, int L, bool has_skip) {
+  return sdf_fwd3h_stages(H, PED, L, has_skip) - rowvec_h_chunks(H / 16, 1) / SCH;
+}
+__host__ __device__ constexpr int pe_tiles_h(int PED) { return round_up(cdiv(PED, 16), 2); }
+__host__ __device__ constexpr int sdf_rev3h_stages(int H, int PED, int L, bool has_skip) {      // d sdf/dx chain: from the second w_sdf copy on
+  const int PT = pe_tiles_h(PED);
+  int c = rowvec_h_chunks(H / 16, 1);
+  for (int l = L - 2; l >= 1; --l) c += x3h_bwd_chunks(H / 16, H / 32);
+  if (has_skip) c += x3h_bwd_chunks(PT, H / 32);
+  c += x3h_bwd_chunks(PT, H / 32);
+  return c / SCH;
+}
+__host__ __device__ constexpr int sdf_rev3h_bwd_stages(int H, int F, int PED, int L, bool has_skip) {   // sweep 2: from W_feat^T down to W_1^T
+  const int PT = pe_tiles_h(PED);
+  int c = 2 * rowvec_h_chunks(H / 16, 1) + x3h_bwd_chunks(H / 16, F / 32);
+  for (int l = L - 2; l >= 1; --l) c += x3h_bwd_chunks(H / 16, H / 32);
+  if (has_skip) c += x3h_bwd_chunks(PT, H / 32);
+  return c / SCH;
+}
+__host__ __device__ constexpr int rgb_fwd3h_stages(int H, int F, int PEDV, int L) {
+  return (x3h_op_chunks(H / 16, cdiv(PEDV, 32) + F / 32) + (L - 2) * x3h_op_chunks(H / 16, H / 32) + rowvec_h_chunks(H / 16, 3)) / SCH;
+}
+__host__ __device__ constexpr int rgb_rev3h_stages(int H, int F, int L) {
+  return (rowvec_h_chunks(H / 16, 3) + (L - 2) * x3h_bwd_chunks(H / 16, H / 32) + x3h_bwd_chunks(F / 16, H / 32)) / SCH;
 }
 __host__ __device__ constexpr int bwd_op_chunks(int KT, int NC) { return round_up(KT * NC, SC); }
 // reverse stream from the w_sdf row vector to W_0^T (the d sdf/dx chain); PT = tiles of the PE space

@@ -393,7 +393,17 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     a3.n_fwd = sdf_fwd3_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);      \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
     a3.kcs = sdf_blocked_points(p, M, Mp, feat != nullptr) > 0 ? KCS_BLK : KCS_PM;                   \
-    i2sdf_launch_train_fwd3(a3, grad != nullptr, G_, st, p->src_ring != 0);                                            \
+    SdfTrainFwdArgs ah = a3;          /* 16-point waves (x3h.h): their own streams, same tensors */    \
+    ah.fwd = base + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;                                              \
+    ah.rev = base + p->sdf.rev3h_wsdf_chunk * CHUNK_FLOATS;                                          \
+    ah.n_fwd = sdf_fwd3h_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);     \
+    ah.n_rev = sdf_rev3h_stages(256, PE<6>::DIM, d.n_lin, has_skip);                                 \
+    const bool hf = (p->wave16 & I2SDF_W16_TRAIN_FWD) != 0, hg = (p->wave16 & I2SDF_W16_IGRAD) != 0;  \
+    const int nw16 = (p->wave16 & I2SDF_W16_WG4) ? 4 : 8;                                            \
+    if (hf) i2sdf_launch_train_fwd3h(ah, true, false, G_, st, nw16);                                    \
+    else i2sdf_launch_train_fwd3(a3, true, false, G_, st);                                           \
+    if (grad && hg) i2sdf_launch_train_fwd3h(ah, false, true, G_, st, nw16);                               \
+    else if (grad) i2sdf_launch_train_fwd3(a3, false, true, G_, st);                                 \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
   if (x3 && i2sdf_parts_on(p)) {
@@ -461,7 +471,11 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
         x3.fwd = packed + p->scale_floats + p->rgb.fwd3_chunk0 * CHUNK_FLOATS;
         x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
         x3.n_fwd = rgb_fwd3_stages(256, 256, PE<4>::DIM, d.n_lin);
-        i2sdf_launch_rgb_fwd3(x3, g, st);
+        if (p->wave16 & I2SDF_W16_RGB_FWD) {          // 16-point waves (x3h.h)
+          x3.fwd = packed + p->scale_floats + p->rgb.fwd3h_chunk0 * CHUNK_FLOATS;
+          x3.n_fwd = rgb_fwd3h_stages(256, 256, PE<4>::DIM, d.n_lin);
+          i2sdf_launch_rgb_fwd3h(x3, g, st);
+        } else i2sdf_launch_rgb_fwd3(x3, g, st);
       } else {
         launch_lds(rgb_fwd_kernel<256, 256, 4>, g, st, x);
       }

@@ -444,20 +444,13 @@ void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int 
   if (H == 256) launch_lds(sdf_fwd3_kernel<256, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
   else launch_lds(sdf_fwd3_kernel<64, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
-void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool grad, unsigned grid, hipStream_t st, bool ring) {
-  launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, grid, st, a);
-  if (grad) {
-    if (ring) i2sdf_launch_igrad3r(a, grid, st);
-    else launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a);
-  }
+void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st) {
+  if (fwd) launch_lds(sdf_train_fwd3_kernel<256, 256, 6, false>, grid, st, a);
+  if (grad) launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a);
 }
-void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st, bool ring) {
-  if (ring) { i2sdf_launch_sdf_bwd3r(a, grid, st); return; }
+void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
   launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
   launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);
 }
 void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(rgb_fwd3_kernel<256, 256, 4>, grid, st, a); }
-void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st, bool ring) {
-  if (ring) i2sdf_launch_rgb_bwd3r(a, grid, st);
-  else launch_lds(rgb_bwd3_kernel<256, 256>, grid, st, a);
-}
+void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(rgb_bwd3_kernel<256, 256>, grid, st, a); }

@@ -129,6 +129,56 @@ __global__ __launch_bounds__(256) void pack_kernel(const Seg* __restrict__ segs,
         }
       }
       out = __builtin_bit_cast(f32x4, u32x4{q[0], q[1], q[2], q[3]});
+    } else if (s.type == SEG_BIAS_H) {
+      // 16-point-wave family (x3h.h): lane = i16 + 16*kg; D layout of tile nt: register t <-> row 16*nt + 4*kg + t
+      const int kg = lane >> 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 16 * c + 4 * kg + t;
+        out[t] = (r < s.nrows) ? params[s.off_bias + s.row_off + r] : 0.f;
+      }
+    } else if (s.type == SEG_WFWD3H || s.type == SEG_WBWD3H) {
+      // chunk c -> pair w = c/2 (e = c&1), k-chunk kc = w / (3G), tile pair g, split plane sp; A row = 16*(2g+e) + i16,
+      // element j <-> reduction index 32*kc + 16*(j>>2) + 4*kg + (j&3)
+      const int G = s.NT / 2, w = c >> 1, e = c & 1;
+      const int kc = w / (3 * G), g = (w / 3) % G, sp = w % 3;
+      const int i16 = lane & 15, kg = lane >> 4;
+      const int arow = 16 * (2 * g + e) + i16;
+      const bool fwd = s.type == SEG_WFWD3H;
+      const int acol = fwd ? -1 : map_col(s.cm, arow);            // transposed: the A row is an input column of the layer
+      unsigned q[4] = {0u, 0u, 0u, 0u};
+      if (fwd ? (arow < s.nrows) : (acol >= 0)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int j = 2 * i + h2;
+            const int k = 32 * kc + 16 * (j >> 2) + 4 * kg + (j & 3);
+            x[h2] = 0.f;
+            if (fwd) {
+              const int row = s.row_off + arow, col = map_col(s.cm, k);
+              if (col >= 0) x[h2] = params[s.off_v + (int64_t)row * s.cols + col] * (scale[s.scale_off + row] * s.mult);
+            } else if (k < s.nrows) {
+              const int row = s.row_off + k;
+              x[h2] = params[s.off_v + (int64_t)row * s.cols + acol] * scale[s.scale_off + row] * s.mult;
+            }
+          }
+          unsigned p0, p1, p2;
+          split3_pair(x[0], x[1], p0, p1, p2);
+          q[i] = sp == 0 ? p0 : (sp == 1 ? p1 : p2);
+        }
+      }
+      out = __builtin_bit_cast(f32x4, u32x4{q[0], q[1], q[2], q[3]});
+    } else if (s.type == SEG_ROWVEC_H) {
+      const int rr = c / s.KC, nt = c % s.KC, kg = lane >> 4;
+      const int row = s.row_off + rr;
+      const float sc = scale[s.scale_off + row] * s.mult;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int col = map_col(s.cm, 16 * nt + 4 * kg + t);
+        out[t] = col >= 0 ? params[s.off_v + (int64_t)row * s.cols + col] * sc : 0.f;
+      }
     } else if (s.type == SEG_WBWD) {
       const int kt = c / s.KC, nc = c % s.KC;
       const int col = map_col(s.cm, 32 * kt + i32);

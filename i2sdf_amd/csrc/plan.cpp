@@ -91,6 +91,30 @@ void emit_dense_bwd3(Builder& b, const NetPlan& np, int l, int KT, int KC16, Col
   sw.row_off = row_off; sw.nrows = nrows;
   b.add(sw);
 }
+// 16-point-wave family (x3h.h): [NT bias chunks][KC32 * NT * 3 split-plane chunks] padded to stages; NT = 16-row tiles
+void emit_dense_fwd3h(Builder& b, const NetPlan& np, int l, int NT, int KC32, ColMap cm, float mult, int row_off, int nrows) {
+  Seg sb = base_seg(np, l, SEG_BIAS_H);
+  sb.NT = NT; sb.KC = 1; sb.nchunks = NT; sb.used = NT; sb.row_off = row_off; sb.nrows = nrows;
+  b.add(sb);
+  Seg sw = base_seg(np, l, SEG_WFWD3H);
+  sw.NT = NT; sw.KC = KC32; sw.used = KC32 * NT * 3; sw.nchunks = x3h_op_chunks(NT, KC32) - NT; sw.cm = cm; sw.mult = mult;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
+void emit_dense_bwd3h(Builder& b, const NetPlan& np, int l, int KT, int KC32, ColMap cm, int row_off, int nrows, float mult) {
+  Seg sw = base_seg(np, l, SEG_WBWD3H);
+  sw.NT = KT; sw.KC = KC32; sw.used = KC32 * KT * 3; sw.nchunks = x3h_bwd_chunks(KT, KC32); sw.cm = cm; sw.mult = mult;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
+void emit_rowvec_h(Builder& b, const NetPlan& np, int l, int nrows, int NTK, ColMap cm) {
+  Seg sw = base_seg(np, l, SEG_ROWVEC_H);
+  sw.NT = nrows; sw.KC = NTK; sw.used = nrows * NTK; sw.nchunks = nrows * NTK; sw.cm = cm; sw.nrows = nrows;
+  b.add(sw);
+  Seg sc = base_seg(np, l, SEG_SCALAR);
+  sc.nchunks = rowvec_h_chunks(NTK, nrows) - nrows * NTK; sc.used = 1; sc.nrows = nrows;
+  b.add(sc);
+}
 void emit_rowvec(Builder& b, const NetPlan& np, int l, int nrows, int KC, ColMap cm) {
   Seg sw = base_seg(np, l, SEG_ROWVEC);
   sw.NT = nrows; sw.KC = KC; sw.used = nrows * KC; sw.nchunks = nrows * KC; sw.cm = cm; sw.nrows = nrows;
@@ -194,6 +218,39 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
     }
   }
   np.rev3_chunks = b.chunk - np.rev3_chunk0;
+  // the same two streams for the 16-point-wave kernels (x3h.h): 16-row tiles, 32-wide k-chunks, same ops in the same order
+  np.fwd3h_chunk0 = b.chunk;
+  if (H == 256 && F == 256) {
+    const int PE32 = cdiv(PED, 32);
+    for (int l = 0; l < L - 1; ++l) {
+      ColMap cm{HUGE_SPLIT, 0, d.in_dim[l], 0, 0};
+      int KC32 = (l == 0) ? PE32 : H / 32;
+      float mult = 1.0f;
+      if (l == d.skip_layer) { cm = ColMap{H, 0, d.in_dim[l] - PED, d.in_dim[l] - PED, PED}; KC32 += PE32; mult = 0.70710678118654752440f; }
+      emit_dense_fwd3h(b, np, l, H / 16, KC32, cm, mult, 0, d.out_dim[l]);
+    }
+    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    emit_dense_fwd3h(b, np, L - 1, F / 16, H / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1.0f, 1, F);          // feature rows
+  }
+  np.fwd3h_chunks = b.chunk - np.fwd3h_chunk0;
+  np.rev3h_chunk0 = b.chunk;
+  if (H == 256 && F == 256) {
+    const int PT = round_up(cdiv(PED, 16), 2);
+    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    emit_dense_bwd3h(b, np, L - 1, H / 16, F / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F, 1.0f);
+    np.rev3h_wsdf_chunk = b.chunk;
+    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    for (int l = L - 2; l >= 0; --l) {
+      if (l == d.skip_layer) {
+        const float rs2 = 0.70710678118654752440f;
+        emit_dense_bwd3h(b, np, l, H / 16, H / 32, ColMap{HUGE_SPLIT, 0, d.in_dim[l] - PED, 0, 0}, 0, d.out_dim[l], rs2);
+        emit_dense_bwd3h(b, np, l, PT, H / 32, ColMap{HUGE_SPLIT, d.in_dim[l] - PED, PED, 0, 0}, 0, d.out_dim[l], rs2);
+      } else {
+        emit_dense_bwd3h(b, np, l, (l == 0) ? PT : H / 16, H / 32, ColMap{HUGE_SPLIT, 0, d.in_dim[l], 0, 0}, 0, d.out_dim[l], 1.0f);
+      }
+    }
+  }
+  np.rev3h_chunks = b.chunk - np.rev3h_chunk0;
   return I2SDF_OK;
 }
 
@@ -232,6 +289,22 @@ int build_rgb(i2sdf_plan* p, Builder& b) {
     emit_dense_bwd3(b, np, 0, F / 32, H / 16, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H, 1.0f);
   }
   np.rev3_chunks = b.chunk - np.rev3_chunk0;
+  // 16-point-wave family (x3h.h): layer 0 reduces over [PE(view) padded to 32-chunks | feature]
+  np.fwd3h_chunk0 = b.chunk;
+  if (H == 256 && F == 256 && L >= 3) {
+    const int PV32 = cdiv(PED, 32);
+    emit_dense_fwd3h(b, np, 0, H / 16, PV32 + F / 32, ColMap{PV32 * 32, 0, PED, PED, F}, 1.0f, 0, H);
+    for (int l = 1; l < L - 1; ++l) emit_dense_fwd3h(b, np, l, H / 16, H / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1.0f, 0, H);
+    emit_rowvec_h(b, np, L - 1, 3, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  }
+  np.fwd3h_chunks = b.chunk - np.fwd3h_chunk0;
+  np.rev3h_chunk0 = b.chunk;
+  if (H == 256 && F == 256 && L >= 3) {
+    emit_rowvec_h(b, np, L - 1, 3, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+    for (int l = L - 2; l >= 1; --l) emit_dense_bwd3h(b, np, l, H / 16, H / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H, 1.0f);
+    emit_dense_bwd3h(b, np, 0, F / 16, H / 32, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H, 1.0f);
+  }
+  np.rev3h_chunks = b.chunk - np.rev3h_chunk0;
   return I2SDF_OK;
 }
 
@@ -306,7 +379,7 @@ extern "C" int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out) {
   if (!rc) rc = build_rgb(p, b);
   if (!rc) rc = build_light(p, b);
   if (rc) { delete p; return rc; }
-  { Seg z{}; z.type = SEG_ZERO; z.nchunks = SC; b.add(z); }   // slack: the DMA look-ahead may touch one stage past the end
+  { Seg z{}; z.type = SEG_ZERO; z.nchunks = SC > SCH ? SC : SCH; b.add(z); }   // slack: the DMA look-ahead may touch one stage past the end
   p->total_chunks = b.chunk;
   p->n_segs = (int32_t)p->segs.size();
   // Device copy of the segment table.  On a host without a GPU the plan is still usable for layout queries
@@ -504,8 +577,10 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     p->blocked_saves = value ? 1 : 0;
     return I2SDF_OK;
   }
-  if (option == I2SDF_OPT_SRC_RING) {
-    p->src_ring = value ? 1 : 0;
+  if (option == I2SDF_OPT_WAVE16) {
+    if (value < 0 || (value & ~(63 | I2SDF_W16_WG4))) return I2SDF_EINVAL;
+    if ((value & 63) && (p->sdf.fwd3h_chunks == 0 || p->rgb.fwd3h_chunks == 0)) return I2SDF_EINVAL;      // 256/256/256 nets only
+    p->wave16 = value;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_TAIL_OVERLAP) {

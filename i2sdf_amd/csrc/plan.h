@@ -5,13 +5,15 @@
 #include <stdint.h>
 #include <vector>
 #include "../../include/i2sdf.h"
-#include "x3.h"
+#include "x3h.h"
 
 namespace i2sdf {
 
 enum SegType : int32_t { SEG_ZERO = 0, SEG_BIAS = 1, SEG_WFWD = 2, SEG_WBWD = 3, SEG_ROWVEC = 4, SEG_SCALAR = 5,
                          SEG_WFWD3 = 6 /* bf16x3 split planes, K-outer order (x3.h) */,
-                         SEG_WBWD3 = 7 /* transposed weights, bf16x3 split planes, K-outer order */ };
+                         SEG_WBWD3 = 7 /* transposed weights, bf16x3 split planes, K-outer order */,
+                         // the 16-point-wave family (x3h.h): 16-row tiles, 32-wide k-chunks
+                         SEG_BIAS_H = 8, SEG_WFWD3H = 9, SEG_WBWD3H = 10, SEG_ROWVEC_H = 11 };
 
 // Column map from a padded register-space index to a source column of weight_v:
 //   kp <  split : kp < valid0 ? base0 + kp : none
@@ -47,6 +49,9 @@ struct NetPlan {
   int64_t fwd3_chunk0 = 0, fwd3_chunks = 0;    // bf16x3 forward stream: hidden layers, sdf row, feature rows (sdf net, x3.h)
   int64_t rev3_chunk0 = 0, rev3_chunks = 0;    // bf16x3 reverse stream: [w_sdf][W_feat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
   int64_t rev3_wsdf_chunk = 0;                 // where the d sdf/dx chain starts inside it
+  int64_t fwd3h_chunk0 = 0, fwd3h_chunks = 0;  // the same two streams for the 16-point-wave kernels (x3h.h)
+  int64_t rev3h_chunk0 = 0, rev3h_chunks = 0;
+  int64_t rev3h_wsdf_chunk = 0;
   int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
   int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
 };
@@ -74,7 +79,7 @@ struct i2sdf_plan {
   int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
   int32_t wgrad_bf16x2 = 0;          // I2SDF_OPT_WGRAD_BF16X2: 256x256 weight-gradient blocks with two split planes / three products
   int32_t blocked_saves = 0;         // I2SDF_OPT_BLOCKED_SAVES: saved tensors of the bf16x3 full workgroups in the blocked layout (mlp_common.h)
-  int32_t src_ring = 0;              // I2SDF_OPT_SRC_RING: saved-tensor reads of the bf16x3 kernels through the per-wave LDS DMA ring (x3r.h)
+  int32_t wave16 = 0;                // I2SDF_OPT_WAVE16: OR of I2SDF_W16_* -- kernel families on 16-point waves (x3h.h)
   int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones
   // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
   mutable hipStream_t side = nullptr;

@@ -1,0 +1,456 @@
+// bf16x3 split arithmetic (x3.h) with 16-POINT waves: two waves per SIMD.
+//
+// The K-outer ops of x3.h give a wave 32 points and v_mfma_f32_32x32x16_bf16: two accumulator sets of 128 registers each (this
+// layer, previous layer) plus operands = 400-490 registers, i.e. ONE wave per SIMD.  That wave issues in order: every stage
+// barrier, every LDS latency behind it, every wait for a saved-tensor load and every burst of B-preparation VALU work leaves
+// the matrix pipe idle (67-70 % busy in the compute-bound kernels, 27-36 % in the memory-bound sweeps), and the bytes one CU
+// keeps in flight are what four waves can issue.  Here a wave owns 16 points and multiplies with v_mfma_f32_16x16x32_bf16:
+//   tile   = 16 output features x 16 points = 4 accumulator registers (f32x4); a 256-wide layer = 16 tiles = 64 registers,
+//            two sets = 128, and the whole wave fits 256 registers -> two waves per SIMD, 8 per CU, which fill each other's stalls;
+//   k-chunk = 32 reduction indices; the D layout of a tile PAIR is the B layout of one k-chunk, so accumulators feed straight
+//            back as in x3.h (lane = point p + 16*kg, kg = lane>>4):
+//              tile nt, register r          <->  feature 16*nt + 4*kg + r
+//              k-chunk c, element j (0..7)  <->  reduction index 32*c + 16*(j>>2) + 4*kg + (j&3)  ==  tile 2c + (j>>2), register j&3
+//   weights: one chunk (64 lanes x 16 B) = the A operand (16 rows x 32 k, one split plane) of one MFMA, lane (i = lane&15, kg)
+//            holding row 16*nt + i, reduction indices of k-chunk c as above.  Same bytes per layer as the 32-point stream, read
+//            from LDS twice as often per point (48 ds_read_b128 per 96 MFMAs and wave: ~50 % of the LDS read rate of a CU).
+// Stream of one op: [NT bias chunks, fp32, D layout][for c: for g < NT/2: for split s < 3: for e < 2: chunk of tile 2g+e], padded
+// to whole stages.  The saved per-point tensors keep their layout (mlp_common.h): a lane reads / writes the 16 B at float 4*kg of
+// the 16-float groups 2c and 2c+1 of its point -- 16 points x 64 B = 1 KB contiguous per wave instruction in the blocked layout --
+// so kernels of both families can be mixed freely along a chain (and wgrad3p reads what either wrote).
+//
+// NW = waves per workgroup: 8 (one workgroup per CU, one weight stage in LDS shared by all eight waves) or 4 (two independent
+// workgroups per CU: twice the L2 -> LDS weight traffic, but their stage barriers are decoupled).
+#pragma once
+#include "x3.h"
+
+namespace i2sdf {
+
+constexpr int HP = 16;                    // points per wave
+constexpr int SCH = SC;                    // chunks per LDS stage (80 KB stages = 5 per 256x256 op instead of 13 measured no gain: the loss is not per barrier)
+constexpr int LDS_BYTES_H = LDS_BYTES;
+template <int NW> using WStreamH = WStreamT<NW * 64, SCH>;
+
+__host__ __device__ constexpr int x3h_op_chunks(int NT, int KC32) { return round_up(NT + KC32 * NT * 3, SCH); }
+__host__ __device__ constexpr int x3h_bwd_chunks(int KT, int KC32) { return round_up(KC32 * KT * 3, SCH); }
+// row vectors: [NROWS*16 chunks: lane (.,kg) of chunk (row, nt) holds w_row[16 nt + 4 kg + 0..3]][1 scalar chunk]
+__host__ __device__ constexpr int rowvec_h_chunks(int NTK, int nrows) { return round_up(nrows * NTK + 1, SCH); }
+
+__device__ __forceinline__ f32x4 mfma_bf16h(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// this lane's B-operand values of an input vector given in reduction-index order (NC32 k-chunks of 32, zero padded)
+template <int NC32>
+__device__ __forceinline__ void x3h_select(const float (&full)[NC32 * 32], float (&sel)[NC32 * 8], int kg) {
+  // bit selects (v_bfi_b32) on lane masks: written as ternaries the four-way choice becomes a table in scratch memory
+  const unsigned m1 = (kg & 1) ? 0xffffffffu : 0u, m2 = (kg & 2) ? 0xffffffffu : 0u;
+  auto pick = [](unsigned m, float a, float b) __attribute__((always_inline)) {      // m ? a : b
+    return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a) & m) | (__builtin_bit_cast(unsigned, b) & ~m));
+  };
+#pragma unroll
+  for (int c = 0; c < NC32; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int b = 32 * c + 16 * (j >> 2) + (j & 3);
+      sel[8 * c + j] = pick(m2, pick(m1, full[b + 12], full[b + 8]), pick(m1, full[b + 4], full[b]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K-outer bf16x3 op on 16-point waves:  acc[NT] (+)= W * src      (BIAS and Src as in x3.h: dense_x3g)
+// Per group: one tile pair, one split plane = two A chunks, four MFMAs (the W0*h2 pair of the sp = 0 group rides in the sp = 2
+// group), one twelfth of the next k-chunk's B preparation in every other group, the next stage's DMA pieces in the first groups.
+// ---------------------------------------------------------------------------------------------
+template <int NT, int KC32, int BIAS, int NW, class Src, bool DEFER = true>
+__device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&acc_io)[NT], int tid) {
+  using WS = WStreamH<NW>;
+  f32x4 acc[NT];
+  if (BIAS == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = acc_io[nt];
+  } else if (BIAS == 2) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  static_assert(NT % 2 == 0, "tiles are processed in pairs");
+  constexpr int NB = BIAS != 0 ? NT : 0, G = NT / 2, PPK = G * 3, NPAIR = KC32 * PPK, NWC = NPAIR * 2;
+  constexpr int TOT = round_up(NB + NWC, SCH), NS = TOT / SCH, PFP = 2;
+  static_assert(NB % 2 == 0, "bias chunks come in pairs");
+  const int lane = tid & 63;
+  float v[8], vx[8];
+  u32x4 bq[2][3];
+  u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // the weights of the sp = 0 group, kept for the deferred W0*h2 pair
+  // B preparation of a k-chunk in NU = 32 pieces of 2-6 VALU instructions, dealt evenly over the MFMA gaps of the k-chunk (96 for a 256-wide op: one piece in every third gap).
+  // Pieces 0..23: the 8 values as a three-deep software pipeline over the source functor's phases (for softplus: exp2 | log2 |
+  // fma), each phase its own piece, so that no piece waits for a transcendental of its own and none is longer than ~24 cycles: a
+  // wave that sits in a long VALU burst issues no MFMAs, and with two in-order waves per SIMD the matrix pipe idles whenever both
+  // do.  Pieces 24..31 split the 4 value pairs, two halves each (leading plane + residuals; the two lower planes).
+  constexpr int NU = 32;
+  float ra[4], rb[4], t1[2], t2[2];
+  auto prep = [&](int kc, int j, u32x4 (&b)[3]) __attribute__((always_inline)) {
+    if (kc >= KC32) return;
+    if (j == 0 && kc + 1 < KC32) src.ahead(kc + 1);
+    if (j < 24) {
+      // slot s = 0..9 holds [p3(s-2)] [p2(s-1)] [p1(s)]; the 24 valid pieces in that order
+      int s_ = 0, ph = 0, n = 0;
+      for (int s2 = 0; s2 < 10; ++s2)
+        for (int q = 0; q < 3; ++q) {
+          const int u = q == 0 ? s2 - 2 : (q == 1 ? s2 - 1 : s2);
+          if (u < 0 || u > 7) continue;
+          if (n == j) { s_ = u; ph = q; }
+          ++n;
+        }
+      const int u = s_;
+      if (ph == 0) v[u] = src.p3(kc, u, t1[u & 1], t2[u & 1], vx[u]);
+      else if (ph == 1) t2[u & 1] = src.p2(kc, u, t1[u & 1]);
+      else t1[u & 1] = src.p1(kc, u);
+    } else {
+      if (j == 24 && Src::STORES) src.done(kc, v, vx);
+      const int i = (j - 24) >> 1;
+      if (((j - 24) & 1) == 0) {
+        const unsigned p0 = pk_bf16(v[2 * i], v[2 * i + 1]);
+        ra[i] = v[2 * i] - bf16_lo(p0); rb[i] = v[2 * i + 1] - bf16_hi(p0);      // exact
+        b[0][i] = p0;
+      } else {
+        const unsigned p1 = pk_bf16(ra[i], rb[i]);
+        b[1][i] = p1;
+        b[2][i] = pk_bf16(ra[i] - bf16_lo(p1), rb[i] - bf16_hi(p1));
+      }
+    }
+  };
+  src.ahead(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) prep(0, u, bq[0]);
+  auto first_pair = [](int s) { return (s * SCH < NB) ? ((NB - s * SCH < SCH) ? (NB - s * SCH) / 2 : SCH / 2) : 0; };
+  auto end_pair = [](int s) { return (NB + NWC - s * SCH < SCH) ? ((NB + NWC - s * SCH > 0) ? (NB + NWC - s * SCH) / 2 : 0) : SCH / 2; };
+  u32x4 ring[PFP][2];                   // A operands (one pair of tiles, one split plane) read PFP groups ahead of their MFMAs
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int p0 = first_pair(s), p1 = end_pair(s);
+    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+#pragma unroll
+    for (int j = 0; j < SCH; ++j) {
+      const int c = s * SCH + j;
+      if (c < NB && BIAS == 1) acc[c] = __builtin_bit_cast(f32x4, cur[j * 64]);
+    }
+#pragma unroll
+    for (int i = 0; i < PFP; ++i)
+      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
+    int npiece = 0;
+#pragma unroll
+    for (int jp = 0; jp < SCH / 2; ++jp) {
+      if (jp >= p0 && jp < p1) {
+        const int w = (s * SCH + 2 * jp - NB) / 2;
+        const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
+        const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
+        const u32x4 (&b)[3] = bq[kc & 1];
+        if (jp + PFP < p1) {
+          ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
+          ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
+        }
+        // four units, one MFMA each, fenced: consecutive MFMAs never share an accumulator (a dependent 16x16x32 issued right behind
+        // its producer waits out the pipeline latency), and the group's other work is dealt behind them instead of clustering
+        const int pi = w % PPK;
+        auto gap = [&](int q) __attribute__((always_inline)) {        // MFMA gap 4*pi + q of the k-chunk (4*PPK gaps): piece j sits in gap j*4*PPK/NU
+          const int gi = 4 * pi + q;
+#pragma unroll
+          for (int j = 0; j < NU; ++j)
+            if (j * (4 * PPK) / NU == gi) prep(kc + 1, j, bq[(kc + 1) & 1]);
+        };
+        acc[nt] = mfma_bf16h(a0, b[0], acc[nt]);
+        gap(0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[nt + 1] = mfma_bf16h(a1, b[0], acc[nt + 1]);
+        gap(1);
+        __builtin_amdgcn_sched_barrier(0);
+        // DEFER: the W0*h2 pair of the sp = 0 group rides in the sp = 2 group (four MFMAs in every group), its weights kept in d0 / d1;
+        // without it (8 registers less) the sp = 0 group has six MFMAs and the sp = 2 group two
+        if (DEFER && sp == 0) { d0 = a0; d1 = a1; }
+        if (sp < 2) acc[nt] = mfma_bf16h(a0, b[1], acc[nt]);
+        else if (DEFER) acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
+        if (npiece < WS::NPIECE) {          // next stage's DMA: one piece per group, from the first group on
+          ws.issue_piece(npiece, tid); ++npiece;
+        }
+        gap(2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sp < 2) acc[nt + 1] = mfma_bf16h(a1, b[1], acc[nt + 1]);
+        else if (DEFER) acc[nt + 1] = mfma_bf16h(d1, b[2], acc[nt + 1]);
+        if (!DEFER && sp == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          acc[nt] = mfma_bf16h(a0, b[2], acc[nt]);
+          __builtin_amdgcn_sched_barrier(0);
+          acc[nt + 1] = mfma_bf16h(a1, b[2], acc[nt + 1]);
+        }
+        gap(3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WS::NPIECE; ++i)
+      if (i >= npiece) ws.issue_piece(i, tid);
+    ws.advance_done();
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc_io[nt] = acc[nt];
+}
+
+// apply a source to every k-chunk without a consuming op (the last epilogue of a chain: loads, products, stores)
+template <int KC32, class Src>
+__device__ __forceinline__ void x3h_drain(Src& src) {
+  float v[8], vx[8];
+  src.ahead(0);
+#pragma unroll
+  for (int kc = 0; kc < KC32; ++kc) {
+    if (kc + 1 < KC32) src.ahead(kc + 1);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const float a1 = src.p1(kc, u); v[u] = src.p3(kc, u, a1, src.p2(kc, u, a1), vx[u]); }
+    src.done(kc, v, vx);
+  }
+}
+
+// Row-vector op on the D-layout activations of a 16-point wave: out[row] = sum_k w_row[k] * in[k] (+ scalar).
+// in[4*nt + r] = value of feature 16*nt + 4*kg + r; the four kg groups of a point are summed by two lane exchanges.
+template <int NROWS, int NTK, int NW>
+__device__ __forceinline__ void rowvec_h(WStreamH<NW>& ws, const float (&in)[NTK * 4], float (&out)[NROWS], int tid) {
+  constexpr int TOT = rowvec_h_chunks(NTK, NROWS), NS = TOT / SCH, NWC = NROWS * NTK;
+  const int lane = tid & 63;
+  float part[NROWS];
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) part[r] = 0.f;
+  f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+#pragma unroll
+    for (int j = 0; j < SCH; ++j) {
+      const int c = s * SCH + j;
+      if (c < NWC) {
+        const int row = c / NTK, nt = c % NTK;
+        const f32x4 w = cur[j * 64];
+        part[row] = fmaf(w.x, in[nt * 4 + 0], part[row]);
+        part[row] = fmaf(w.y, in[nt * 4 + 1], part[row]);
+        part[row] = fmaf(w.z, in[nt * 4 + 2], part[row]);
+        part[row] = fmaf(w.w, in[nt * 4 + 3], part[row]);
+      } else if (c == NWC) {
+        sc = cur[j * 64];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NROWS; ++r) {
+    float x = part[r] + __shfl_xor(part[r], 16);
+    x += __shfl_xor(x, 32);
+    out[r] = x + (r == 0 ? sc.x : r == 1 ? sc.y : r == 2 ? sc.z : sc.w);
+  }
+}
+
+// two f32x4 of a saved row: this lane's 8 reduction indices of k-chunk c (kcs = floats between consecutive 16-float groups of the
+// row: 16 point-major, 512 blocked)
+__device__ __forceinline__ void x3h_load8(const float* row, int c, int kg, f32x4 (&q)[2], int kcs) {
+  q[0] = *reinterpret_cast<const f32x4*>(row + kcs * (2 * c) + 4 * kg);
+  q[1] = *reinterpret_cast<const f32x4*>(row + kcs * (2 * c + 1) + 4 * kg);
+}
+__device__ __forceinline__ void x3h_store8(float* row, int c, int kg, const float (&v)[8], int kcs) {
+  *reinterpret_cast<f32x4*>(row + kcs * (2 * c) + 4 * kg) = f32x4{v[0], v[1], v[2], v[3]};
+  *reinterpret_cast<f32x4*>(row + kcs * (2 * c + 1) + 4 * kg) = f32x4{v[4], v[5], v[6], v[7]};
+}
+
+// B-operand sources (the twins of x3.h's) ---------------------------------------------------------------------------------
+// softplus100 of the previous layer's pre-activations for k-chunks < KACC, this lane's PE values beyond; stores h
+template <int NT, int KACC, int NPE, bool ST = true>
+struct XhFwdSrc {
+  static constexpr bool STORES = ST;
+  const f32x4 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int kg; bool valid; int kcs = 16;
+  __device__ __forceinline__ void ahead(int) {}
+  // softplus100 in three phases (common.h: softplus100): z = exp2(-|a| c) | l = log2(1 + z) | h = l k + max(a, 0)
+  __device__ __forceinline__ float pre(int kc, int u) const { return accP[(2 * kc + (u >> 2)) < NT ? (2 * kc + (u >> 2)) : 0][u & 3]; }
+  __device__ __forceinline__ float p1(int kc, int u) {
+    return kc < KACC ? __builtin_amdgcn_exp2f(-fabsf(pre(kc, u)) * (100.f * 1.44269504088896341f)) : 0.f;
+  }
+  __device__ __forceinline__ float p2(int kc, int, float z) { return kc < KACC ? __builtin_amdgcn_logf(1.0f + z) : 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float l, float&) {
+    if (kc < KACC) return fmaf(l, 0.693147180559945309f * 0.01f, relu0(pre(kc, u)));
+    return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (kc < KACC && hrow != nullptr && valid) x3h_store8(hrow, kc, kg, v, kcs);
+  }
+};
+// values held in registers in D layout order (register 4*nt + r <-> feature 16*nt + 4*kg + r; k-chunk c = registers 8c .. 8c+7)
+template <int NREG>
+struct XhRegSrc {
+  static constexpr bool STORES = false;
+  const float (&r)[NREG];
+  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return r[8 * kc + u]; }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+};
+
+// reverse chain (d sdf/dx): abar = (previous op's accumulators) * sigma(h), h re-read from the saved tensor; stores abar
+template <int NT>
+struct XhRevSrc {
+  static constexpr bool STORES = true;
+  const f32x4 (&accP)[NT]; const float* hrow; float* abrow; int kg; bool valid; int kcs = 16;
+  f32x4 hq[2][2];
+  __device__ __forceinline__ void ahead(int kc) { x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); }
+  __device__ __forceinline__ float p1(int kc, int u) { return __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]); }
+  __device__ __forceinline__ float p2(int, int, float e) { return 1.0f - e; }                      // sigma = 1 - exp(-100 h)
+  __device__ __forceinline__ float p3(int kc, int u, float, float sg, float&) { return accP[2 * kc + (u >> 2)][u & 3] * sg; }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (abrow != nullptr && valid) x3h_store8(abrow, kc, kg, v, kcs);
+  }
+};
+// sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
+//                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
+template <int NT, int KACC, int NREG>
+struct XhSweep1Src {
+  static constexpr bool STORES = true;
+  const f32x4 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers (G(pbar) in this lane's B order)
+  const float* hrow; const float* arow; float* g2row; float* gurow; int kg; bool valid; int kcs = 16;
+  f32x4 hq[2][2], aq[2][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    if (kc < KACC) { x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); x3h_load8(arow, kc, kg, aq[kc & 1], kcs); }
+  }
+  __device__ __forceinline__ float p1(int kc, int u) {
+    return kc < KACC ? __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]) : 0.f;      // e = 1 - sigma
+  }
+  __device__ __forceinline__ float p2(int kc, int u, float e) { return kc < KACC ? aq[kc & 1][u >> 2][u & 3] * (100.f * e) : 0.f; }      // abar 100 (1 - sigma)
+  __device__ __forceinline__ float p3(int kc, int u, float e, float ae, float& g2) {
+    g2 = 0.f;
+    if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
+    const float ga = accP[(2 * kc + (u >> 2)) < NT ? (2 * kc + (u >> 2)) : 0][u & 3];
+    g2 = ga * ae;
+    return ga * (1.0f - e);
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
+    if (kc < KACC && valid) { x3h_store8(gurow, kc, kg, v, kcs); x3h_store8(g2row, kc, kg, g2, kcs); }
+  }
+};
+// sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
+template <int NT, bool TOP>
+struct XhSweep2Src {
+  static constexpr bool STORES = true;
+  const f32x4 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int kg; bool valid;
+  float sb; const float* wsdf;        // TOP: w_sdf in row-vector stream layout (chunk nt = 64 lanes x 16 B), + lane*4 applied
+  int kcs = 16;
+  f32x4 hq[2][2], gq[2][2], wq[2][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); x3h_load8(g2row, kc, kg, gq[kc & 1], kcs);
+    if (TOP) {
+      wq[kc & 1][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
+      wq[kc & 1][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
+    }
+  }
+  __device__ __forceinline__ float p1(int kc, int u) { return __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]); }
+  __device__ __forceinline__ float p2(int, int, float e) { return 1.0f - e; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float sg, float&) {
+    float x = accP[2 * kc + (u >> 2)][u & 3];
+    if (TOP) x = fmaf(sb, wq[kc & 1][u >> 2][u & 3], x);
+    return fmaf(x, sg, gq[kc & 1][u >> 2][u & 3]);
+  }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (valid) x3h_store8(grow, kc, kg, v, kcs);
+  }
+};
+// a point-major row in global memory (or zeros) as B operand
+struct XhRowSrc {
+  static constexpr bool STORES = false;
+  const float* row; int kg; bool on;
+  f32x4 q[2][2];
+  __device__ __forceinline__ void ahead(int kc) {
+    if (on) x3h_load8(row, kc, kg, q[kc & 1], 16);
+    else { q[kc & 1][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc & 1][u >> 2][u & 3]; }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+};
+// ---- radiance net ----------------------------------------------------------------------------------------------------
+// ReLU of the previous layer's pre-activations; stores the activations r (saved tensor)
+template <int NT>
+struct XhReluSrc {
+  static constexpr bool STORES = true;
+  const f32x4 (&accP)[NT]; float* rrow; int kg; bool valid; int kcs = 16;
+  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return relu0(accP[2 * kc + (u >> 2)][u & 3]); }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (rrow != nullptr && valid) x3h_store8(rrow, kc, kg, v, kcs);
+  }
+};
+// layer-0 input of the radiance net: NPV k-chunks of PE(view dir) held in registers, then the feature row from global memory
+template <int NPV>
+struct XhPeRowSrc {
+  static constexpr bool STORES = false;
+  const float (&pe)[NPV * 8]; const float* row; int kg;
+  f32x4 q[2][2];
+  __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3h_load8(row, kc - NPV, kg, q[kc & 1], 16); }
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc & 1][u >> 2][u & 3]; }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+};
+// radiance backward: G(a_l) = (previous op's accumulators) where the saved activation r is positive; stores G(a_l)
+template <int NT>
+struct XhMaskSrc {
+  static constexpr bool STORES = true;
+  const f32x4 (&accP)[NT]; const float* rrow; float* grow; int kg; bool valid; int kcs = 16;
+  f32x4 q[2][2];
+  __device__ __forceinline__ void ahead(int kc) { x3h_load8(rrow, kc, kg, q[kc & 1], kcs); }
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc & 1][u >> 2][u & 3] > 0.f ? accP[2 * kc + (u >> 2)][u & 3] : 0.f; }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (valid) x3h_store8(grow, kc, kg, v, kcs);
+  }
+};
+
+// D-layout registers (register 4*nt + r <-> feature 16*nt + 4*kg + r) <-> a saved row (kcs as above) / a point-major row (kcs = 16)
+template <int NTK>
+__device__ __forceinline__ void store_regs_h(float* __restrict__ row, int kg, bool valid, const float (&r)[NTK * 4], int kcs) {
+  if (!valid) return;
+#pragma unroll
+  for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + nt * kcs + 4 * kg) = f32x4{r[4 * nt], r[4 * nt + 1], r[4 * nt + 2], r[4 * nt + 3]};
+}
+template <int NTK>
+__device__ __forceinline__ void load_regs_h(const float* __restrict__ row, int kg, float (&r)[NTK * 4], int kcs) {
+#pragma unroll
+  for (int nt = 0; nt < NTK; ++nt) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(row + nt * kcs + 4 * kg);
+    r[4 * nt] = v.x; r[4 * nt + 1] = v.y; r[4 * nt + 2] = v.z; r[4 * nt + 3] = v.w;
+  }
+}
+template <int NTK>
+__device__ __forceinline__ void store_tile_h(float* __restrict__ row, int kg, bool valid, const f32x4 (&t)[NTK]) {
+  if (!valid) return;
+#pragma unroll
+  for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + 16 * nt + 4 * kg) = t[nt];
+}
+// read a row vector (rowvec_h layout) into D-layout order registers w[4*nt + r] = w_row[16 nt + 4 kg + r]; also the scalar chunk
+template <int NTK, int NW>
+__device__ __forceinline__ void rowvec_h_load(WStreamH<NW>& ws, float (&w)[NTK * 4], f32x4& scalars, int tid) {
+  constexpr int TOT = rowvec_h_chunks(NTK, 1), NS = TOT / SCH;
+  const int lane = tid & 63;
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
+#pragma unroll
+    for (int j = 0; j < SCH; ++j) {
+      const int c = s * SCH + j;
+      if (c < NTK) {
+        const f32x4 v = cur[j * 64];
+        w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
+      } else if (c == NTK) {
+        scalars = cur[j * 64];
+      }
+    }
+  }
+}
+
+}  // namespace i2sdf

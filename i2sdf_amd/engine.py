@@ -42,15 +42,16 @@ class RenderEngine:
                 self.set_sdf_backward_bf16x3(True)
             if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
                 self.set_rgb_bf16x3(True)
-        self.src_ring = False
-        if cfg.bf16x3 and os.environ.get("I2SDF_SRC_RING", "0") != "0":       # off by default (no gain measured); I2SDF_SRC_RING=1 for A/B runs
-            self.set_src_ring(True)
         self.wgrad_bf16x2 = False
         if cfg.bf16x3 and os.environ.get("I2SDF_WGRAD_BF16X2", "0") != "0":   # opt-in (see include/i2sdf.h); bench.py reports it as a sub-record
             self.set_wgrad_bf16x2(True)
         self.blocked_saves = False
         if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
             self.set_blocked_saves(True)
+        # kernel families on 16-point waves, two waves per SIMD (include/i2sdf.h: I2SDF_OPT_WAVE16; csrc/x3h.h); I2SDF_WAVE16=<mask> for A/B runs
+        self.wave16 = 0
+        if cfg.bf16x3 and cfg.sdf.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.hidden == 256 and cfg.rgb.n_lin >= 3:
+            self.set_wave16(int(os.environ.get("I2SDF_WAVE16", str(L.W16_DEFAULT))))
         self.tail_overlap = False
         if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
             self.set_tail_overlap(True)
@@ -173,15 +174,15 @@ class RenderEngine:
         out[:, :n_blocked] = t[:, :n_blocked].reshape(Lr, n_blocked // 32, 16, 32, 16).permute(0, 1, 3, 2, 4).reshape(Lr, n_blocked, 256)
         return out
 
-    def set_src_ring(self, on: bool):
-        """Saved-tensor reads of the bf16x3 kernels through the per-wave LDS DMA ring (I2SDF_OPT_SRC_RING, csrc/x3r.h)."""
-        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SRC_RING, int(bool(on))), "i2sdf_plan_set_option")
-        self.src_ring = bool(on)
-
     def set_tail_overlap(self, on: bool):
         """Split-K tail workgroups on the plan's side stream, concurrent with the full workgroups (I2SDF_OPT_TAIL_OVERLAP)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TAIL_OVERLAP, int(bool(on))), "i2sdf_plan_set_option")
         self.tail_overlap = bool(on)
+
+    def set_wave16(self, mask: int):
+        """Which bf16x3 kernel families run on 16-point waves (I2SDF_OPT_WAVE16: OR of lib.W16_*; 0 = all on 32-point waves)."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_WAVE16, int(mask)), "i2sdf_plan_set_option")
+        self.wave16 = int(mask)
 
     def set_parts(self, n: int):
         """Cut the per-point entry points into n point ranges, each on its own stream (I2SDF_OPT_PARTS; 0 / 1 = off).  Change it only

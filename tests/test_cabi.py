@@ -65,8 +65,8 @@ def test_plan_layout_sizes(lib):
             assert lay.n_params == n_params          # SURVEY.md appendix B [probed on the reference]
         pack = h.i2sdf_plan_pack_floats(plan)
         # fp32 forward + transposed streams hold every weight about twice; the bf16x3 forward / reverse streams of the SDF net
-        # add 1.5x each; plus stage padding
-        assert 2 * lay.n_params * 0.9 < pack < 5 * lay.n_params * 1.2 + 128 * 8192
+        # add 1.5x each, and so do their 16-point-wave twins (256-wide nets); plus stage padding
+        assert 2 * lay.n_params * 0.9 < pack < 8 * lay.n_params * 1.2 + 128 * 8192
         assert h.i2sdf_plan_wgrad_floats(plan) >= lay.n_params - 1
         h.i2sdf_plan_destroy(plan)
 
@@ -141,8 +141,11 @@ def test_new_plan_options_and_blocked_prefix(lib):
     h = lib.load()
     rc, plan, _, _ = _plan(lib, synthetic_conf())
     assert rc == 0
-    for opt in (lib.OPT_SRC_RING, lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2):
+    for opt in (lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0 and h.i2sdf_plan_set_option(plan, opt, 0) == 0
+    assert h.i2sdf_plan_set_option(plan, 64, 1) != 0           # (the LDS source ring of rounds 2-3 is gone)
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 63) == 0 and h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 0) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 64) != 0
     for opt in (lib.OPT_TRAIN_FWD_BF16X3, lib.OPT_SDF_BWD_BF16X3, lib.OPT_RGB_BF16X3, lib.OPT_TAIL_OVERLAP):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0
     M = 1024 * 98 + 1024 * 2                                   # the training batch: 98 shaded + 2 eikonal points per ray
