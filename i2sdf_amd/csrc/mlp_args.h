@@ -62,12 +62,10 @@ struct RgbBwdArgs {
   int wg0 = 0;              // first 128-point workgroup of this launch
 };
 
-// bf16x3 twins: launch over `grid` workgroups of 128 points -- four 32-point waves (mlp_x3.hip) or eight 16-point waves (mlp_x3h.hip)
-void i2sdf_launch_train_fwd3(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st);
+// bf16x3 kernels: launch over `grid` workgroups of 128 points -- four 32-point waves (mlp_x3.hip: d sdf/dx chain, sweeps) or eight 16-point
+// waves (mlp_x3h.hip: forward with saves, radiance net)
+void i2sdf_launch_igrad3(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_rgb_fwd3(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_rgb_bwd3(const RgbBwdArgs& a, unsigned grid, hipStream_t st);
-void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st, int nw);
-void i2sdf_launch_sdf_bwd3h(const SdfBwdArgs& a, unsigned grid, hipStream_t st, int nw);
+void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st);

@@ -404,6 +404,7 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
     const int64_t bulk = split_bulk_points(M, p->n_cu);
     // full workgroups in bf16x3 split arithmetic (two launches); needs at least one plain hidden layer above the skip layer
     const bool x3 = p->sdf_bwd_bf16x3 != 0 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
+    ChainGuard guard(p, st, x3 && i2sdf_parts_on(p));
     auto launch3 = [&](unsigned g) {
       SdfBwdArgs a3 = a;
       a3.fwd = base + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;
@@ -411,13 +412,7 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       a3.n_fwd = sdf_fwd3_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
       a3.n_rev = sdf_rev3_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
       a3.kcs = sdf_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
-      if (p->wave16 & I2SDF_W16_SWEEPS) {          // 16-point waves (x3h.h): their own streams, same tensors
-        a3.fwd = base + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;
-        a3.rev = base + p->sdf.rev3h_chunk0 * CHUNK_FLOATS;
-        a3.n_fwd = sdf_fwd3h_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
-        a3.n_rev = sdf_rev3h_bwd_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip);
-        i2sdf_launch_sdf_bwd3h(a3, g, st, (p->wave16 & I2SDF_W16_WG4) ? 4 : 8);
-      } else i2sdf_launch_sdf_bwd3(a3, g, st);
+      i2sdf_launch_sdf_bwd3(a3, g, st);
     };
     if (x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun): both sweeps of a range on the range's stream
       PartRun pr;
@@ -463,20 +458,17 @@ extern "C" int i2sdf_rgb_backward(const i2sdf_plan* p, const float* packed, cons
   a.L = d.n_lin; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rgb_bar = rgb_bar; a.rs = rs; a.gar = gar; a.ga_last = ga_last; a.fbar = fbar;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  ChainGuard guard(p, st, d.hidden == 256 && p->F == 256 && p->rgb_bf16x3 && i2sdf_parts_on(p));
   if (d.hidden == 256 && p->F == 256) {
     a.n_rev = rgb_rev_stages(256, 256, d.n_lin);
     const int64_t bulk = split_bulk_points(M, p->n_cu);
     auto full = [&](const RgbBwdArgs& x, unsigned g) {
       if (p->rgb_bf16x3) {
         RgbBwdArgs x3 = x;
-        x3.rev = packed + p->scale_floats + p->rgb.rev3_chunk0 * CHUNK_FLOATS;
-        x3.n_rev = rgb_rev3_stages(256, 256, d.n_lin);
+        x3.rev = packed + p->scale_floats + p->rgb.rev3h_chunk0 * CHUNK_FLOATS;          // 16-point waves (x3h.h)
+        x3.n_rev = rgb_rev3h_stages(256, 256, d.n_lin);
         x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
-        if (p->wave16 & I2SDF_W16_RGB_BWD) {         // 16-point waves (x3h.h)
-          x3.rev = packed + p->scale_floats + p->rgb.rev3h_chunk0 * CHUNK_FLOATS;
-          x3.n_rev = rgb_rev3h_stages(256, 256, d.n_lin);
-          i2sdf_launch_rgb_bwd3h(x3, g, st);
-        } else i2sdf_launch_rgb_bwd3(x3, g, st);
+        i2sdf_launch_rgb_bwd3h(x3, g, st);
       } else {
         launch_lds(rgb_bwd_kernel<256, 256>, g, st, x);
       }

@@ -103,9 +103,6 @@ __host__ __device__ constexpr int sdf_fwd3_stages(int H, int PED, int L, bool ha
   c += rowvec_chunks(H / 8, 1);
   return c / SC;
 }
-__host__ __device__ constexpr int sdf_fwd3_train_stages(int H, int F, int PED, int L, bool has_skip, bool full) {
-  return sdf_fwd3_stages(H, PED, L, has_skip) + (full ? x3_op_chunks(F / 32, H / 16) / SC : 0);
-}
 __host__ __device__ constexpr int x3_bwd_chunks(int KT, int KC16) { return round_up(KC16 * KT * 3, SC); }
 __host__ __device__ constexpr int sdf_rev3_stages(int H, int PEC, int L, bool has_skip) {
   const int PT = cdiv(PEC * 8, 32);
@@ -126,12 +123,6 @@ __host__ __device__ constexpr int sdf_rev3_bwd_stages(int H, int F, int PEC, int
   if (has_skip) c += x3_bwd_chunks(PT, H / 16);
   return c / SC;
 }
-__host__ __device__ constexpr int rgb_fwd3_stages(int H, int F, int PEDV, int L) {
-  return (x3_op_chunks(H / 32, cdiv(PEDV, 16) + F / 16) + (L - 2) * x3_op_chunks(H / 32, H / 16) + rowvec_chunks(H / 8, 3)) / SC;
-}
-__host__ __device__ constexpr int rgb_rev3_stages(int H, int F, int L) {
-  return (rowvec_chunks(H / 8, 3) + (L - 2) * x3_bwd_chunks(H / 32, H / 16) + x3_bwd_chunks(F / 32, H / 16)) / SC;
-}
 // ---- 16-point-wave family (x3h.h): same ops, 16-row tiles / 32-wide k-chunks -- must mirror plan.cpp
 __host__ __device__ constexpr int sdf_fwd3h_stages(int H, int PED, int L, bool has_skip) {
   const int PE32 = cdiv(PED, 32);
@@ -143,25 +134,6 @@ __host__ __device__ constexpr int sdf_fwd3h_stages(int H, int PED, int L, bool h
 }
 __host__ __device__ constexpr int sdf_fwd3h_train_stages(int H, int F, int PED, int L, bool has_skip, bool full) {
   return sdf_fwd3h_stages(H, PED, L, has_skip) + (full ? x3h_op_chunks(F / 16, H / 32) / SCH : 0);
-}
-__host__ __device__ constexpr int sdf_fwd3h_hidden_stages(int H, int PED, int L, bool has_skip) {
-  return sdf_fwd3h_stages(H, PED, L, has_skip) - rowvec_h_chunks(H / 16, 1) / SCH;
-}
-__host__ __device__ constexpr int pe_tiles_h(int PED) { return round_up(cdiv(PED, 16), 2); }
-__host__ __device__ constexpr int sdf_rev3h_stages(int H, int PED, int L, bool has_skip) {      // d sdf/dx chain: from the second w_sdf copy on
-  const int PT = pe_tiles_h(PED);
-  int c = rowvec_h_chunks(H / 16, 1);
-  for (int l = L - 2; l >= 1; --l) c += x3h_bwd_chunks(H / 16, H / 32);
-  if (has_skip) c += x3h_bwd_chunks(PT, H / 32);
-  c += x3h_bwd_chunks(PT, H / 32);
-  return c / SCH;
-}
-__host__ __device__ constexpr int sdf_rev3h_bwd_stages(int H, int F, int PED, int L, bool has_skip) {   // sweep 2: from W_feat^T down to W_1^T
-  const int PT = pe_tiles_h(PED);
-  int c = 2 * rowvec_h_chunks(H / 16, 1) + x3h_bwd_chunks(H / 16, F / 32);
-  for (int l = L - 2; l >= 1; --l) c += x3h_bwd_chunks(H / 16, H / 32);
-  if (has_skip) c += x3h_bwd_chunks(PT, H / 32);
-  return c / SCH;
 }
 __host__ __device__ constexpr int rgb_fwd3h_stages(int H, int F, int PEDV, int L) {
   return (x3h_op_chunks(H / 16, cdiv(PEDV, 32) + F / 32) + (L - 2) * x3h_op_chunks(H / 16, H / 32) + rowvec_h_chunks(H / 16, 3)) / SCH;

@@ -9,8 +9,8 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
                            float* sdf_out, unsigned grid, hipStream_t st);
 
-void i2sdf_launch_sdf_fwd3h(int nw, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
-                            float* sdf_out, hipStream_t st);
+void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M, float* sdf_out,
+                            hipStream_t st);
 
 namespace {
 
@@ -71,14 +71,14 @@ int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, c
   const i2sdf_mlp_desc& d = p->sdf.d;
   const float* stream = packed + p->scale_floats + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
   const bool full = feat_out != nullptr;
-  if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && H == 256 && (p->wave16 & I2SDF_W16_SDF_FWD) && p->sdf.fwd3h_chunks > 0) {
-    // 16-point waves, two per SIMD (x3h.h)
+  if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && H == 256 && p->sdf.fwd3h_chunks > 0) {
+    // 256-wide nets: 16-point waves, two per SIMD (x3h.h)
     const float* s3 = packed + p->scale_floats + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;
     const int ns3 = sdf_fwd3h_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
-    i2sdf_launch_sdf_fwd3h((p->wave16 & I2SDF_W16_WG4) ? 4 : 8, s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, st);
+    i2sdf_launch_sdf_fwd3h(s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, st);
     return i2sdf_hip_check(hipGetLastError(), "sdf_forward (bf16x3, 16-point waves) launch");
   }
-  if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && p->sdf.fwd3_chunks > 0) {
+  if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && H == 64 && p->sdf.fwd3_chunks > 0) {
     const float* s3 = packed + p->scale_floats + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;
     const int ns3 = sdf_fwd3_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
     i2sdf_launch_sdf_fwd3(H, s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st);

@@ -384,28 +384,21 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     if (grad) launch_lds(sdf_train_fwd_kernel<HH, FF, 6, true>, G_, st, a);                          \
     else launch_lds(sdf_train_fwd_kernel<HH, FF, 6, false>, G_, st, a);                              \
   } while (0)
-  // full workgroups in bf16x3 split arithmetic (x3.h); the split-K tail keeps the fp32 MFMA kernel
+  // full workgroups in bf16x3 split arithmetic: the forward with saves on 16-point waves (x3h.h, mlp_x3h.hip), the d sdf/dx chain on
+  // 32-point waves (x3.h, mlp_x3.hip) -- both read / write the same saved tensors; the split-K tail keeps the fp32 MFMA kernel
 #define LAUNCH3(G_)                                                                                  \
   do {                                                                                               \
     SdfTrainFwdArgs a3 = a;                                                                          \
-    a3.fwd = base + p->sdf.fwd3_chunk0 * CHUNK_FLOATS;                                               \
-    a3.rev = base + p->sdf.rev3_wsdf_chunk * CHUNK_FLOATS;                                               \
-    a3.n_fwd = sdf_fwd3_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);      \
+    a3.fwd = base + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;                                              \
+    a3.rev = base + p->sdf.rev3_wsdf_chunk * CHUNK_FLOATS;                                           \
+    a3.n_fwd = sdf_fwd3h_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);     \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
     a3.kcs = sdf_blocked_points(p, M, Mp, feat != nullptr) > 0 ? KCS_BLK : KCS_PM;                   \
-    SdfTrainFwdArgs ah = a3;          /* 16-point waves (x3h.h): their own streams, same tensors */    \
-    ah.fwd = base + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;                                              \
-    ah.rev = base + p->sdf.rev3h_wsdf_chunk * CHUNK_FLOATS;                                          \
-    ah.n_fwd = sdf_fwd3h_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);     \
-    ah.n_rev = sdf_rev3h_stages(256, PE<6>::DIM, d.n_lin, has_skip);                                 \
-    const bool hf = (p->wave16 & I2SDF_W16_TRAIN_FWD) != 0, hg = (p->wave16 & I2SDF_W16_IGRAD) != 0;  \
-    const int nw16 = (p->wave16 & I2SDF_W16_WG4) ? 4 : 8;                                            \
-    if (hf) i2sdf_launch_train_fwd3h(ah, true, false, G_, st, nw16);                                    \
-    else i2sdf_launch_train_fwd3(a3, true, false, G_, st);                                           \
-    if (grad && hg) i2sdf_launch_train_fwd3h(ah, false, true, G_, st, nw16);                               \
-    else if (grad) i2sdf_launch_train_fwd3(a3, false, true, G_, st);                                 \
+    i2sdf_launch_train_fwd3h(a3, G_, st);                                                            \
+    if (grad) i2sdf_launch_igrad3(a3, G_, st);                                                       \
   } while (0)
   const bool x3 = p->train_fwd_bf16x3 != 0 && p->H == 256 && p->F == 256 && d.n_lin >= 4 && d.skip_layer != d.n_lin - 2;
+  ChainGuard guard(p, st, x3 && i2sdf_parts_on(p));
   if (x3 && i2sdf_parts_on(p)) {
     // point ranges (plan.h: PartRun): one launch pair per range, each on the range's own stream; no split-K tail
     PartRun pr;
@@ -461,6 +454,7 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
   a.L = d.n_lin; a.dirs = dirs; a.n_per_ray = n_per_ray; a.feat = feat; a.M = M; a.Mp = Mp; a.rgb = rgb; a.rs = rs; a.pev_save = pev_save;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  ChainGuard guard(p, st, d.hidden == 256 && p->F == 256 && p->rgb_bf16x3 && i2sdf_parts_on(p));
   if (d.hidden == 256 && p->F == 256) {
     a.n_fwd = rgb_fwd_stages(256, 256, PE<4>::PEC, d.n_lin);
     const int64_t bulk = split_bulk_points(M, p->n_cu);
@@ -468,14 +462,10 @@ extern "C" int i2sdf_rgb_forward(const i2sdf_plan* p, const float* packed, const
     auto full = [&](const RgbFwdArgs& x, unsigned g) {
       if (p->rgb_bf16x3) {
         RgbFwdArgs x3 = x;
-        x3.fwd = packed + p->scale_floats + p->rgb.fwd3_chunk0 * CHUNK_FLOATS;
         x3.kcs = rgb_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
-        x3.n_fwd = rgb_fwd3_stages(256, 256, PE<4>::DIM, d.n_lin);
-        if (p->wave16 & I2SDF_W16_RGB_FWD) {          // 16-point waves (x3h.h)
-          x3.fwd = packed + p->scale_floats + p->rgb.fwd3h_chunk0 * CHUNK_FLOATS;
-          x3.n_fwd = rgb_fwd3h_stages(256, 256, PE<4>::DIM, d.n_lin);
-          i2sdf_launch_rgb_fwd3h(x3, g, st);
-        } else i2sdf_launch_rgb_fwd3(x3, g, st);
+        x3.fwd = packed + p->scale_floats + p->rgb.fwd3h_chunk0 * CHUNK_FLOATS;
+        x3.n_fwd = rgb_fwd3h_stages(256, 256, PE<4>::DIM, d.n_lin);
+        i2sdf_launch_rgb_fwd3h(x3, g, st);
       } else {
         launch_lds(rgb_fwd_kernel<256, 256, 4>, g, st, x);
       }

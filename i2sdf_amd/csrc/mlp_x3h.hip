@@ -1,6 +1,7 @@
-// The bf16x3 MLP kernels on 16-point waves (x3h.h): two waves per SIMD instead of one.  Same results as the 32-point kernels of
-// mlp_x3.hip up to the summation order inside an MFMA (the reduction index is dealt to the MFMA k-slots differently), same saved-tensor
-// layouts, same 1e-4 parity tests.  Built with the lifted unroll cap like mlp_x3.hip (build.sh).
+// The bf16x3 kernels that run on 16-point waves (x3h.h), two waves per SIMD: the sdf-only forward (sampler passes, grid queries), the SDF
+// forward with saves, the radiance net forward and backward -- the families that measured 4-8 % faster than their 32-point-wave
+// predecessors (round 4, profiles/r4_wave16_experiments.txt; the d sdf/dx chain and the backward sweeps did not and stay in mlp_x3.hip).
+// Same saved-tensor layouts as the 32-point kernels, so both families mix along a chain.  Built with the lifted unroll cap (build.sh).
 #define I2SDF_RELU_ASM 1      // common.h: relu0
 #include "mlp_args.h"
 #include "x3h.h"
@@ -19,7 +20,7 @@ __device__ __forceinline__ void pe_select_h(float px, float py, float pz, float 
   x3h_select<PE32>(pad, pe, kg);
 }
 
-// sdf-only forward (sampler passes, grid queries): twin of sdf_fwd3_kernel
+// sdf-only forward (sampler passes, grid queries) of the 256-wide net; 64-wide nets: sdf_fwd3_kernel, mlp_x3.hip
 template <int H, int LF, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void sdf_fwd3h_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
                                                                 const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out) {
@@ -71,7 +72,7 @@ __device__ __forceinline__ void store_pe_row_h(float* __restrict__ row, int kg, 
                                                                sel[8 * (j >> 1) + 4 * (j & 1) + 2], sel[8 * (j >> 1) + 4 * (j & 1) + 3]};
 }
 
-// SDF forward with saves (twin of sdf_train_fwd3_kernel): hidden activations -> hs, sdf, feature rows
+// SDF forward with saves: hidden activations -> hs, sdf, feature rows (the d sdf/dx chain is sdf_igrad3_kernel, mlp_x3.hip)
 template <int H, int F, int LF, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwdArgs a) {
   constexpr int NT = H / 16, KH32 = H / 32, PEC = PE<LF>::PEC, PE32 = cdiv(PE<LF>::DIM, 32), NPE = PE32 * 8, FT = F / 16;
@@ -122,206 +123,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwd
   }
 }
 
-// d sdf/dx chain (twin of sdf_igrad3_kernel)
-template <int H, int LF, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void sdf_igrad3h_kernel(SdfTrainFwdArgs a) {
-  constexpr int NT = H / 16, KH32 = H / 32, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PT = pe_tiles_h(PED);
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4;
-  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * NW + wave) * HP + (lane & 15);
-  const bool valid = m < a.M;
-  const int64_t mc = valid ? m : a.M - 1;
-  const int64_t lstride = a.Mp * H;
-  const int kcs = a.kcs;
-  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);
-  float px, py, pz;
-  fetch_point(a.pts, mc, px, py, pz);
-  f32x4 accA[NT], accB[NT];
-  float h[NT * 4];
-  load_regs_h<NT>(a.hs + (a.L - 2) * lstride + mcrow, kg, h, kcs);
-  WStreamH<NW> ws;
-  ws.begin(a.rev, lds, a.n_rev, tid);
-  {
-    float wv[NT * 4];
-    f32x4 sc;
-    rowvec_h_load<NT, NW>(ws, wv, sc, tid);
-#pragma unroll
-    for (int i = 0; i < NT * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
-  }
-  if (a.abars) store_regs_h<NT>(a.abars + (a.L - 2) * lstride + mrow, kg, valid, h, kcs);
-  f32x4 pt[PT];
-#pragma unroll
-  for (int i = 0; i < PT; ++i) pt[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto zero = [&](f32x4 (&x)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  {
-    XhRegSrc<NT * 4> src{h};
-    zero(accA);
-    dense_x3h<NT, KH32, 0, NW>(ws, src, accA, tid);       // l = L-2 (never the skip layer, checked by the host)
-  }
-  for (int l = a.L - 3; l >= 1; --l) {
-    const float* hrow = a.hs + l * lstride + mcrow;
-    XhRevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + mrow : nullptr, kg, valid, kcs};
-    zero(accB);
-    dense_x3h<NT, KH32, 0, NW>(ws, src, accB, tid);
-    if (l == a.skip) {
-      XhRevSrc<NT> src2{accA, hrow, nullptr, kg, valid, kcs};
-      dense_x3h<PT, KH32, 0, NW>(ws, src2, pt, tid);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  {
-    XhRevSrc<NT> src{accA, a.hs + mcrow, a.abars ? a.abars + mrow : nullptr, kg, valid, kcs};     // abar_0 = (.) * sigma(h_1)
-    dense_x3h<PT, KH32, 0, NW>(ws, src, pt, tid);       // pbar += W_0^T abar_0
-  }
-  {
-    // n = J^T pbar: pbar tile t, register r <-> PE index k = 16 t + 4 kg + r
-    float full[PEC * 8], coef[PEC * 8];
-    pe_full<LF>(px, py, pz, full);
-    pe_coef<LF>(full, coef);
-    float n[3];
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) {
-      float cax[PT * 16], csel[PT * 4];
-#pragma unroll
-      for (int k = 0; k < PT * 16; ++k) cax[k] = (k < PED && pe_axis(k) == ax) ? coef[k < PEC * 8 ? k : 0] : 0.f;
-      // csel[4t + r] = cax[16 t + 4 kg + r]: x3h_select's map with tile pairs as 32-chunks
-      float sel8[(PT / 2) * 8];
-      x3h_select<PT / 2>(cax, sel8, kg);
-#pragma unroll
-      for (int t = 0; t < PT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) csel[4 * t + r] = sel8[8 * (t >> 1) + 4 * (t & 1) + r];
-      float acc = 0.f;
-#pragma unroll
-      for (int t = 0; t < PT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc = fmaf(csel[4 * t + r], pt[t][r], acc);
-      acc += __shfl_xor(acc, 16);
-      acc += __shfl_xor(acc, 32);
-      n[ax] = acc;
-    }
-    if (valid && kg == 0) { a.grad[m * 3 + 0] = n[0]; a.grad[m * 3 + 1] = n[1]; a.grad[m * 3 + 2] = n[2]; }
-  }
-}
-
-// backward sweeps (twins of sdf_bwd3_sweep1_kernel / sdf_bwd3_sweep2_kernel)
-template <int H, int LF, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void sdf_bwd3h_sweep1_kernel(SdfBwdArgs a) {
-  constexpr int NT = H / 16, KH32 = H / 32, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PE32 = cdiv(PED, 32), NGP = PE32 * 8;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4;
-  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * NW + wave) * HP + (lane & 15);
-  const bool valid = m < a.M;
-  const int64_t mc = valid ? m : a.M - 1;
-  const int64_t lstride = a.Mp * H;
-  const int kcs = a.kcs;
-  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);
-  // G(pbar) = J nbar, this lane's values of the padded PE space: needed by layer 0 and by the skip layer only, recomputed there instead of
-  // held in 16 registers across the whole sweep (the kernel sits at the 256-register limit of two waves per SIMD)
-  auto make_gp = [&](float (&gpx)[NGP]) __attribute__((always_inline)) {
-    float px, py, pz, full[PEC * 8], coef[PEC * 8], nb[3] = {0.f, 0.f, 0.f}, gfull[PE32 * 32];
-    fetch_point(a.pts, mc, px, py, pz);
-    pe_full<LF>(px, py, pz, full);
-    pe_coef<LF>(full, coef);
-    if (a.nbar) { nb[0] = a.nbar[mc * 3 + 0]; nb[1] = a.nbar[mc * 3 + 1]; nb[2] = a.nbar[mc * 3 + 2]; }
-#pragma unroll
-    for (int k = 0; k < PE32 * 32; ++k) gfull[k] = k < PED ? coef[k < PEC * 8 ? k : 0] * nb[pe_axis(k)] : 0.f;
-    x3h_select<PE32>(gfull, gpx, kg);
-  };
-  WStreamH<NW> ws;
-  ws.begin(a.fwd, lds, a.n_fwd, tid);
-  f32x4 accA[NT], accB[NT];
-  {
-    float gpx[NGP];
-    make_gp(gpx);
-    store_pe_row_h<PEC>(a.gpbar + m * (PEC * 8), kg, valid, gpx);
-    XhSweep1Src<NT, 0, NGP> src{accB, gpx, nullptr, nullptr, nullptr, nullptr, kg, valid};
-    dense_x3h<NT, PE32, 2, NW, XhSweep1Src<NT, 0, NGP>, false>(ws, src, accA, tid);
-  }
-  for (int l = 1; l < a.L - 1; ++l) {
-    // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l], G2(a_{l-1}) -> gas[l-1]
-    float gpx[NGP];
-    if (l == a.skip) {
-      make_gp(gpx);
-      XhSweep1Src<NT, KH32, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
-                                     a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, kg, valid, kcs};
-      dense_x3h<NT, KH32 + PE32, 2, NW, XhSweep1Src<NT, KH32, NGP>, false>(ws, src, accB, tid);
-    } else {
-      XhSweep1Src<NT, KH32, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
-                                     a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, kg, valid, kcs};
-      dense_x3h<NT, KH32, 2, NW, XhSweep1Src<NT, KH32, NGP>, false>(ws, src, accB, tid);
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  {
-    const int l = a.L - 1;
-    float gpx[NGP];
-    XhSweep1Src<NT, KH32, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.abars + (l - 1) * lstride + mcrow,
-                                   a.gas + (l - 1) * lstride + mrow, a.gus + l * lstride + mrow, kg, valid, kcs};
-    x3h_drain<KH32>(src);
-  }
-}
-
-template <int H, int F, int LF, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void sdf_bwd3h_sweep2_kernel(SdfBwdArgs a) {
-  constexpr int NT = H / 16, KH32 = H / 32, PED = PE<LF>::DIM, PT = pe_tiles_h(PED);
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4;
-  const int64_t m = ((int64_t)(blockIdx.x + a.wg0) * NW + wave) * HP + (lane & 15);
-  const bool valid = m < a.M;
-  const int64_t mc = valid ? m : a.M - 1;
-  const int64_t lstride = a.Mp * H;
-  const int kcs = a.kcs;
-  const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);
-  const float sb = a.sbar ? a.sbar[mc] : 0.f;
-  if (valid && kg == 0) {
-    *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
-    *reinterpret_cast<f32x4*>(a.ones4 + m * 4) = f32x4{1.f, 0.f, 0.f, 0.f};
-  }
-  WStreamH<NW> ws;
-  ws.begin(a.rev, lds, a.n_rev, tid);
-  f32x4 accA[NT], accB[NT];
-  auto zero = [&](f32x4 (&x)[NT]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) x[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  };
-  ws.skip(rowvec_h_chunks(NT, 1) / SCH, tid);         // w_sdf is read straight from the packed buffer (XhSweep2Src<TOP>)
-  {
-    XhRowSrc src{a.fbar ? a.fbar + mc * F : nullptr, kg, a.fbar != nullptr && mc < a.m_fbar};
-    zero(accA);
-    dense_x3h<NT, F / 32, 0, NW>(ws, src, accA, tid);  // W_feat^T fbar
-  }
-  ws.skip(rowvec_h_chunks(NT, 1) / SCH, tid);         // the d sdf/dx chain's copy of w_sdf
-  {
-    const int l = a.L - 2;                            // G(a_{L-2}) = (W_feat^T fbar + sbar w_sdf) sigma + G2, then W_{L-2}^T G(a_{L-2})
-    XhSweep2Src<NT, true> src{accA, a.hs + l * lstride + mcrow, a.gas + l * lstride + mcrow, a.gas + l * lstride + mrow, kg, valid,
-                              sb, a.rev + lane * 4, kcs};
-    zero(accB);
-    dense_x3h<NT, KH32, 0, NW>(ws, src, accB, tid);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  for (int l = a.L - 3; l >= 1; --l) {
-    XhSweep2Src<NT, false> src{accA, a.hs + l * lstride + mcrow, a.gas + l * lstride + mcrow, a.gas + l * lstride + mrow, kg, valid,
-                               0.f, nullptr, kcs};
-    zero(accB);
-    dense_x3h<NT, KH32, 0, NW>(ws, src, accB, tid);
-    if (l == a.skip) ws.skip(x3h_bwd_chunks(PT, KH32) / SCH, tid);      // the PE rows of W_skip^T are not needed here
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
-  }
-  {
-    XhSweep2Src<NT, false> src{accA, a.hs + mcrow, a.gas + mcrow, a.gas + mrow, kg, valid, 0.f, nullptr, kcs};     // G(a_0)
-    x3h_drain<KH32>(src);
-  }
-}
-
-// radiance net forward / backward (twins of rgb_fwd3_kernel / rgb_bwd3_kernel)
+// radiance net (RenderingNetwork, 'nerf' mode: mlp.py:208-229) forward and backward
 template <int H, int F, int LFV, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void rgb_fwd3h_kernel(RgbFwdArgs a) {
   constexpr int NT = H / 16, KH32 = H / 32, PECV = PE<LFV>::PEC, PV32 = cdiv(PE<LFV>::DIM, 32);
@@ -446,37 +248,11 @@ __global__ __launch_bounds__(NW * 64, 2) void rgb_bwd3h_kernel(RgbBwdArgs a) {
 
 }  // namespace
 
-void i2sdf_launch_sdf_fwd3h(int nw, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
-                            float* sdf_out, hipStream_t st) {
-  if (nw == 8) {
-    const unsigned grid = (unsigned)((M + 8 * HP - 1) / (8 * HP));
-    launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
-  } else {
-    const unsigned grid = (unsigned)((M + 4 * HP - 1) / (4 * HP));
-    launch_lds_threads(256, sdf_fwd3h_kernel<256, 6, 4>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
-  }
+// launches over workgroups of 128 points (eight 16-point waves)
+void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M, float* sdf_out,
+                            hipStream_t st) {
+  launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8>, (unsigned)((M + 8 * HP - 1) / (8 * HP)), st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
-
-// launches over `grid` workgroups of 128 points like the 32-point twins in mlp_x3.hip; nw = 8: one workgroup of eight 16-point waves per 128
-// points, nw = 4: two workgroups of four (independent stage barriers, twice the weight traffic)
-template <class A> static A half_wgs(const A& a) { A b = a; b.wg0 = 2 * a.wg0; return b; }
-void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, bool fwd, bool grad, unsigned grid, hipStream_t st, int nw) {
-  if (nw == 4) {
-    if (fwd) launch_lds_threads(256, sdf_train_fwd3h_kernel<256, 256, 6, 4>, 2 * grid, st, half_wgs(a));
-    if (grad) launch_lds_threads(256, sdf_igrad3h_kernel<256, 6, 4>, 2 * grid, st, half_wgs(a));
-    return;
-  }
-  if (fwd) launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8>, grid, st, a);
-  if (grad) launch_lds_threads(512, sdf_igrad3h_kernel<256, 6, 8>, grid, st, a);
-}
-void i2sdf_launch_sdf_bwd3h(const SdfBwdArgs& a, unsigned grid, hipStream_t st, int nw) {
-  if (nw == 4) {
-    launch_lds_threads(256, sdf_bwd3h_sweep1_kernel<256, 6, 4>, 2 * grid, st, half_wgs(a));
-    launch_lds_threads(256, sdf_bwd3h_sweep2_kernel<256, 256, 6, 4>, 2 * grid, st, half_wgs(a));
-    return;
-  }
-  launch_lds_threads(512, sdf_bwd3h_sweep1_kernel<256, 6, 8>, grid, st, a);
-  launch_lds_threads(512, sdf_bwd3h_sweep2_kernel<256, 256, 6, 8>, grid, st, a);
-}
+void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8>, grid, st, a); }
 void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8>, grid, st, a); }
 void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_bwd3h_kernel<256, 256, 8>, grid, st, a); }

@@ -186,15 +186,6 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
       emit_dense_fwd3(b, np, l, H / 32, KC16, cm, mult);
     }
     emit_rowvec(b, np, L - 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
-    if (F > 0 && (F / 32) % 2 == 0) {          // feature rows (training forward)
-      Seg sb = base_seg(np, L - 1, SEG_BIAS);
-      sb.NT = F / 32; sb.KC = 4; sb.nchunks = F / 32 * 4; sb.used = sb.nchunks; sb.row_off = 1; sb.nrows = F;
-      b.add(sb);
-      Seg sw = base_seg(np, L - 1, SEG_WFWD3);
-      sw.NT = F / 32; sw.KC = H / 16; sw.used = (H / 16) * (F / 32) * 3; sw.nchunks = x3_op_chunks(F / 32, H / 16) - F / 32 * 4;
-      sw.cm = ColMap{HUGE_SPLIT, 0, H, 0, 0}; sw.row_off = 1; sw.nrows = F;
-      b.add(sw);
-    }
   }
   np.fwd3_chunks = b.chunk - np.fwd3_chunk0;
   // bf16x3 reverse stream (d sdf/dx chain): [w_sdf row][W_{L-2}^T] ... [W_0^T]; skip factor folded into the weights
@@ -233,23 +224,7 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
     emit_dense_fwd3h(b, np, L - 1, F / 16, H / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1.0f, 1, F);          // feature rows
   }
   np.fwd3h_chunks = b.chunk - np.fwd3h_chunk0;
-  np.rev3h_chunk0 = b.chunk;
-  if (H == 256 && F == 256) {
-    const int PT = round_up(cdiv(PED, 16), 2);
-    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
-    emit_dense_bwd3h(b, np, L - 1, H / 16, F / 32, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1, F, 1.0f);
-    np.rev3h_wsdf_chunk = b.chunk;
-    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
-    for (int l = L - 2; l >= 0; --l) {
-      if (l == d.skip_layer) {
-        const float rs2 = 0.70710678118654752440f;
-        emit_dense_bwd3h(b, np, l, H / 16, H / 32, ColMap{HUGE_SPLIT, 0, d.in_dim[l] - PED, 0, 0}, 0, d.out_dim[l], rs2);
-        emit_dense_bwd3h(b, np, l, PT, H / 32, ColMap{HUGE_SPLIT, d.in_dim[l] - PED, PED, 0, 0}, 0, d.out_dim[l], rs2);
-      } else {
-        emit_dense_bwd3h(b, np, l, (l == 0) ? PT : H / 16, H / 32, ColMap{HUGE_SPLIT, 0, d.in_dim[l], 0, 0}, 0, d.out_dim[l], 1.0f);
-      }
-    }
-  }
+  np.rev3h_chunk0 = b.chunk;          // (no reverse stream of this family for the SDF net: its d sdf/dx chain and sweeps run on 32-point waves)
   np.rev3h_chunks = b.chunk - np.rev3h_chunk0;
   return I2SDF_OK;
 }
@@ -273,23 +248,8 @@ int build_rgb(i2sdf_plan* p, Builder& b) {
   for (int l = L - 2; l >= 1; --l) emit_dense_bwd(b, np, l, H / 32, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H);
   emit_dense_bwd(b, np, 0, F / 32, H / 8, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H);   // feature columns only
   np.rev_chunks = b.chunk - np.rev_chunk0;
-  // bf16x3 streams (x3.h): layer 0 reduces over [PE(view) padded to 16-chunks | feature]
-  np.fwd3_chunk0 = b.chunk;
-  if ((H / 32) % 2 == 0 && F % 32 == 0 && (F / 32) % 2 == 0) {
-    const int PV16 = cdiv(PED, 16);
-    emit_dense_fwd3(b, np, 0, H / 32, PV16 + F / 16, ColMap{PV16 * 16, 0, PED, PED, F}, 1.0f);
-    for (int l = 1; l < L - 1; ++l) emit_dense_fwd3(b, np, l, H / 32, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 1.0f);
-    emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
-  }
-  np.fwd3_chunks = b.chunk - np.fwd3_chunk0;
-  np.rev3_chunk0 = b.chunk;
-  if ((H / 32) % 2 == 0 && F % 32 == 0 && (F / 32) % 2 == 0) {
-    emit_rowvec(b, np, L - 1, 3, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
-    for (int l = L - 2; l >= 1; --l) emit_dense_bwd3(b, np, l, H / 32, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0}, 0, H, 1.0f);
-    emit_dense_bwd3(b, np, 0, F / 32, H / 16, ColMap{HUGE_SPLIT, PED, F, 0, 0}, 0, H, 1.0f);
-  }
-  np.rev3_chunks = b.chunk - np.rev3_chunk0;
-  // 16-point-wave family (x3h.h): layer 0 reduces over [PE(view) padded to 32-chunks | feature]
+  np.fwd3_chunk0 = np.rev3_chunk0 = b.chunk;      // (the radiance net's bf16x3 kernels all run on 16-point waves)
+  // bf16x3 streams, 16-point-wave family (x3h.h): layer 0 reduces over [PE(view) padded to 32-chunks | feature]
   np.fwd3h_chunk0 = b.chunk;
   if (H == 256 && F == 256 && L >= 3) {
     const int PV32 = cdiv(PED, 32);
@@ -551,7 +511,7 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_TRAIN_FWD_BF16X3) {
-    if (value && (p->sdf.rev3_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
+    if (value && (p->sdf.rev3_chunks == 0 || p->sdf.fwd3h_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
     p->train_fwd_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
@@ -561,7 +521,7 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_RGB_BF16X3) {
-    if (value && (p->rgb.rev3_chunks == 0 || p->rgb.d.hidden != 256 || p->F != 256 || p->rgb.d.n_lin < 3)) return I2SDF_EINVAL;
+    if (value && (p->rgb.rev3h_chunks == 0 || p->rgb.d.hidden != 256 || p->F != 256 || p->rgb.d.n_lin < 3)) return I2SDF_EINVAL;
     p->rgb_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }
@@ -575,12 +535,6 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
   }
   if (option == I2SDF_OPT_BLOCKED_SAVES) {
     p->blocked_saves = value ? 1 : 0;
-    return I2SDF_OK;
-  }
-  if (option == I2SDF_OPT_WAVE16) {
-    if (value < 0 || (value & ~(63 | I2SDF_W16_WG4))) return I2SDF_EINVAL;
-    if ((value & 63) && (p->sdf.fwd3h_chunks == 0 || p->rgb.fwd3h_chunks == 0)) return I2SDF_EINVAL;      // 256/256/256 nets only
-    p->wave16 = value;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_TAIL_OVERLAP) {

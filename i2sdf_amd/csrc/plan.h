@@ -49,9 +49,8 @@ struct NetPlan {
   int64_t fwd3_chunk0 = 0, fwd3_chunks = 0;    // bf16x3 forward stream: hidden layers, sdf row, feature rows (sdf net, x3.h)
   int64_t rev3_chunk0 = 0, rev3_chunks = 0;    // bf16x3 reverse stream: [w_sdf][W_feat^T][w_sdf][W_{L-2}^T] ... [W_0^T]
   int64_t rev3_wsdf_chunk = 0;                 // where the d sdf/dx chain starts inside it
-  int64_t fwd3h_chunk0 = 0, fwd3h_chunks = 0;  // the same two streams for the 16-point-wave kernels (x3h.h)
-  int64_t rev3h_chunk0 = 0, rev3h_chunks = 0;
-  int64_t rev3h_wsdf_chunk = 0;
+  int64_t fwd3h_chunk0 = 0, fwd3h_chunks = 0;  // bf16x3 streams of the 16-point-wave kernels (x3h.h): sdf net forward [hidden layers, sdf row, feature rows];
+  int64_t rev3h_chunk0 = 0, rev3h_chunks = 0;  // radiance net forward and reverse
   int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
   int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
 };
@@ -79,7 +78,6 @@ struct i2sdf_plan {
   int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
   int32_t wgrad_bf16x2 = 0;          // I2SDF_OPT_WGRAD_BF16X2: 256x256 weight-gradient blocks with two split planes / three products
   int32_t blocked_saves = 0;         // I2SDF_OPT_BLOCKED_SAVES: saved tensors of the bf16x3 full workgroups in the blocked layout (mlp_common.h)
-  int32_t wave16 = 0;                // I2SDF_OPT_WAVE16: OR of I2SDF_W16_* -- kernel families on 16-point waves (x3h.h)
   int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones
   // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
   mutable hipStream_t side = nullptr;
@@ -114,6 +112,16 @@ void i2sdf_parts_end(const i2sdf_plan* p, hipStream_t st, PartRun* pr);
 void i2sdf_parts_join_all(const i2sdf_plan* p, hipStream_t st);        // `st` waits for every side stream (also inside a chain)
 void i2sdf_parts_fence(const i2sdf_plan* p, hipStream_t st);           // every side stream waits for what is enqueued on `st`
 inline bool i2sdf_parts_on(const i2sdf_plan* p) { return p->parts >= 2; }
+// An entry point that does NOT cut its batch into ranges (its kernel family is not on the ranged path, e.g. rgb_bf16x3 off while the SDF
+// flags are on) called inside a chain: the side streams still hold un-joined work of the previous entry point, and the next one will run
+// on them again.  The guard joins every range into `st` before the entry point's launches and fences the side streams behind them.
+struct ChainGuard {
+  const i2sdf_plan* p; hipStream_t st; bool on;
+  ChainGuard(const i2sdf_plan* p_, hipStream_t st_, bool ranged) : p(p_), st(st_), on(!ranged && p_->chain_active != 0) {
+    if (on) i2sdf_parts_join_all(p, st);
+  }
+  ~ChainGuard() { if (on) i2sdf_parts_fence(p, st); }
+};
 
 // Fork: returns the stream the split-K tail of an entry point should be launched on -- the plan's side stream, ordered after
 // everything already enqueued on `st`, or `st` itself when the overlap is off.  Join: `st` waits for the side stream.

@@ -426,46 +426,4 @@ struct X3RowSrc {
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
 
-// ---- sources of the radiance-net kernels ---------------------------------------------------------------------------
-// ReLU of the previous layer's pre-activations; stores the activations r (saved tensor)
-template <int NT>
-struct X3ReluSrc {
-  static constexpr bool STORES = true;
-  static constexpr int nld(int) { return 0; }
-  const f32x16 (&accP)[NT]; float* rrow; int hi; bool valid; int kcs = 16;
-  __device__ __forceinline__ void ahead(int) {}
-  __device__ __forceinline__ float value(int kc, int u, float&) { return relu0(accP[kc >> 1][8 * (kc & 1) + u]); }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (rrow != nullptr && valid) x3_store8(rrow, kc, hi, v, kcs);
-  }
-};
-// layer-0 input of the radiance net: NPV k-chunks of PE(view dir) held in registers, then the feature row from global memory
-template <int NPV>
-struct X3PeRowSrc {
-  static constexpr bool STORES = false;
-  static constexpr int nld(int kc) { return kc >= NPV ? 2 : 0; }
-  const float (&pe)[NPV * 8]; const float* row; int hi;
-  f32x4 q[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3_load8(row, kc - NPV, hi, q[kc % X3_RING]); }
-  __device__ __forceinline__ float value(int kc, int u, float&) {
-    return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc % X3_RING][u >> 2][u & 3];
-  }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
-};
-// radiance backward: G(a_l) = (previous op's accumulators) where the saved activation r is positive; stores G(a_l)
-template <int NT>
-struct X3MaskSrc {
-  static constexpr bool STORES = true;
-  static constexpr int nld(int) { return 2; }
-  const f32x16 (&accP)[NT]; const float* rrow; float* grow; int hi; bool valid; int kcs = 16;
-  f32x4 q[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { x3_load8(rrow, kc, hi, q[kc % X3_RING], kcs); }
-  __device__ __forceinline__ float value(int kc, int u, float&) {
-    return q[kc % X3_RING][u >> 2][u & 3] > 0.f ? accP[kc >> 1][8 * (kc & 1) + u] : 0.f;
-  }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v, kcs);
-  }
-};
-
 }  // namespace i2sdf

@@ -19,8 +19,17 @@
 // the 16-float groups 2c and 2c+1 of its point -- 16 points x 64 B = 1 KB contiguous per wave instruction in the blocked layout --
 // so kernels of both families can be mixed freely along a chain (and wgrad3p reads what either wrote).
 //
-// NW = waves per workgroup: 8 (one workgroup per CU, one weight stage in LDS shared by all eight waves) or 4 (two independent
-// workgroups per CU: twice the L2 -> LDS weight traffic, but their stage barriers are decoupled).
+// NW = waves per workgroup: 8 -- one workgroup per CU, one weight stage in LDS shared by all eight waves (4, i.e. two independent
+// workgroups per CU with twice the L2 -> LDS weight traffic, measured 5 % slower on the sampler pass).
+//
+// What it bought (round 4, MI355X, profiles/r4_wave16_experiments.txt): the sampler pass 551 -> 517 us per 131 072 points (matrix pipe
+// 68 -> 72 % busy at a higher clock), the training forward 314 -> 289 us, the radiance forward / backward 159 -> 147 / 183 -> 176 us per
+// half batch.  The d sdf/dx chain and the backward sweeps were built the same way and measured SLOWER (they need the 256 registers for
+// their saved-tensor operands: spills; and without spills sweep 2 ran 399 vs 387 us -- memory-bound kernels gain nothing from a second
+// wave that moves the same bytes), so they stay on 32-point waves (mlp_x3.hip).  A micro-benchmark of the instruction mix
+// (scripts/ubench/mfma16_mix.hip) holds 0.91-0.97 matrix-pipe occupancy; the kernels hold 0.72, and knock-outs attribute the gap to
+// the B preparation (~1 VALU instruction per MFMA costs ~1.7 matrix-pipe cycles each whatever its placement: 0.80 -> 0.72), the stage
+// barrier + DMA (0.06) and the LDS reads (0.03); with four waves per SIMD (a knock-out that frees the registers) the same code reaches 0.88.
 #pragma once
 #include "x3.h"
 
@@ -62,7 +71,7 @@ __device__ __forceinline__ void x3h_select(const float (&full)[NC32 * 32], float
 // Per group: one tile pair, one split plane = two A chunks, four MFMAs (the W0*h2 pair of the sp = 0 group rides in the sp = 2
 // group), one twelfth of the next k-chunk's B preparation in every other group, the next stage's DMA pieces in the first groups.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int KC32, int BIAS, int NW, class Src, bool DEFER = true>
+template <int NT, int KC32, int BIAS, int NW, class Src>
 __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&acc_io)[NT], int tid) {
   using WS = WStreamH<NW>;
   f32x4 acc[NT];
@@ -165,24 +174,16 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
         acc[nt + 1] = mfma_bf16h(a1, b[0], acc[nt + 1]);
         gap(1);
         __builtin_amdgcn_sched_barrier(0);
-        // DEFER: the W0*h2 pair of the sp = 0 group rides in the sp = 2 group (four MFMAs in every group), its weights kept in d0 / d1;
-        // without it (8 registers less) the sp = 0 group has six MFMAs and the sp = 2 group two
-        if (DEFER && sp == 0) { d0 = a0; d1 = a1; }
+        if (sp == 0) { d0 = a0; d1 = a1; }
         if (sp < 2) acc[nt] = mfma_bf16h(a0, b[1], acc[nt]);
-        else if (DEFER) acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
+        else acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
         if (npiece < WS::NPIECE) {          // next stage's DMA: one piece per group, from the first group on
           ws.issue_piece(npiece, tid); ++npiece;
         }
         gap(2);
         __builtin_amdgcn_sched_barrier(0);
         if (sp < 2) acc[nt + 1] = mfma_bf16h(a1, b[1], acc[nt + 1]);
-        else if (DEFER) acc[nt + 1] = mfma_bf16h(d1, b[2], acc[nt + 1]);
-        if (!DEFER && sp == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          acc[nt] = mfma_bf16h(a0, b[2], acc[nt]);
-          __builtin_amdgcn_sched_barrier(0);
-          acc[nt + 1] = mfma_bf16h(a1, b[2], acc[nt + 1]);
-        }
+        else acc[nt + 1] = mfma_bf16h(d1, b[2], acc[nt + 1]);
         gap(3);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -194,20 +195,6 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc_io[nt] = acc[nt];
-}
-
-// apply a source to every k-chunk without a consuming op (the last epilogue of a chain: loads, products, stores)
-template <int KC32, class Src>
-__device__ __forceinline__ void x3h_drain(Src& src) {
-  float v[8], vx[8];
-  src.ahead(0);
-#pragma unroll
-  for (int kc = 0; kc < KC32; ++kc) {
-    if (kc + 1 < KC32) src.ahead(kc + 1);
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { const float a1 = src.p1(kc, u); v[u] = src.p3(kc, u, a1, src.p2(kc, u, a1), vx[u]); }
-    src.done(kc, v, vx);
-  }
 }
 
 // Row-vector op on the D-layout activations of a 16-point wave: out[row] = sum_k w_row[k] * in[k] (+ scalar).
@@ -290,86 +277,6 @@ struct XhRegSrc {
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
 
-// reverse chain (d sdf/dx): abar = (previous op's accumulators) * sigma(h), h re-read from the saved tensor; stores abar
-template <int NT>
-struct XhRevSrc {
-  static constexpr bool STORES = true;
-  const f32x4 (&accP)[NT]; const float* hrow; float* abrow; int kg; bool valid; int kcs = 16;
-  f32x4 hq[2][2];
-  __device__ __forceinline__ void ahead(int kc) { x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); }
-  __device__ __forceinline__ float p1(int kc, int u) { return __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]); }
-  __device__ __forceinline__ float p2(int, int, float e) { return 1.0f - e; }                      // sigma = 1 - exp(-100 h)
-  __device__ __forceinline__ float p3(int kc, int u, float, float sg, float&) { return accP[2 * kc + (u >> 2)][u & 3] * sg; }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (abrow != nullptr && valid) x3h_store8(abrow, kc, kg, v, kcs);
-  }
-};
-// sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
-//                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
-template <int NT, int KACC, int NREG>
-struct XhSweep1Src {
-  static constexpr bool STORES = true;
-  const f32x4 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers (G(pbar) in this lane's B order)
-  const float* hrow; const float* arow; float* g2row; float* gurow; int kg; bool valid; int kcs = 16;
-  f32x4 hq[2][2], aq[2][2];
-  __device__ __forceinline__ void ahead(int kc) {
-    if (kc < KACC) { x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); x3h_load8(arow, kc, kg, aq[kc & 1], kcs); }
-  }
-  __device__ __forceinline__ float p1(int kc, int u) {
-    return kc < KACC ? __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]) : 0.f;      // e = 1 - sigma
-  }
-  __device__ __forceinline__ float p2(int kc, int u, float e) { return kc < KACC ? aq[kc & 1][u >> 2][u & 3] * (100.f * e) : 0.f; }      // abar 100 (1 - sigma)
-  __device__ __forceinline__ float p3(int kc, int u, float e, float ae, float& g2) {
-    g2 = 0.f;
-    if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
-    const float ga = accP[(2 * kc + (u >> 2)) < NT ? (2 * kc + (u >> 2)) : 0][u & 3];
-    g2 = ga * ae;
-    return ga * (1.0f - e);
-  }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
-    if (kc < KACC && valid) { x3h_store8(gurow, kc, kg, v, kcs); x3h_store8(g2row, kc, kg, g2, kcs); }
-  }
-};
-// sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
-template <int NT, bool TOP>
-struct XhSweep2Src {
-  static constexpr bool STORES = true;
-  const f32x4 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int kg; bool valid;
-  float sb; const float* wsdf;        // TOP: w_sdf in row-vector stream layout (chunk nt = 64 lanes x 16 B), + lane*4 applied
-  int kcs = 16;
-  f32x4 hq[2][2], gq[2][2], wq[2][2];
-  __device__ __forceinline__ void ahead(int kc) {
-    x3h_load8(hrow, kc, kg, hq[kc & 1], kcs); x3h_load8(g2row, kc, kg, gq[kc & 1], kcs);
-    if (TOP) {
-      wq[kc & 1][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
-      wq[kc & 1][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
-    }
-  }
-  __device__ __forceinline__ float p1(int kc, int u) { return __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc & 1][u >> 2][u & 3]); }
-  __device__ __forceinline__ float p2(int, int, float e) { return 1.0f - e; }
-  __device__ __forceinline__ float p3(int kc, int u, float, float sg, float&) {
-    float x = accP[2 * kc + (u >> 2)][u & 3];
-    if (TOP) x = fmaf(sb, wq[kc & 1][u >> 2][u & 3], x);
-    return fmaf(x, sg, gq[kc & 1][u >> 2][u & 3]);
-  }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3h_store8(grow, kc, kg, v, kcs);
-  }
-};
-// a point-major row in global memory (or zeros) as B operand
-struct XhRowSrc {
-  static constexpr bool STORES = false;
-  const float* row; int kg; bool on;
-  f32x4 q[2][2];
-  __device__ __forceinline__ void ahead(int kc) {
-    if (on) x3h_load8(row, kc, kg, q[kc & 1], 16);
-    else { q[kc & 1][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc & 1][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  }
-  __device__ __forceinline__ float p1(int, int) { return 0.f; }
-  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
-  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc & 1][u >> 2][u & 3]; }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
-};
 // ---- radiance net ----------------------------------------------------------------------------------------------------
 // ReLU of the previous layer's pre-activations; stores the activations r (saved tensor)
 template <int NT>
@@ -419,38 +326,9 @@ __device__ __forceinline__ void store_regs_h(float* __restrict__ row, int kg, bo
   for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + nt * kcs + 4 * kg) = f32x4{r[4 * nt], r[4 * nt + 1], r[4 * nt + 2], r[4 * nt + 3]};
 }
 template <int NTK>
-__device__ __forceinline__ void load_regs_h(const float* __restrict__ row, int kg, float (&r)[NTK * 4], int kcs) {
-#pragma unroll
-  for (int nt = 0; nt < NTK; ++nt) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(row + nt * kcs + 4 * kg);
-    r[4 * nt] = v.x; r[4 * nt + 1] = v.y; r[4 * nt + 2] = v.z; r[4 * nt + 3] = v.w;
-  }
-}
-template <int NTK>
 __device__ __forceinline__ void store_tile_h(float* __restrict__ row, int kg, bool valid, const f32x4 (&t)[NTK]) {
   if (!valid) return;
 #pragma unroll
   for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + 16 * nt + 4 * kg) = t[nt];
 }
-// read a row vector (rowvec_h layout) into D-layout order registers w[4*nt + r] = w_row[16 nt + 4 kg + r]; also the scalar chunk
-template <int NTK, int NW>
-__device__ __forceinline__ void rowvec_h_load(WStreamH<NW>& ws, float (&w)[NTK * 4], f32x4& scalars, int tid) {
-  constexpr int TOT = rowvec_h_chunks(NTK, 1), NS = TOT / SCH;
-  const int lane = tid & 63;
-#pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const f32x4* cur = reinterpret_cast<const f32x4*>(ws.advance(tid)) + lane;
-#pragma unroll
-    for (int j = 0; j < SCH; ++j) {
-      const int c = s * SCH + j;
-      if (c < NTK) {
-        const f32x4 v = cur[j * 64];
-        w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
-      } else if (c == NTK) {
-        scalars = cur[j * 64];
-      }
-    }
-  }
-}
-
 }  // namespace i2sdf

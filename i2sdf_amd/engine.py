@@ -48,18 +48,14 @@ class RenderEngine:
         self.blocked_saves = False
         if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
             self.set_blocked_saves(True)
-        # kernel families on 16-point waves, two waves per SIMD (include/i2sdf.h: I2SDF_OPT_WAVE16; csrc/x3h.h); I2SDF_WAVE16=<mask> for A/B runs
-        self.wave16 = 0
-        if cfg.bf16x3 and cfg.sdf.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.hidden == 256 and cfg.rgb.n_lin >= 3:
-            self.set_wave16(int(os.environ.get("I2SDF_WAVE16", str(L.W16_DEFAULT))))
         self.tail_overlap = False
         if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
             self.set_tail_overlap(True)
         # point ranges on their own streams instead of split-K tail workgroups (include/i2sdf.h: I2SDF_OPT_PARTS); I2SDF_PARTS=0 for A/B runs
         self.parts = 0
         n_parts = int(os.environ.get("I2SDF_PARTS", "2"))
-        if cfg.bf16x3 and n_parts >= 2 and self.train_forward_bf16x3 and self.sdf_backward_bf16x3:
-            self.set_parts(n_parts)
+        self._parts_wanted = n_parts if (cfg.bf16x3 and n_parts >= 2) else 0
+        self._sync_parts()
         sc = cfg.sampler
         self._scfg = L.SamplerCfg(near=sc.near, eps=sc.eps, add_tiny=sc.add_tiny, N_samples=sc.N_samples, N_samples_eval=sc.N_samples_eval,
                                   N_samples_extra=sc.N_samples_extra, beta_iters=sc.beta_iters, max_total_iters=sc.max_total_iters)
@@ -136,16 +132,22 @@ class RenderEngine:
         """SDF forward + d sdf/dx kernel (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_TRAIN_FWD_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TRAIN_FWD_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.train_forward_bf16x3 = bool(on)
+        if hasattr(self, "_parts_wanted"):
+            self._sync_parts()
 
     def set_sdf_backward_bf16x3(self, on: bool):
         """SDF backward sweeps (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_SDF_BWD_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SDF_BWD_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.sdf_backward_bf16x3 = bool(on)
+        if hasattr(self, "_parts_wanted"):
+            self._sync_parts()
 
     def set_rgb_bf16x3(self, on: bool):
         """Radiance forward / backward (full workgroups) in bf16x3 split arithmetic (I2SDF_OPT_RGB_BF16X3)."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_RGB_BF16X3, int(bool(on))), "i2sdf_plan_set_option")
         self.rgb_bf16x3 = bool(on)
+        if hasattr(self, "_parts_wanted"):
+            self._sync_parts()
 
     def set_wgrad_bf16x2(self, on: bool):
         """256x256 weight-gradient blocks with two split planes / three products (I2SDF_OPT_WGRAD_BF16X2): 16+ mantissa bits per
@@ -179,17 +181,20 @@ class RenderEngine:
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_TAIL_OVERLAP, int(bool(on))), "i2sdf_plan_set_option")
         self.tail_overlap = bool(on)
 
-    def set_wave16(self, mask: int):
-        """Which bf16x3 kernel families run on 16-point waves (I2SDF_OPT_WAVE16: OR of lib.W16_*; 0 = all on 32-point waves)."""
-        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_WAVE16, int(mask)), "i2sdf_plan_set_option")
-        self.wave16 = int(mask)
+    def _sync_parts(self):
+        """Point ranges need every per-point kernel family on the ranged (bf16x3 full-workgroup) path: with the flags mixed an entry point
+        of a chain would run whole-batch between two ranged ones (the library then joins and fences around it, at the price of the overlap)."""
+        want = self._parts_wanted if (self.train_forward_bf16x3 and self.sdf_backward_bf16x3 and self.rgb_bf16x3) else 0
+        if want != self.parts:
+            n = int(want) if int(want) >= 2 else 0
+            L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_PARTS, n), "i2sdf_plan_set_option")
+            self.parts = n
 
     def set_parts(self, n: int):
         """Cut the per-point entry points into n point ranges, each on its own stream (I2SDF_OPT_PARTS; 0 / 1 = off).  Change it only
         between training steps (the layout of the saved tensors depends on it)."""
-        n = int(n) if int(n) >= 2 else 0
-        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_PARTS, n), "i2sdf_plan_set_option")
-        self.parts = n
+        self._parts_wanted = int(n) if int(n) >= 2 else 0
+        self._sync_parts()
 
     def chain(self, M: int):
         """Context manager: the per-point entry points called inside leave their point ranges un-joined (i2sdf_chain_begin / _end);

@@ -72,9 +72,6 @@ OPT_TAIL_OVERLAP = 32
 OPT_BLOCKED_SAVES = 128
 OPT_WGRAD_BF16X2 = 256
 OPT_PARTS = 512
-OPT_WAVE16 = 1024
-W16_SDF_FWD, W16_TRAIN_FWD, W16_IGRAD, W16_SWEEPS, W16_RGB_FWD, W16_RGB_BWD, W16_WG4 = 1, 2, 4, 8, 16, 32, 256
-W16_DEFAULT = 51         # the engine's default mask (engine.py): sampler forward, training forward, radiance forward + backward -- the families that measured faster on 16-point waves
 MAX_PARTS = 4
 GRID_ORDER_MESHGRID, GRID_ORDER_VOLUME = 0, 1
 

@@ -124,18 +124,6 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   by another range's next kernel instead of idling -- which replaces the split-K tail workgroups (none in this mode: every point
  *   goes through the full-workgroup kernels and every saved tensor is blocked throughout).  Results do not depend on n.  Default 0. */
 #define I2SDF_OPT_PARTS 512
-/*   I2SDF_OPT_WAVE16 (256-wide nets with the bf16x3 options on): which bf16x3 kernel families run on 16-point waves -- two waves per
- *   SIMD, v_mfma_f32_16x16x32_bf16, 16-row tiles (csrc/x3h.h) -- instead of 32-point waves, one per SIMD (csrc/x3.h).  Value = OR of
- *   I2SDF_W16_*.  Same arithmetic (bf16x3 split products, fp32 accumulate), same saved-tensor layouts: the families can be mixed along
- *   a chain.  I2SDF_W16_WG4: four waves per workgroup (two independent workgroups per CU) instead of eight.  Default 0. */
-#define I2SDF_OPT_WAVE16 1024
-#define I2SDF_W16_SDF_FWD 1      /* sdf-only forward: sampler passes, grid queries */
-#define I2SDF_W16_TRAIN_FWD 2    /* i2sdf_sdf_forward_grad: forward with saves */
-#define I2SDF_W16_IGRAD 4        /* i2sdf_sdf_forward_grad: d sdf/dx chain */
-#define I2SDF_W16_SWEEPS 8       /* i2sdf_sdf_backward: both sweeps */
-#define I2SDF_W16_RGB_FWD 16
-#define I2SDF_W16_RGB_BWD 32
-#define I2SDF_W16_WG4 256
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset

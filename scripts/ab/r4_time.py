@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Round-4 A/B timing on the GPU box, everything in ONE process so that variants see the same box and clocks, interleaved and repeated:
 
-  python scripts/ab/r4_time.py fwd                 sdf-only forward (one sampler pass: 131 072 points) per I2SDF_OPT_WAVE16 mask
-  python scripts/ab/r4_time.py step [rays ...]     training step per (parts, wave16 mask) at the given ray counts
-  python scripts/ab/r4_time.py entries             un-chained per-entry-point times of a step per wave16 mask
+  python scripts/ab/r4_time.py fwd                 sdf-only forward (one sampler pass: 131 072 points)
+  python scripts/ab/r4_time.py step [rays ...] [c=PARTS ...]   training step per point-range count at the given ray counts
+  python scripts/ab/r4_time.py entries             un-chained per-entry-point times of a step
+(I2SDF_LIB_PATH selects an A/B build, scripts/ab/variant_build.sh)
 
 Kernel times are HIP-event brackets around REP back-to-back launches (median of several); steps are wall clock around synchronised windows."""
 import os
@@ -14,7 +15,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 
 from i2sdf_amd import I2SDFNetwork, I2SDFLoss, FusedAdam, synthetic_conf
-from i2sdf_amd import lib as L
 
 
 def make(light=False):
@@ -60,18 +60,10 @@ def mode_fwd():
     eng = net._engine_for(dev)
     M = 1024 * 128
     x = ((torch.rand(M, 3, device=dev) * 2 - 1) * 2.5).contiguous()
-    masks = [0, L.W16_SDF_FWD, L.W16_SDF_FWD | L.W16_WG4]
-    ref = None
     for rnd in range(3):
-        for m in masks:
-            eng.set_wave16(m)
-            out = eng.sdf_forward(x)
-            if ref is None:
-                ref = out.clone()
-            err = float((out - ref).abs().max() / ref.abs().max())
-            med, best = ev_time(lambda: eng.sdf_forward(x))
-            print(f"fwd round {rnd} wave16={m:3d}: {med * 1e3:7.1f} us (best {best * 1e3:7.1f}) per {M} points, "
-                  f"{2 * 459008 * M / med / 1e9:6.1f} TFLOP/s fp32-eq, max rel diff vs 32-pt {err:.1e}", flush=True)
+        eng.sdf_forward(x)
+        med, best = ev_time(lambda: eng.sdf_forward(x))
+        print(f"fwd round {rnd}: {med * 1e3:7.1f} us (best {best * 1e3:7.1f}) per {M} points, {2 * 459008 * M / med / 1e9:6.1f} TFLOP/s fp32-eq", flush=True)
 
 
 def step_fn(net, loss_fn, opt, inp, gt):
@@ -92,7 +84,7 @@ def mode_step(rays, combos=None):
     net.force_iters = 2
     loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
     opt = FusedAdam(net, lr=5e-4, eps=1e-15)
-    combos = combos or [(2, 0), (0, 0)]
+    combos = combos or [(2,), (0,)]
     for B in rays:
         inp, gt = batch(B, dev)
         step = step_fn(net, loss_fn, opt, inp, gt)
@@ -100,20 +92,19 @@ def mode_step(rays, combos=None):
         eng = net._engine_for(dev)
         n = max(6, min(30, int(600 / max(B / 1024 * 6.3, 1))))
         for rnd in range(3):
-            for parts, mask in combos:
+            for (parts,) in combos:
                 eng.set_parts(parts)
-                eng.set_wave16(mask)
                 for _ in range(3):
                     step()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 for _ in range(n):
                     step()
                 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-                print(f"step rays={B:5d} round {rnd} parts={parts} wave16={mask:3d}: {dt * 1e3:8.3f} ms  = {dt / B * 1e6:6.3f} us/ray  "
+                print(f"step rays={B:5d} round {rnd} parts={parts}: {dt * 1e3:8.3f} ms  = {dt / B * 1e6:6.3f} us/ray  "
                       f"{B * (eng.n_z - 1) / dt / 1e6:6.2f} M ray-samples/s", flush=True)
 
 
-def mode_entries(masks):
+def mode_entries():
     net, dev = make()
     net.force_iters = 2
     loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
@@ -123,8 +114,7 @@ def mode_entries(masks):
     step()
     eng = net._engine_for(dev)
     for rnd in range(2):
-        for mask in masks:
-            eng.set_wave16(mask)
+        for _ in (0,):
             eng.use_chain = False
             for _ in range(3):
                 step()
@@ -137,7 +127,7 @@ def mode_entries(masks):
             eng.use_chain = True
             short = {"i2sdf_weight_grads": "wgrad", "i2sdf_sdf_backward": "sdf_bwd", "i2sdf_sdf_forward_grad": "sdf_fwdg", "i2sdf_sample_rays": "sampler",
                      "i2sdf_rgb_forward": "rgb_f", "i2sdf_rgb_backward": "rgb_b"}
-            print(f"entries round {rnd} wave16={mask:3d}: " + " ".join(f"{short[k]}={v[0] / 10:.3f}" for k, v in kt.items() if k in short), flush=True)
+            print(f"entries round {rnd}: " + " ".join(f"{short[k]}={v[0] / 10:.3f}" for k, v in kt.items() if k in short), flush=True)
 
 
 if __name__ == "__main__":
@@ -146,7 +136,7 @@ if __name__ == "__main__":
         mode_fwd()
     elif mode == "step":
         rays = [int(a) for a in sys.argv[2:] if not a.startswith("c=")] or [1024]
-        combos = [tuple(int(x) for x in a[2:].split(":")) for a in sys.argv[2:] if a.startswith("c=")] or None
+        combos = [(int(a[2:]),) for a in sys.argv[2:] if a.startswith("c=")] or None
         mode_step(rays, combos)
     elif mode == "entries":
-        mode_entries([int(a) for a in sys.argv[2:]] or [0])
+        mode_entries()

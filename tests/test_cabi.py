@@ -144,8 +144,6 @@ def test_new_plan_options_and_blocked_prefix(lib):
     for opt in (lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0 and h.i2sdf_plan_set_option(plan, opt, 0) == 0
     assert h.i2sdf_plan_set_option(plan, 64, 1) != 0           # (the LDS source ring of rounds 2-3 is gone)
-    assert h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 63) == 0 and h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 0) == 0
-    assert h.i2sdf_plan_set_option(plan, lib.OPT_WAVE16, 64) != 0
     for opt in (lib.OPT_TRAIN_FWD_BF16X3, lib.OPT_SDF_BWD_BF16X3, lib.OPT_RGB_BF16X3, lib.OPT_TAIL_OVERLAP):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0
     M = 1024 * 98 + 1024 * 2                                   # the training batch: 98 shaded + 2 eikonal points per ray

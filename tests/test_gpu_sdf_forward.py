@@ -52,7 +52,7 @@ def test_sdf_forward_golden(golden, name, skip):
 
 @pytest.mark.parametrize("which", ["synthetic", "light", "plumbing", "plumbing_skip"])
 def test_sdf_forward_bf16x3(which):
-    """The bf16x3 split-arithmetic forward (x3.h) against the fp64 oracle at the SAME bar as the fp32 MFMA kernel, and
+    """The bf16x3 split-arithmetic forward (256-wide nets: 16-point waves, x3h.h; 64-wide: x3.h) against the fp64 oracle at the SAME bar as the fp32 MFMA kernel, and
     against the fp32 kernel itself."""
     from i2sdf_amd.config import synthetic_conf, plumbing_conf
     if which in ("synthetic", "light"):
@@ -74,28 +74,3 @@ def test_sdf_forward_bf16x3(which):
     e3 = assert_close(x3[idx], ref, 1e-5, "sdf (bf16x3)")
     print(f"max-norm relative error vs fp64: fp32 MFMA {e32:.2e}, bf16x3 {e3:.2e}")
     assert_close(x3, f32, 1e-5, "bf16x3 vs fp32 kernel, all points")
-
-
-@pytest.mark.parametrize("wg4", [False, True])
-@pytest.mark.parametrize("light", [False, True])
-def test_sdf_forward_wave16(light, wg4):
-    """The 16-point-wave kernels (x3h.h: v_mfma_f32_16x16x32_bf16, two waves per SIMD; 8 or 4 waves per workgroup) against the fp64
-    oracle at the bar of the 32-point kernels, and against those kernels on every point (ragged last workgroup included)."""
-    from i2sdf_amd.config import synthetic_conf
-    from i2sdf_amd import lib as L
-    ocfg, conf = orc.synthetic_cfg(light), synthetic_conf(light)
-    sd = orc.perturb_params(orc.init_params(ocfg, seed=3), 0.05, seed=4)
-    eng = _engine(conf, sd)
-    g = torch.Generator().manual_seed(23)
-    for M in (1, 77, 256 * 128 + 333):
-        x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.5
-        eng.set_wave16(0)
-        x3 = eng.sdf_forward(x.cuda()).cpu()
-        eng.set_wave16(L.W16_SDF_FWD | (L.W16_WG4 if wg4 else 0))
-        xh = eng.sdf_forward(x.cuda()).cpu()
-        idx = torch.cat([torch.arange(0, min(M, 2000)), torch.arange(max(M - 500, 0), M)]).unique()
-        ref = orc.sdf_forward({k: v.double() for k, v in sd.items()}, ocfg.sdf, x.double()[idx])[:, :1]
-        e3 = assert_close(x3[idx], ref, 1e-5, "sdf (32-point waves)")
-        eh = assert_close(xh[idx], ref, 1e-5, "sdf (16-point waves)")
-        assert_close(xh, x3, 1e-5, "16-point vs 32-point waves, all points")
-    print(f"max-norm relative error vs fp64: 32-point waves {e3:.2e}, 16-point waves {eh:.2e}")
