@@ -1,4 +1,4 @@
-// I2SDFLoss forward + gradient w.r.t. the render outputs in three tiny launches:
+// I2SDFLoss forward + gradient w.r.t. the render outputs in two tiny launches:
 // model/network/__init__.py:289-406 with its quirks (angular term = the same L1 normal term, :368-369).
 // Replaces ~100 element-wise torch kernels (forward and autograd backward) per training step.
 #include <algorithm>
@@ -24,7 +24,9 @@ struct LossArgs {
   float* partial;      // (LOSS_BLOCKS, S_N)
   float* sums;         // (S_N)
   float* cnt;          // (C_N)
+  int* arrived;        // workgroups of the reduction launch that have written their partial sums (0 on entry, 0 again on exit)
   float* losses;       // (10): loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask
+  float* loss_value;   // (1) | NULL: the total once more, as a tensor of its own
   float *g_rgb, *g_depth, *g_wsum, *g_normal, *g_grad_theta, *g_diff_norm, *g_surface, *g_lmask;
 };
 
@@ -75,21 +77,27 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < S_N) a.partial[blockIdx.x * S_N + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-}
-
-// stage 1 of the finalisation: block partials -> sums, and the local denominators
-__global__ void loss_sums_kernel(LossArgs a, int nblocks) {
+  // The workgroup that arrives last adds the block partials up -- in block order, whoever it is, so the sums do not depend on the
+  // schedule -- and sets the local denominators (what used to be a launch of its own).
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(a.arrived, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
   if (threadIdx.x < S_N) {
     float v = 0.f;
-    for (int b = 0; b < nblocks; ++b) v += a.partial[b * S_N + threadIdx.x];
+    for (int b = 0; b < (int)gridDim.x; ++b) v += a.partial[b * S_N + threadIdx.x];
     a.sums[threadIdx.x] = v;
     if (threadIdx.x == S_DEPTH_CNT) a.cnt[C_DEPTH] = v;
     if (threadIdx.x == S_NORMAL_CNT) a.cnt[C_NORMAL] = v;
   }
-  if (threadIdx.x == 0) { a.cnt[C_B] = (float)a.B; a.cnt[C_NPC] = (float)a.n_pc; }
+  if (threadIdx.x == 0) { a.cnt[C_B] = (float)a.B; a.cnt[C_NPC] = (float)a.n_pc; *a.arrived = 0; }
 }
 
-__global__ void loss_finalize_kernel(LossArgs a) {
+// the reported values (workgroup 0 of the gradient launch)
+__device__ __forceinline__ void loss_finalize(const LossArgs& a) {
   __shared__ float tot[S_N];
   if (threadIdx.x < S_N) tot[threadIdx.x] = a.sums[threadIdx.x];
   __syncthreads();
@@ -108,10 +116,12 @@ __global__ void loss_finalize_kernel(LossArgs a) {
                   a.c.angular_w * angular + a.c.bubble_w * bubble + a.c.light_w * light;
     a.losses[1] = rgb; a.losses[2] = eik; a.losses[3] = smooth; a.losses[4] = mask; a.losses[5] = depth;
     a.losses[6] = normal; a.losses[7] = angular; a.losses[8] = bubble; a.losses[9] = light;
+    if (a.loss_value) a.loss_value[0] = a.losses[0];
   }
 }
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
+  if (blockIdx.x == 0) loss_finalize(a);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float B = a.cnt[C_B];
   if (i < a.B) {
@@ -231,13 +241,13 @@ __global__ __launch_bounds__(256) void eik_out_bwd_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N + C_N + 2; }
+extern "C" int64_t i2sdf_loss_scratch_floats(void) { return LOSS_BLOCKS * S_N + S_N + C_N + 4; }
 
 extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_pc, const float* rgb, const float* depth,
                                            const float* wsum, const float* normal, const float* grad_theta, const float* diff_norm,
                                            const float* surface, const float* lmask, const float* gt_rgb, const float* gt_depth,
                                            const uint8_t* depth_mask, const float* gt_normal, const uint8_t* normal_mask, const float* gt_mask,
-                                           const float* gt_lmask, float* scratch, float* losses, float* g_rgb, float* g_depth, float* g_wsum,
+                                           const float* gt_lmask, float* scratch, float* losses, float* loss_value, float* g_rgb, float* g_depth, float* g_wsum,
                                            float* g_normal, float* g_grad_theta, float* g_diff_norm, float* g_surface, float* g_lmask,
                                            void* stream) {
   if (!cfg || B <= 0 || !rgb || !depth || !wsum || !gt_rgb || !scratch || !losses || !g_rgb || !g_depth || !g_wsum) return I2SDF_EINVAL;
@@ -247,20 +257,19 @@ extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B,
   a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.normal = normal; a.grad_theta = grad_theta; a.diff_norm = diff_norm; a.surface = surface;
   a.lmask = lmask; a.gt_rgb = gt_rgb; a.gt_depth = gt_depth; a.gt_normal = gt_normal; a.gt_mask = gt_mask; a.gt_lmask = gt_lmask;
   a.depth_mask = depth_mask; a.normal_mask = normal_mask;
-  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.cnt = a.sums + S_N; a.losses = losses;
+  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.cnt = a.sums + S_N; a.arrived = (int*)(a.cnt + C_N); a.losses = losses;
+  a.loss_value = loss_value;
   a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_wsum = g_wsum; a.g_normal = g_normal; a.g_grad_theta = g_grad_theta; a.g_diff_norm = g_diff_norm;
   a.g_surface = g_surface; a.g_lmask = g_lmask;
   hipStream_t st = (hipStream_t)stream;
   const int64_t work = std::max<int64_t>(2 * B, a.n_pc);
   const int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (work + 255) / 256);
   loss_partial_kernel<<<nb, 256, 0, st>>>(a);
-  loss_sums_kernel<<<1, 64, 0, st>>>(a, nb);
   if (cfg->exchange) {       // data parallel: denominators -> their mean over the ranks (global count / world)
     if (!cfg->exchange->allreduce) return I2SDF_EINVAL;
     const int rc = cfg->exchange->allreduce(cfg->exchange->ctx, a.cnt, C_N, I2SDF_XCHG_F32, I2SDF_XCHG_AVG, stream);
     if (rc) return rc;
   }
-  loss_finalize_kernel<<<1, 64, 0, st>>>(a);
   loss_grad_kernel<<<(unsigned)((work + 255) / 256), 256, 0, st>>>(a);
   return i2sdf_hip_check(hipGetLastError(), "loss_forward_backward launch");
 }

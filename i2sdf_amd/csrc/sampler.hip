@@ -11,7 +11,9 @@
 //   per iteration it (row length n = N_eval * (it + 1)):
 //     [sdf_forward on the newest samples]                                   (mlp_fwd.hip, ray mode)
 //     sampler_beta_kernel     : merge sdf, d* bound, error bound at beta0, bisection -> beta; atomic OR of "beta > beta0"
-//     sampler_resample_kernel : batch flag -> mode; density, transmittance, pdf/cdf, inverse-CDF samples, sorted merge
+//     sampler_resample_kernel : batch flag -> mode; density, transmittance, pdf/cdf, inverse-CDF samples, sorted merge; the last
+//                               workgroup to finish raises the "done" flag (no separate launch)
+//     (a caller-fixed iteration count needs no batch flag: sampler_iter_fixed_kernel does both steps in one launch)
 //   sampler_final_kernel      : near/far/extra samples, sort, eikonal sample
 #include "plan.h"
 
@@ -26,7 +28,7 @@ constexpr int NNEW = 128;        // most new samples per iteration
 constexpr int EMAX = NMAX / 64;
 
 // state words
-enum { ST_DONE = 0, ST_ITERS = 1, ST_FLAG0 = 2 /* +it */, ST_WORDS = 16 };
+enum { ST_DONE = 0, ST_ITERS = 1, ST_FLAG0 = 2 /* +it */, ST_CNT0 = 16 /* +it: workgroups that finished step B of iteration it */, ST_WORDS = 32 };
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -162,24 +164,20 @@ __device__ __forceinline__ void load_row(Row<E>& r, const float* z, const float*
 }
 
 // ---- step A: merged sdf row, d*, beta line search (ray_sampler.py:88-132) + batch flag (:151) ----------------
+// fills r with the merged row of ray rc (and its intervals), stores the merged sdf row, returns the ray's new beta
 template <int E>
-__global__ __launch_bounds__(256) void sampler_beta_kernel(SamplerArgs a) {
-  if (a.state[ST_DONE]) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= a.B) return;
+__device__ __forceinline__ float beta_step(const SamplerArgs& a, Row<E>& r, int64_t rc, bool active, int lane) {
   const float beta0 = fabsf(a.beta_param[0]) + a.beta_min;
   const int n = a.n;
   // merge: sdf_cur[j] = idx[j] < n_old ? sdf_prev[idx[j]] : sdf_new[idx[j]-n_old]   (ray_sampler.py:90-95)
-  float* sc = a.sdf_cur + ray * NMAX;
-  const float* zc = a.z_cur + ray * NMAX;
-  Row<E> r;
+  float* sc = a.sdf_cur + rc * NMAX;
+  const float* zc = a.z_cur + rc * NMAX;
   r.n = n;
   {
     const int n_old = n - a.n_new;
-    const int* ix = a.idx + ray * NMAX;
-    const float* sp = a.sdf_prev + ray * NMAX;
-    const float* sn = a.sdf_new + ray * a.n_new;
+    const int* ix = a.idx + rc * NMAX;
+    const float* sp = a.sdf_prev + rc * NMAX;
+    const float* sn = a.sdf_new + rc * a.n_new;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int j = lane * E + e;
@@ -188,13 +186,13 @@ __global__ __launch_bounds__(256) void sampler_beta_kernel(SamplerArgs a) {
         zv = zc[j];
         if (a.it == 0) sv = sn[j];
         else { const int k = ix[j]; sv = (k < n_old) ? sp[k] : sn[k - n_old]; }
-        sc[j] = sv;
+        if (active) sc[j] = sv;
       }
       r.z[e] = zv; r.s[e] = sv;
     }
   }
   row_intervals<E>(r, lane);
-  float beta = a.beta[ray];
+  float beta = a.beta[rc];
   const float err0 = row_error_bound<E>(r, beta0, lane);
   if (err0 <= a.eps) beta = beta0;
   float bmin = beta0, bmax = beta;
@@ -203,32 +201,28 @@ __global__ __launch_bounds__(256) void sampler_beta_kernel(SamplerArgs a) {
     const float err = row_error_bound<E>(r, bmid, lane);
     if (err <= a.eps) bmax = bmid; else bmin = bmid;
   }
-  beta = bmax;
+  return bmax;
+}
+template <int E>
+__global__ __launch_bounds__(256) void sampler_beta_kernel(SamplerArgs a) {
+  if (a.state[ST_DONE]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.B) return;
+  Row<E> r;
+  const float beta = beta_step<E>(a, r, ray, true, lane);
   if (lane == 0) {
     a.beta[ray] = beta;
-    if (beta > beta0) atomicOr(&a.state[ST_FLAG0 + a.it], 1);
+    if (beta > fabsf(a.beta_param[0]) + a.beta_min) atomicOr(&a.state[ST_FLAG0 + a.it], 1);
   }
 }
 
 // ---- step B: density/transmittance, pdf, inverse CDF, merge (ray_sampler.py:139-212) --------------------------
+// the row r of ray rc (intervals computed) and its beta -> new samples, and for `more` the merged row of the next iteration
 template <int E>
-__global__ __launch_bounds__(256) void sampler_resample_kernel(SamplerArgs a) {
-  __shared__ float s_cdf[4][NMAX + 1];
-  __shared__ float s_z[4][NMAX];
-  __shared__ float s_new[4][NNEW];
-  if (a.state[ST_DONE]) return;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
-  const bool active = ray < a.B;
-  const int64_t rc = active ? ray : a.B - 1;
+__device__ __forceinline__ void resample_step(const SamplerArgs& a, const Row<E>& r, float beta, bool more, int64_t ray, int64_t rc, bool active,
+                                              float (&s_cdf)[4][NMAX + 1], float (&s_z)[4][NMAX], float (&s_new)[4][NNEW], int lane, int wv) {
   const int n = a.n;
-  bool not_conv = a.state[ST_FLAG0 + a.it] != 0;
-  if (a.force_iters > 0) not_conv = (a.it + 1) < a.force_iters;
-  const bool more = not_conv && (a.it + 1 < a.max_iters);
-  Row<E> r;
-  load_row<E>(r, a.z_cur + rc * NMAX, a.sdf_cur + rc * NMAX, n, lane);
-  row_intervals<E>(r, lane);
-  const float beta = a.beta[rc];
   const float ib = 1.0f / beta;
   // free energy with the 1e10 tail, transmittance, weights (ray_sampler.py:139-147)
   float fe[E], cum[E];
@@ -302,9 +296,7 @@ __global__ __launch_bounds__(256) void sampler_resample_kernel(SamplerArgs a) {
     if (active) a.samples[ray * NNEW + k] = smp;
   }
   __syncthreads();
-  if (!more) {
-    return;                 // ST_DONE / ST_ITERS are set by `sampler_mark_kernel`, enqueued after this step
-  }
+  if (!more) return;
   // sorted merge of z (n) and the N new samples -> z_nxt (n+N), idx_nxt (ray_sampler.py:211-212); stable: old first
   if (active) {
     float* zn = a.z_nxt + ray * NMAX;
@@ -324,12 +316,55 @@ __global__ __launch_bounds__(256) void sampler_resample_kernel(SamplerArgs a) {
   }
 }
 
-// raises ST_DONE once the iteration that produced the final samples has finished (own launch = grid-wide ordering)
-__global__ void sampler_mark_kernel(int* state, int it, int max_iters, int force_iters) {
-  if (state[ST_DONE]) return;
-  bool not_conv = state[ST_FLAG0 + it] != 0;
-  if (force_iters > 0) not_conv = (it + 1) < force_iters;
-  if (!(not_conv && (it + 1 < max_iters))) { state[ST_DONE] = 1; state[ST_ITERS] = it + 1; }
+// The last workgroup to finish step B of the iteration that produced the final samples raises ST_DONE: every workgroup of this
+// launch has finished by then, and the launches behind it (the remaining iterations, enqueued up front) return at once.
+__device__ __forceinline__ void iteration_done(const SamplerArgs& a, bool more) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int c = atomicAdd(&a.state[ST_CNT0 + a.it], 1);
+    if (c == (int)gridDim.x - 1 && !more) { a.state[ST_ITERS] = a.it + 1; __threadfence(); a.state[ST_DONE] = 1; }
+  }
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void sampler_resample_kernel(SamplerArgs a) {
+  __shared__ float s_cdf[4][NMAX + 1];
+  __shared__ float s_z[4][NMAX];
+  __shared__ float s_new[4][NNEW];
+  if (a.state[ST_DONE]) return;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+  const bool active = ray < a.B;
+  const int64_t rc = active ? ray : a.B - 1;
+  bool not_conv = a.state[ST_FLAG0 + a.it] != 0;
+  if (a.force_iters > 0) not_conv = (a.it + 1) < a.force_iters;
+  const bool more = not_conv && (a.it + 1 < a.max_iters);
+  Row<E> r;
+  load_row<E>(r, a.z_cur + rc * NMAX, a.sdf_cur + rc * NMAX, a.n, lane);
+  row_intervals<E>(r, lane);
+  resample_step<E>(a, r, a.beta[rc], more, ray, rc, active, s_cdf, s_z, s_new, lane, wv);
+  iteration_done(a, more);
+}
+
+// Steps A and B in one launch when the iteration count is fixed by the caller (force_iters > 0): the batch-global test
+// `beta.max() > beta0` (ray_sampler.py:151), which needs every ray's step A before any ray's step B, is not consulted then, and
+// the row stays in registers between the steps.
+template <int E>
+__global__ __launch_bounds__(256) void sampler_iter_fixed_kernel(SamplerArgs a) {
+  __shared__ float s_cdf[4][NMAX + 1];
+  __shared__ float s_z[4][NMAX];
+  __shared__ float s_new[4][NNEW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
+  const bool active = ray < a.B;
+  const int64_t rc = active ? ray : a.B - 1;
+  const bool more = ((a.it + 1) < a.force_iters) && (a.it + 1 < a.max_iters);
+  Row<E> r;
+  const float beta = beta_step<E>(a, r, rc, active, lane);
+  if (active && lane == 0) a.beta[ray] = beta;
+  resample_step<E>(a, r, beta, more, ray, rc, active, s_cdf, s_z, s_new, lane, wv);
+  iteration_done(a, more);
 }
 
 // ---- initial uniform / stratified samples + Lemma-2 beta (ray_sampler.py:22-43, 75-77) ------------------------
@@ -371,13 +406,14 @@ __global__ __launch_bounds__(256) void sampler_final_kernel(int64_t B, const int
                                                              const float* z_b, const float* __restrict__ samples, int N_final, int N_extra,
                                                              const int* __restrict__ extra_idx, const int* __restrict__ extra_tab,
                                                              float near, float far, const int* __restrict__ eik_idx, float* __restrict__ z_out,
-                                                             int64_t ldz, float* __restrict__ z_eik) {
+                                                             int64_t ldz, float* __restrict__ z_eik, int* __restrict__ iters_out) {
   __shared__ float buf[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t ray = (int64_t)blockIdx.x * 4 + wv;
   const bool active = ray < B;
   const int64_t rc = active ? ray : B - 1;
   const int iters = state[ST_ITERS];
+  if (iters_out != nullptr && blockIdx.x == 0 && threadIdx.x == 0) iters_out[0] = iters;      // the caller's copy of the iteration count
   const int n_row = N_eval * iters;
   const float* zr = ((iters & 1) ? z_a : z_b) + rc * NMAX;       // row used by the last executed iteration
   const int total = N_final + 2 + N_extra;
@@ -450,6 +486,10 @@ __global__ __launch_bounds__(256) void error_bound_kernel(int64_t B, int n, cons
 template <int E>
 int launch_iter(const SamplerArgs& a, hipStream_t st, const i2sdf_exchange* ex) {
   const unsigned grid = (unsigned)((a.B + 3) / 4);
+  if (a.force_iters > 0 && !ex) {          // fixed iteration count: one launch per iteration
+    sampler_iter_fixed_kernel<E><<<grid, 256, 0, st>>>(a);
+    return I2SDF_OK;
+  }
   sampler_beta_kernel<E><<<grid, 256, 0, st>>>(a);
   // 1-GPU-equivalent data parallelism: `beta.max() > beta0` (ray_sampler.py:151) over the rays of ALL ranks
   if (ex) {
@@ -457,7 +497,6 @@ int launch_iter(const SamplerArgs& a, hipStream_t st, const i2sdf_exchange* ex) 
     if (rc) return rc;
   }
   sampler_resample_kernel<E><<<grid, 256, 0, st>>>(a);
-  sampler_mark_kernel<<<1, 1, 0, st>>>(a.state, a.it, a.max_iters, a.force_iters);
   return I2SDF_OK;
 }
 
@@ -562,10 +601,6 @@ extern "C" int i2sdf_sample_rays(const i2sdf_plan* p, const float* packed, const
   }
   sampler_final_kernel<<<grid, 256, 0, st>>>(B, state, sc->N_samples_eval, zA, zB, samples, sc->N_samples, sc->N_samples_extra,
                                              training ? (const int*)extra_idx : nullptr, (const int*)extra_tab, near, far, (const int*)eik_idx, z_out, ldz,
-                                             z_eik);
-  if (iters_out) {
-    hipError_t e = hipMemcpyAsync(iters_out, state + ST_ITERS, sizeof(int), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return i2sdf_hip_check(e, "sample_rays iters copy");
-  }
+                                             z_eik, iters_out);
   return i2sdf_hip_check(hipGetLastError(), "sample_rays launch");
 }

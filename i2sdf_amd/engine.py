@@ -27,6 +27,7 @@ class RenderEngine:
         self.pack_floats = int(self._lib.i2sdf_plan_pack_floats(plan))
         self.wgrad_floats = int(self._lib.i2sdf_plan_wgrad_floats(plan))
         self.packed = torch.zeros(self.pack_floats, dtype=torch.float32, device=self.device)
+        self._pack_stream, self._pack_event = None, None
         self.F = cfg.feature_size
         self.sdf_forward_bf16x3 = False
         self.wgrad_bf16x3 = False
@@ -120,7 +121,28 @@ class RenderEngine:
     def pack(self, flat_params: torch.Tensor):
         """weight-norm reparametrisation + stream packing; call after every parameter update."""
         assert flat_params.is_cuda and flat_params.dtype == torch.float32 and flat_params.numel() == self.layout.n_params
-        L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
+        # On a side stream: the two pack launches (35 us) then run beside the ray set-up, the draws and the sampler's first kernel instead
+        # of in front of them; the first entry point that reads the streams waits for the event (`_pk`).  The side stream first waits
+        # for everything enqueued so far (the optimizer's update of the parameters, the previous step's readers of `packed`).
+        if os.environ.get("I2SDF_PACK_ASYNC", "1") == "0":
+            L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
+            return
+        dev = flat_params.device
+        side = self._pack_stream
+        if side is None:
+            side = self._pack_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
+            self._pack_event = side.record_event()
+
+    def _pk(self):
+        """pointer to the packed weight streams, after making the current stream wait for a pack still in flight"""
+        ev = self._pack_event
+        if ev is not None:
+            torch.cuda.current_stream(self.packed.device).wait_event(ev)
+            self._pack_event = None
+        return L.ptr(self.packed)
 
     def set_sdf_forward_bf16x3(self, on: bool):
         """Evaluate the sdf-only forward (sampler passes, grid queries) in bf16x3 split arithmetic (include/i2sdf.h,
@@ -236,7 +258,7 @@ class RenderEngine:
         M = pts.shape[0]
         sdf = torch.empty(M, 1, dtype=torch.float32, device=pts.device)
         feat = torch.empty(M, self.F, dtype=torch.float32, device=pts.device) if want_features else None
-        L.check(self._lib.i2sdf_sdf_forward(self._plan, L.ptr(self.packed), L.ptr(pts), M, L.ptr(sdf), L.ptr(feat), self.F,
+        L.check(self._lib.i2sdf_sdf_forward(self._plan, self._pk(), L.ptr(pts), M, L.ptr(sdf), L.ptr(feat), self.F,
                                             L.stream_ptr()), "i2sdf_sdf_forward")
         return (sdf, feat) if want_features else sdf
 
@@ -269,7 +291,7 @@ class RenderEngine:
         out["hs"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
         out["abars"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
         out["pe"] = torch.empty(Mp, 40, dtype=torch.float32, device=dev) if save else None
-        L.check(self._lib.i2sdf_sdf_forward_grad(self._plan, L.ptr(self.packed), L.ptr(pts), L.ptr(cam), L.ptr(dirs), L.ptr(z),
+        L.check(self._lib.i2sdf_sdf_forward_grad(self._plan, self._pk(), L.ptr(pts), L.ptr(cam), L.ptr(dirs), L.ptr(z),
                                                   ldz, npr, n_ray, M, Mp, L.ptr(out["sdf"]), L.ptr(out["feat"]), L.ptr(out["grad"]),
                                                   L.ptr(out["hs"]), L.ptr(out["abars"]), L.ptr(out["pe"]), L.stream_ptr()),
                  "i2sdf_sdf_forward_grad")
@@ -281,7 +303,7 @@ class RenderEngine:
         Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
         rs = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=feat.device) if save else None
         pev = torch.empty(Mp, 32, dtype=torch.float32, device=feat.device) if save else None
-        L.check(self._lib.i2sdf_rgb_forward(self._plan, L.ptr(self.packed), L.ptr(dirs.contiguous()), n_per_ray, L.ptr(feat), M, Mp,
+        L.check(self._lib.i2sdf_rgb_forward(self._plan, self._pk(), L.ptr(dirs.contiguous()), n_per_ray, L.ptr(feat), M, Mp,
                                              L.ptr(rgb), L.ptr(rs), L.ptr(pev), L.stream_ptr()), "i2sdf_rgb_forward")
         return rgb, rs, pev
 
@@ -291,7 +313,7 @@ class RenderEngine:
         gar = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=dev)
         ga_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
         fbar = torch.empty(Mp, self.F, dtype=torch.float32, device=dev)
-        L.check(self._lib.i2sdf_rgb_backward(self._plan, L.ptr(self.packed), L.ptr(rgb), L.ptr(rgb_bar.contiguous()), L.ptr(rs), M, Mp,
+        L.check(self._lib.i2sdf_rgb_backward(self._plan, self._pk(), L.ptr(rgb), L.ptr(rgb_bar.contiguous()), L.ptr(rs), M, Mp,
                                               L.ptr(gar), L.ptr(ga_last), L.ptr(fbar), L.stream_ptr()), "i2sdf_rgb_backward")
         return gar, ga_last, fbar
 
@@ -305,7 +327,7 @@ class RenderEngine:
              "gas": torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
              "ones4": torch.empty(Mp, 4, dtype=torch.float32, device=dev)}
         c = lambda t: None if t is None else t.contiguous()
-        L.check(self._lib.i2sdf_sdf_backward(self._plan, L.ptr(self.packed), L.ptr(fw["pts"]), L.ptr(cam), L.ptr(dirs), L.ptr(z),
+        L.check(self._lib.i2sdf_sdf_backward(self._plan, self._pk(), L.ptr(fw["pts"]), L.ptr(cam), L.ptr(dirs), L.ptr(z),
                                               z.shape[1] if z is not None else 0, npr, fw["n_ray_pts"], M, Mp,
                                               L.ptr(fw["hs"]), L.ptr(fw["abars"]), L.ptr(c(sbar)), L.ptr(c(fbar)), m_fbar, L.ptr(c(nbar)),
                                               L.ptr(o["gus"]), L.ptr(o["gpbar"]), L.ptr(o["gas"]), L.ptr(o["ga_last4"]), L.ptr(o["ones4"]),
@@ -414,7 +436,7 @@ class RenderEngine:
         ws = torch.empty(int(self._lib.i2sdf_sampler_workspace_floats(B)), dtype=torch.float32, device=dev)
         z_out = torch.empty(B, self.n_z, dtype=torch.float32, device=dev)
         z_eik = torch.empty(B, 1, dtype=torch.float32, device=dev)
-        iters = torch.zeros(1, dtype=torch.int32, device=dev)
+        iters = torch.empty(1, dtype=torch.int32, device=dev) if B > 0 else torch.zeros(1, dtype=torch.int32, device=dev)      # written by the final kernel
         i32 = lambda t: None if t is None else t.to(torch.int32).contiguous()
         if training:
             u_final, ldu = cdf_u.contiguous(), cdf_u.shape[1]
@@ -422,7 +444,7 @@ class RenderEngine:
             u_final, ldu = self.u_final, 0
         ex, ek = i32(extra_idx), i32(eik_idx)
         su = None if strat_u is None else strat_u.contiguous()
-        L.check(self._lib.i2sdf_sample_rays(self._plan, L.ptr(self.packed), L.ptr(flat_params), C.byref(self._scfg), L.ptr(cam.contiguous()),
+        L.check(self._lib.i2sdf_sample_rays(self._plan, self._pk(), L.ptr(flat_params), C.byref(self._scfg), L.ptr(cam.contiguous()),
                                              L.ptr(dirs.contiguous()), B, 1 if training else 0, L.ptr(self.t_lin), L.ptr(self.u_more),
                                              L.ptr(u_final), ldu, L.ptr(self.extra_tab), L.ptr(su), L.ptr(ex), L.ptr(ek), force_iters,
                                              L.ptr(ws), L.ptr(z_out), self.n_z, L.ptr(z_eik), L.ptr(iters), L.stream_ptr()),
@@ -466,7 +488,7 @@ class RenderEngine:
         o = {"rgb": e(P, 3), "depth": e(P), "wsum": e(P, 1), "normal": e(P, 3) if want_normal else None,
              "lmask": e(P, 1) if self.cfg.light is not None else None, "z": e(P, self.n_z) if want_z else None,
              "iters": torch.zeros((P + chunk - 1) // chunk, dtype=torch.int32, device=dev)}
-        L.check(self._lib.i2sdf_render_image(self._plan, L.ptr(self.packed), L.ptr(flat_params), C.byref(self._scfg), L.ptr(uv), L.ptr(pose),
+        L.check(self._lib.i2sdf_render_image(self._plan, self._pk(), L.ptr(flat_params), C.byref(self._scfg), L.ptr(uv), L.ptr(pose),
                                              int(quat), L.ptr(intrinsics), P, chunk, L.ptr(self.t_lin), L.ptr(self.u_more), L.ptr(self.u_final),
                                              L.ptr(self.extra_tab), L.ptr(ws), L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["wsum"]),
                                              L.ptr(o["normal"]), L.ptr(o["lmask"]), L.ptr(o["z"]), L.ptr(o["iters"]), L.stream_ptr()),
@@ -491,7 +513,7 @@ class RenderEngine:
         out = torch.empty(count, dtype=torch.float32, device=dev)
         host = lambda v, n: None if v is None else (C.c_float * n)(*[float(a) for a in torch.as_tensor(v, dtype=torch.float32).reshape(-1).tolist()])
         r, t = host(rot, 9), host(trans, 3)
-        L.check(self._lib.i2sdf_sdf_grid(self._plan, L.ptr(self.packed), L.ptr(x), L.ptr(y), L.ptr(z), nx, ny, nz, int(order),
+        L.check(self._lib.i2sdf_sdf_grid(self._plan, self._pk(), L.ptr(x), L.ptr(y), L.ptr(z), nx, ny, nz, int(order),
                                          C.cast(r, C.c_void_p) if r is not None else None, C.cast(t, C.c_void_p) if t is not None else None,
                                          int(first), int(count), L.ptr(out), L.ptr(ws), chunk, L.stream_ptr()), "i2sdf_sdf_grid")
         return out
@@ -502,7 +524,7 @@ class RenderEngine:
         HL = self.cfg.light.hidden
         lm = torch.empty(M, dtype=torch.float32, device=dev)
         hl = torch.empty(Mp, HL, dtype=torch.float32, device=dev) if save else None
-        L.check(self._lib.i2sdf_light_forward(self._plan, L.ptr(self.packed), L.ptr(feat), M, Mp, L.ptr(lm), L.ptr(hl), L.stream_ptr()),
+        L.check(self._lib.i2sdf_light_forward(self._plan, self._pk(), L.ptr(feat), M, Mp, L.ptr(lm), L.ptr(hl), L.stream_ptr()),
                  "i2sdf_light_forward")
         return lm, hl
 
@@ -510,6 +532,6 @@ class RenderEngine:
         Mp, dev = hl.shape[0], hl.device
         gal0 = torch.empty(Mp, hl.shape[1], dtype=torch.float32, device=dev)
         gal_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
-        L.check(self._lib.i2sdf_light_backward(self._plan, L.ptr(self.packed), L.ptr(lm), L.ptr(lm_bar.contiguous()), L.ptr(hl), M, Mp,
+        L.check(self._lib.i2sdf_light_backward(self._plan, self._pk(), L.ptr(lm), L.ptr(lm_bar.contiguous()), L.ptr(hl), M, Mp,
                                                 L.ptr(gal0), L.ptr(gal_last), L.stream_ptr()), "i2sdf_light_backward")
         return gal0, gal_last

@@ -143,7 +143,7 @@ SIGNATURES = {
     "i2sdf_light_forward": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_light_backward": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "i2sdf_loss_scratch_floats": (_I64, []),
-    "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 26),
+    "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 27),
     "i2sdf_eikonal_outputs_forward": (C.c_int, [_P, _I64, _P, _P, _P]),
     "i2sdf_extra_points": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
     "i2sdf_backward_seeds": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P]),

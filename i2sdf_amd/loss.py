@@ -10,10 +10,11 @@ import torch.nn as nn
 
 
 class _FusedLossFn(torch.autograd.Function):
-    """value + gradient of the whole loss in three HIP launches (include/i2sdf.h: i2sdf_loss_forward_backward)."""
+    """value + gradient of the whole loss in two HIP launches (include/i2sdf.h: i2sdf_loss_forward_backward).  Returns the total as a
+    0-dim tensor of its own (the only differentiable output) and the vector of the ten reported values."""
 
     @staticmethod
-    def forward(ctx, cfg, n_pc, gt, rgb, depth, wsum, normal, grad_theta, diff_norm, surface, lmask):
+    def forward(ctx, cfg, n_pc, gt, scratch, rgb, depth, wsum, normal, grad_theta, diff_norm, surface, lmask):
         from . import lib as L
         lib = L.load()
         dev = rgb.device
@@ -32,22 +33,22 @@ class _FusedLossFn(torch.autograd.Function):
                 assert gts[m].dtype == torch.bool or gts[m].dtype == torch.uint8
         grads = [torch.empty_like(t) if t is not None else None for t in ins]
         losses = torch.empty(10, dtype=torch.float32, device=dev)
-        scratch = torch.empty(int(lib.i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             L.check(lib.i2sdf_loss_forward_backward(cfg, B, n_pc, *[L.ptr(t) for t in ins], L.ptr(gts[0]), L.ptr(gts[1]), L.ptr(gts[2]),
                                                     L.ptr(gts[3]), L.ptr(gts[4]), L.ptr(gts[5]), L.ptr(gts[6]), L.ptr(scratch), L.ptr(losses),
-                                                    *[L.ptr(g) for g in grads], L.stream_ptr()), "i2sdf_loss_forward_backward")
+                                                    L.ptr(total), *[L.ptr(g) for g in grads], L.stream_ptr()), "i2sdf_loss_forward_backward")
         if diff_norm is not None and not (cfg._obj.smooth_on and cfg._obj.smooth_w > 0):
             grads[5] = None      # smoothness term inactive (:347-349): its gradient is identically zero -- let autograd skip that branch
         ctx.grads = grads
-        return losses
+        ctx.mark_non_differentiable(losses)
+        return total, losses
 
     @staticmethod
-    def backward(ctx, g):
-        scale = g[0]            # only `loss` (entry 0) is differentiable; the itemised entries are reported values
+    def backward(ctx, g, _g_items):
         live = [gr for gr in ctx.grads if gr is not None]
-        scaled = iter(torch._foreach_mul(live, scale))          # one launch for all of them
-        out = [None, None, None] + [(next(scaled) if gr is not None else None) for gr in ctx.grads]
+        scaled = iter(torch._foreach_mul(live, g))          # one launch for all of them
+        out = [None, None, None, None] + [(next(scaled) if gr is not None else None) for gr in ctx.grads]
         ctx.grads = None
         return tuple(out)
 
@@ -64,6 +65,7 @@ class I2SDFLoss(nn.Module):
         if self.bubble_weight > 0 and self.max_bubble_iter is not None and self.smooth_iter < self.max_bubble_iter:
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
+        self._scratch = {}         # per device: the reduction scratch, zeroed once (its arrival counter resets itself, include/i2sdf.h)
         self.exchange = None       # i2sdf_amd.dist.attach_loss: lib.Exchange hook -> global denominators (1-GPU-equivalent data parallelism)
         self._dp_state = None      # the attached module's DataParallelState (its `enabled` flag: no_sync())
 
@@ -90,14 +92,18 @@ class I2SDFLoss(nn.Module):
         if not ("light_mask" in out and self.light_mask_weight > 0 and "light_mask" in gt):
             gtc.pop("light_mask", None)
         import ctypes as C
-        vec = _FusedLossFn.apply(C.byref(cfg), 0 if surf is None else surf.shape[0], gtc, out["rgb_values"], out["depth_values"],
+        dev = out["rgb_values"].device
+        scratch = self._scratch.get(dev)
+        if scratch is None:
+            scratch = self._scratch[dev] = torch.zeros(int(L.load().i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
+        total, vec = _FusedLossFn.apply(C.byref(cfg), 0 if surf is None else surf.shape[0], gtc, scratch, out["rgb_values"], out["depth_values"],
                                  out["weight_sum"].reshape(-1), out.get("normal_values"), out.get("grad_theta"), out.get("diff_norm"),
                                  None if surf is None else surf.reshape(-1),
                                  out["light_mask"].reshape(-1) if "light_mask" in out else None)
         names = ["loss", "rgb_loss", "eikonal_loss", "smooth_loss", "mask_loss", "depth_loss", "normal_loss", "angular_loss", "bubble_loss",
                  "light_mask_loss"]
-        res = {n: vec[i].detach() for i, n in enumerate(names)}
-        res["loss"] = vec[0]
+        res = {n: vec[i] for i, n in enumerate(names)}
+        res["loss"] = total
         return res
 
     def forward(self, out, gt, current_step):

@@ -432,8 +432,12 @@ int i2sdf_light_backward(const i2sdf_plan* plan, const float* packed, const floa
  * normal (B,3)|NULL, grad_theta (2B,3)|NULL, diff_norm (B)|NULL, surface (n_pc)|NULL, lmask (B)|NULL; ground truth
  * gt_rgb (B,3), gt_depth (B)+depth_mask (B bytes)|NULL, gt_normal (B,3)+normal_mask|NULL, gt_mask (B)|NULL,
  * gt_lmask (B)|NULL.  `smooth_on` = the reference's `smooth_iter is None or step > smooth_iter` (:347).
- *   -> losses[10] = {loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask} (device),
- *      g_* = d loss / d (same-named input); scratch: i2sdf_loss_scratch_floats() floats.
+ *   -> losses[10] = {loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask} (device), loss_value (1)|NULL = the
+ *      total once more as a tensor of its own (a scalar for autograd without a select on the vector),
+ *      g_* = d loss / d (same-named input); scratch: i2sdf_loss_scratch_floats() floats, of which the LAST FOUR must be zero on entry
+ *      and are zero again on exit (an arrival counter: a buffer zeroed once can be reused by every call on one stream).
+ *   Two launches: per-block partial sums whose last-arriving workgroup reduces them (in block order: deterministic), [the exchange
+ *   hook], then the reported values + every gradient.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct i2sdf_loss_cfg {
   float eikonal_w, smooth_w, mask_w, depth_w, normal_w, angular_w, bubble_w, light_w;
@@ -448,7 +452,7 @@ int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B, int64_t n_
                                 const float* wsum, const float* normal, const float* grad_theta, const float* diff_norm,
                                 const float* surface, const float* lmask, const float* gt_rgb, const float* gt_depth,
                                 const uint8_t* depth_mask, const float* gt_normal, const uint8_t* normal_mask, const float* gt_mask,
-                                const float* gt_lmask, float* scratch, float* losses, float* g_rgb, float* g_depth, float* g_wsum,
+                                const float* gt_lmask, float* scratch, float* losses, float* loss_value, float* g_rgb, float* g_depth, float* g_wsum,
                                 float* g_normal, float* g_grad_theta, float* g_diff_norm, float* g_surface, float* g_lmask,
                                 void* stream);
 
