@@ -17,10 +17,12 @@ gradients) -> [N>1: one flat all-reduce] -> Adam step.  Inputs are resident in H
 
 Arithmetic: fp32 storage and fp32 accumulation everywhere; the matrix products run either on fp32-input MFMA or (default) as
 bf16x3 split products on the bf16 MFMA pipe (three bf16 terms per fp32 operand, six partial products, error 2^-24:
-fp32-equivalent, csrc/x3.h) -- `dtype` says which.
+fp32-equivalent, csrc/x3.h).  Since round 4 the 256x256 weight-gradient GEMMs use TWO bf16 terms per operand by default (three
+products, per-product error <= 3 * 2^-18; every parameter gradient at 3e-6 of the fp64 oracle, the whole GPU suite runs in both
+modes); the sub-record `wgrad_bf16x3` is the same step with the fp32-equivalent form there too -- `dtype` says which.
 
 Timing: W warm-up steps, then --windows windows of EXACTLY K steps each, every window bracketed by a barrier + device
-synchronisation on both sides and reduced with MAX over the ranks.  `ms_per_step` / `value` are the MEDIAN window (the chip's DVFS and
+synchronisation on both sides and reduced with MAX over the ranks (sub-records: --sub-windows windows each, median).  `ms_per_step` / `value` are the MEDIAN window (the chip's DVFS and
 the boxes of the pool move a 20-step window by 1-2 %); `windows_ms_per_step` lists them all, `ms_per_step_min` is the fastest.
 
 Per-entry-point times (`kernels`, `roofline`): the timed steps run the per-point entry points as a CHAIN of point ranges on several
@@ -33,8 +35,9 @@ starts itself on a 3-step run of the same workload.
 
 Sub-records of the same JSON line: `dense128` (BASELINE.json's metric convention: 128 shaded samples/ray, sampler bypassed),
 `strong` (fixed global batch of --strong-rays rays split over the ranks), `k1` / `k5` / `natural_k` (sampler iteration count fixed
-to 1 / 5, and the data-dependent loop, instead of k=2), `wgrad_bf16x2` (opt-in two-term split arithmetic in the weight-gradient
-kernel only), `roofline`, `cpu_baseline` (the CPU restatement on this node's host cores: best thread count, 1 thread, all physical
+to 1 / 5, and the data-dependent loop, instead of k=2), `wgrad_bf16x3` (fp32-equivalent arithmetic in the weight-gradient kernel too),
+`rays4096` (BASELINE cfg 5: the per-GPU batch of the 8-GPU run), `cfg3` (synthetic_light_mask.yml networks), `cfg4_image` (one full
+640x480 eval render through i2sdf_render_image), `allreduce_us` (the flat gradient all-reduce alone), `roofline`, `cpu_baseline` (the CPU restatement on this node's host cores: best thread count, 1 thread, all physical
 cores), `eager_rocm_baseline` (the same restatement as stock PyTorch-ROCm eager ops on this GPU: the un-fused baseline of
 BASELINE.md section 3).
 """
@@ -61,6 +64,7 @@ def parse():
                     help="which scaling mode(s) to time; `value`/`scaling` of the JSON line are the weak ones unless --scaling strong")
     ap.add_argument("--sampler-iters", type=int, default=2, help="fixed sampler iterations k (0 = data dependent)")
     ap.add_argument("--windows", type=int, default=7, help="timed windows of --steps steps each (median reported)")
+    ap.add_argument("--sub-windows", type=int, default=3, help="timed windows of every sub-record (strong, dense128, k1, k5, natural_k, wgrad_bf16x3, rays4096, cfg3)")
     ap.add_argument("--profile-steps", type=int, default=10, help="steps of the per-entry-point timing pass behind the timed windows")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not start the rocprofv3 --pmc passes for roofline.traffic / kernels_hbm")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)      # the run under rocprofv3: headline steps only, no output
@@ -139,19 +143,20 @@ def bytes_per_point(cfg):
 class Workload:
     """One rank's training-step workload: `rays` rays of the synthetic camera, the synthetic.yml networks, loss, optimizer."""
 
-    def __init__(self, args, dev, rank, world):
+    def __init__(self, args, dev, rank, world, light=False):
         import torch
         from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
         from i2sdf_amd import dist as i2dist
         self.torch, self.dev, self.rank, self.world, self.args = torch, dev, rank, world, args
-        conf = synthetic_conf()
+        conf = synthetic_conf(light)               # light: synthetic_light_mask.yml (adds the light-mask head; BASELINE cfg 3)
         conf["use_normal"] = True
         torch.manual_seed(0)                                  # identical initial weights on every rank
         self.net = I2SDFNetwork(conf).to(dev)
         with torch.no_grad():
             self.net.density.beta.fill_(0.02)
         self.net.train()
-        self.loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)   # synthetic.yml:15-23
+        self.loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05,
+                                 light_mask_weight=0.5 if light else 0.0)   # synthetic.yml:15-23 / synthetic_light_mask.yml
         if args.fused_adam:
             from i2sdf_amd import FusedAdam
             self.opt = FusedAdam(self.net, lr=5.0e-4, eps=1e-15)         # model/trainer/recon.py:203 (Adam, lr 5e-4)
@@ -172,7 +177,8 @@ class Workload:
         gt = {"rgb": torch.rand(B, 3, generator=g).to(dev), "depth": (torch.rand(B, generator=g) * 3).to(dev),
               "depth_mask": torch.ones(B, dtype=torch.bool, device=dev),
               "normal": torch.nn.functional.normalize(torch.randn(B, 3, generator=g), dim=1).to(dev),
-              "normal_mask": torch.ones(B, dtype=torch.bool, device=dev)}
+              "normal_mask": torch.ones(B, dtype=torch.bool, device=dev),
+              "light_mask": (torch.rand(B, 1, generator=g) > 0.5).float().to(dev)}
         return inp, gt
 
     def fence(self):
@@ -328,13 +334,14 @@ def main():
         return
 
     # ---- headline: weak scaling, every rank draws its own `rays` rays -----------------------------------------------
+    SW = max(args.sub_windows, 1)
     weak = strong = None
     if args.scaling in ("weak", "both"):
         weak = wl.run(B, 1000 + rank, args.sampler_iters, K, W, timing=True, windows=args.windows,
                       profile_steps=args.profile_steps)      # each rank draws its own rays (ray-sharded data parallelism)
     if args.scaling in ("strong", "both"):
         Bs = args.strong_rays // world                    # fixed GLOBAL batch, split over the ranks
-        strong = wl.run(Bs, 2000 + rank, args.sampler_iters, K, W, timing=(weak is None), windows=(args.windows if weak is None else 1),
+        strong = wl.run(Bs, 2000 + rank, args.sampler_iters, K, W, timing=(weak is None), windows=(args.windows if weak is None else SW),
                         profile_steps=(args.profile_steps if weak is None else 0))
         strong["rays_per_gpu"] = Bs
     head = weak if weak is not None else strong
@@ -343,31 +350,47 @@ def main():
     ms = dt / K * 1e3
     value = head_B * n_shaded * world / (dt / K)
 
+    def sub(r, rays, shaded, workload, **more):
+        """a sub-record from a Workload.run() result: median of its windows, the windows themselves, us per ray"""
+        d = {"value": round(rays * shaded * world / (r["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(r["dt"] / K * 1e3, 4),
+             "windows_ms_per_step": [round(x / K * 1e3, 4) for x in r["dts"]], "us_per_ray": round(r["dt"] / K / rays * 1e6, 4), "workload": workload}
+        d.update(more)
+        return d
+
     extras = {}
     if not args.no_extras:
-        d128 = wl.run(B, 1000 + rank, 0, K, W, dense=128)
-        extras["dense128"] = {"value": round(B * 128 * world / (d128["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(d128["dt"] / K * 1e3, 4),
-                              "workload": f"{B} rays/GPU x 128 uniform shaded samples, sampler bypassed (BASELINE.json metric convention), same step otherwise"}
-        # opt-in arithmetic variant of ONE kernel family: the 256x256 weight-gradient blocks with two bf16 planes per operand
-        # (I2SDF_OPT_WGRAD_BF16X2, include/i2sdf.h); everything else unchanged.  Reported beside the headline, never as the headline.
-        if eng.wgrad_bf16x3 and not eng.wgrad_bf16x2:
-            eng.set_wgrad_bf16x2(True)
-            x2 = wl.run(B, 1000 + rank, args.sampler_iters, K, W)
+        d128 = wl.run(B, 1000 + rank, 0, K, W, dense=128, windows=SW)
+        extras["dense128"] = sub(d128, B, 128, f"{B} rays/GPU x 128 uniform shaded samples, sampler bypassed (BASELINE.json metric convention), same step otherwise")
+        # the fp32-equivalent form of the ONE kernel family that runs narrower by default: the 256x256 weight-gradient blocks with three
+        # bf16 planes per operand and six products instead of two and three (I2SDF_OPT_WGRAD_BF16X2 off); everything else unchanged
+        if eng.wgrad_bf16x3 and eng.wgrad_bf16x2:
             eng.set_wgrad_bf16x2(False)
-            extras["wgrad_bf16x2"] = {"value": round(B * n_shaded * world / (x2["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(x2["dt"] / K * 1e3, 4),
-                                      "workload": "the headline step with I2SDF_OPT_WGRAD_BF16X2: weight gradients of the 256x256 blocks from two bf16 terms per operand "
-                                                  "(three products, fp32 accumulate; per-product error <= 3*2^-18).  Not fp32-equivalent, but above the reference's own "
-                                                  "float32_matmul_precision('medium') (main_recon.py:61); measured: every parameter gradient stays at 3e-6 max-norm relative "
-                                                  "of the fp64 oracle on full-size batches (bar 1e-4; tests/test_gpu_network.py::test_wgrad_bf16x2_stays_inside_the_parity_bar)"}
+            x3r = wl.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW)
+            eng.set_wgrad_bf16x2(True)
+            extras["wgrad_bf16x3"] = sub(x3r, B, n_shaded, "the headline step with the weight-gradient GEMMs in bf16x3 too (I2SDF_OPT_WGRAD_BF16X2 off: three bf16 terms per "
+                                         "operand, six products): fp32-equivalent arithmetic in EVERY kernel of the step -- the round-3 headline convention")
         for kk in (1, 5):
             if kk != args.sampler_iters:
-                rk = wl.run(B, 1000 + rank, kk, K, W)
-                extras[f"k{kk}"] = {"value": round(B * n_shaded * world / (rk["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(rk["dt"] / K * 1e3, 4),
-                                    "workload": f"same as the headline with the sampler iteration count fixed to k={kk}"}
-        nat = wl.run(B, 1000 + rank, 0, K, W)
-        extras["natural_k"] = {"value": round(B * n_shaded * world / (nat["dt"] / K), 1), "unit": "ray-samples/s", "ms_per_step": round(nat["dt"] / K * 1e3, 4),
-                               "sampler_iters_observed": nat["iters"],
-                               "workload": "same as the headline with the data-dependent sampler loop (all max_total_iters iterations enqueued, device flag)"}
+                extras[f"k{kk}"] = sub(wl.run(B, 1000 + rank, kk, K, W, windows=SW), B, n_shaded,
+                                       f"same as the headline with the sampler iteration count fixed to k={kk}")
+        nat = wl.run(B, 1000 + rank, 0, K, W, windows=SW)
+        extras["natural_k"] = sub(nat, B, n_shaded, "same as the headline with the data-dependent sampler loop (all max_total_iters iterations enqueued, device flag)",
+                                  sampler_iters_observed=nat["iters"])
+        # BASELINE.json configs[4]: the per-GPU batch of the 8-GPU run (4096 rays per GPU), here on this rank's GPU
+        if B != 4096:
+            extras["rays4096"] = sub(wl.run(4096, 3000 + rank, args.sampler_iters, K, W, windows=SW), 4096, n_shaded,
+                                     "BASELINE cfg 5 per-GPU batch: 4096 rays/GPU, same nets / camera / k, training step incl. loss, backward, optimizer")
+        if world == 1 and not mock:
+            # BASELINE.json configs[2]: synthetic_light_mask.yml networks (adds the light-mask head and its loss term)
+            wl3 = Workload(args, dev, rank, world, light=True)
+            r3 = wl3.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW)
+            extras["cfg3"] = sub(r3, B, n_shaded, "BASELINE cfg 3: synthetic_light_mask.yml nets (8x256 SDF + 4x256 radiance + light-mask head), "
+                                                  f"{B} rays, k={args.sampler_iters}, training step incl. loss (light_mask_weight 0.5), backward, optimizer")
+            del wl3, r3
+            extras["cfg4_image"] = full_image(wl, dev, n_shaded)
+        extras["allreduce_us"] = allreduce_alone(wl, dev, world)
+    elif mock and world > 1:
+        extras["allreduce_us"] = allreduce_alone(wl, dev, world)      # the launch self-test exercises the record the first N-GPU run will carry
 
     result = None
     live = live_traffic(args) if (rank == 0 and world == 1) else None
@@ -438,7 +461,9 @@ def main():
             "windows_ms_per_step": [round(x / K * 1e3, 4) for x in head["dts"]], "ms_per_step_min": round(min(head["dts"]) / K * 1e3, 4),
             "timing": f"median of {len(head['dts'])} windows of exactly {K} steps each (barrier + synchronize around every window, max over ranks)",
             "vs_baseline": None,
-            "dtype": "f32" if not any_x3 else "f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate)",
+            "dtype": "f32" if not any_x3 else ("f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate"
+                                                + ("; weight-gradient GEMMs: 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
+                                                   if eng.wgrad_bf16x2 else ")")),
             "data": "synthetic" if not mock else "mock (launch-logic self-test on the CPU stand-in core: value / ms_per_step carry NO throughput claim)",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
                        "rays_per_gpu": head_B, "shaded_samples_per_ray": n_shaded, "sampler_iters": iters, "sampler_samples_per_iter": cfg.sampler.N_samples_eval,
@@ -481,7 +506,9 @@ def main():
         if weak is not None and strong is not None:
             Bs = strong["rays_per_gpu"]
             result["strong"] = {"value": round(Bs * world * n_shaded / (strong["dt"] / K), 1), "unit": "ray-samples/s", "scaling": "strong",
-                                "ms_per_step": round(strong["dt"] / K * 1e3, 4), "global_rays": Bs * world, "rays_per_gpu": Bs, "n_gpus": world}
+                                "ms_per_step": round(strong["dt"] / K * 1e3, 4), "windows_ms_per_step": [round(x / K * 1e3, 4) for x in strong["dts"]],
+                                "us_per_ray": round(strong["dt"] / K / Bs * 1e6, 4), "global_rays": Bs * world, "rays_per_gpu": Bs, "n_gpus": world}
+            result["us_per_ray"] = round(dt / K / head_B * 1e6, 4)
         result.update(extras)
         if not args.no_extras and world == 1:
             result["eager_rocm_baseline"] = eager_rocm_baseline(dev, iters, n_shaded)
@@ -491,6 +518,65 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def full_image(wl, dev, n_shaded, H=480, W_=640, chunk=12000, reps=3):
+    """BASELINE.json configs[3] on one GPU: one full 640x480 eval render, all chunks of split_n_pixels = 12000 rays in ONE library call
+    (i2sdf_render_image; model/eval/recon.py:161-182, utils/__init__.py:35-84), eval mode, the sampler's data-dependent loop per chunk."""
+    import torch
+    net = wl.net
+    was_training = net.training
+    net.eval()
+    k_saved, net.force_iters = net.force_iters, 0
+    ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W_), indexing="ij")
+    uv = torch.stack([xs, ys], -1).float().reshape(1, -1, 2).to(dev)
+    K4 = torch.eye(4); K4[0, 0] = K4[1, 1] = 600.0; K4[0, 2] = W_ / 2; K4[1, 2] = H / 2
+    pose = torch.eye(4); pose[:3, 3] = torch.tensor([0.0, 0.0, -2.0])
+    inp = {"uv": uv, "intrinsics": K4.unsqueeze(0).to(dev), "pose": pose.unsqueeze(0).to(dev)}
+    ts = []
+    with torch.no_grad():
+        out = net.render_image(inp, split_n_pixels=chunk)
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = net.render_image(inp, split_n_pixels=chunk)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    its = net.last_sampler_iters.tolist()
+    net.force_iters = k_saved
+    net.train(was_training)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": round(H * W_ * n_shaded / med, 1), "unit": "ray-samples/s", "s_per_image": round(med, 4), "images_s": [round(x, 4) for x in ts],
+            "rays_per_s": round(H * W_ / med, 1), "chunks": (H * W_ + chunk - 1) // chunk, "sampler_iters_per_chunk": [int(i) for i in its],
+            "finite": bool(torch.isfinite(out["rgb_values"]).all() and torch.isfinite(out["normal_map"]).all()),
+            "workload": f"BASELINE cfg 4 on one GPU: {W_}x{H} eval render ({H * W_} rays in {(H * W_ + chunk - 1) // chunk} chunks of {chunk}), "
+                        f"error-bounded up-sampling with the data-dependent loop per chunk, {n_shaded} shaded samples per ray, one i2sdf_render_image call"}
+
+
+def allreduce_alone(wl, dev, world, reps=20):
+    """The one collective of a training step, timed alone: the mean of the flat gradient buffer over the ranks (3.2 MB), through whatever
+    transport attach_data_parallel chose (library RCCL communicator: i2sdf_allreduce_grads; else torch.distributed).  At N = 1 there is
+    no collective: the record says so instead of reporting a number."""
+    import torch
+    net = wl.net
+    flat = getattr(net, "_flat", None)
+    n = int(flat.numel()) if flat is not None else 0
+    if world == 1 or net.grad_sync is None or flat is None:
+        return {"value": None, "unit": "us", "bytes": n * 4, "note": "one rank: no collective in the step (the hook is installed by attach_data_parallel for N > 1)"}
+    buf = torch.zeros_like(flat)
+    for _ in range(3):
+        net.grad_sync(buf)
+    wl.fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        net.grad_sync(buf)
+    wl.fence()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    t = torch.tensor([us], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    st = getattr(net, "dp_state", None)
+    return {"value": round(float(t.item()), 2), "unit": "us", "bytes": n * 4, "reps": reps,
+            "transport": "library RCCL communicator (i2sdf_allreduce_grads)" if getattr(st, "comm", None) is not None else "torch.distributed.all_reduce",
+            "note": f"mean of {reps} back-to-back all-reduces of the flat fp32 gradient buffer, max over ranks; in a step it runs once, behind the weight-norm backward"}
 
 
 ENTRY_KERNELS = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),

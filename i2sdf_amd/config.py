@@ -70,6 +70,12 @@ class NetConfig:
     # partial products accumulated in fp32 -- fp32-level accuracy (same parity bar) on the 16x faster bf16 matrix pipe.
     # `bf16x3: false` in the model conf selects the plain fp32-MFMA kernels everywhere.
     bf16x3: bool = True
+    # The weight-gradient GEMMs (256x256 blocks) with TWO bf16 terms per operand and three products instead of three and six
+    # (include/i2sdf.h: I2SDF_OPT_WGRAD_BF16X2).  Weight gradients are terminal sums over ~1e5 points -- their rounding errors average out
+    # and propagate nowhere; measured 3e-6 of the fp64 oracle on every parameter gradient (bar 1e-4), above the reference's own
+    # float32_matmul_precision('medium') (main_recon.py:61).  Forward and backward ACTIVATIONS always keep the fp32-equivalent bf16x3
+    # form.  `wgrad_bf16x2: false` in the model conf (or I2SDF_WGRAD_BF16X2=0) selects the fp32-equivalent form here too.
+    wgrad_bf16x2: bool = True
 
     @staticmethod
     def from_conf(conf) -> "NetConfig":
@@ -140,7 +146,7 @@ class NetConfig:
                          beta_init=float(_get(_get(dens, "params_init"), "beta")), beta_min=float(_get(dens, "beta_min", 1e-4)),
                          sdf_bias=float(_get(inet, "bias", 1.0)), use_normal=bool(_get(conf, "use_normal", False)),
                          detach_light_feature=bool(_get(conf, "detach_light_feature", True)),
-                         bf16x3=bool(_get(conf, "bf16x3", True)))
+                         bf16x3=bool(_get(conf, "bf16x3", True)), wgrad_bf16x2=bool(_get(conf, "wgrad_bf16x2", True)))
 
 
 def synthetic_conf(light: bool = False) -> dict:

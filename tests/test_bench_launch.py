@@ -28,6 +28,9 @@ def _check(stdout, n):
     assert f"dp{n}" in d["config"]["parallelism"]
     if n > 1:
         assert "torch.distributed all_reduce" in d["config"]["parallelism"] and d["config"]["backend"] == "gloo"
+        ar = d["allreduce_us"]                      # the collective of a step timed alone: the record the first N-GPU run will carry
+        assert ar["unit"] == "us" and ar["value"] > 0 and ar["bytes"] > 3_000_000 and "torch.distributed" in ar["transport"]
+    assert len(d["strong"]["windows_ms_per_step"]) >= 1 and d["strong"]["us_per_ray"] > 0 and d["us_per_ray"] > 0
     return d
 
 
@@ -36,6 +39,16 @@ def test_self_spawned_two_ranks_print_one_line():
                         "--warmup", "1", "--windows", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check(r.stdout.decode(), 2)
+
+
+def test_self_spawned_eight_ranks_print_one_line():
+    """the real world size of the driver's scaling run: rendezvous, port logic and the rank-0 line with 8 ranks on 127.0.0.1"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-launch", "--gpus", "8", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--windows", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = _check(r.stdout.decode(), 8)
+    assert d["strong"]["rays_per_gpu"] == 1024
 
 
 def test_driver_form_torchrun_two_ranks():
