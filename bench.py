@@ -421,12 +421,18 @@ def main():
         x3 = {"i2sdf_sample_rays": eng.sdf_forward_bf16x3, "i2sdf_sdf_forward_grad": eng.train_forward_bf16x3,
               "i2sdf_sdf_backward": eng.sdf_backward_bf16x3, "i2sdf_weight_grads": eng.wgrad_bf16x3,
               "i2sdf_rgb_forward": eng.rgb_bf16x3, "i2sdf_rgb_backward": eng.rgb_bf16x3}
+        # the roof of an entry point: six bf16 MFMAs per fp32 product block (bf16x3), fp32-input MFMA otherwise; the weight-gradient GEMMs
+        # with two bf16 terms per operand issue THREE MFMAs per product block: their roof is twice as high, and their fraction is priced against it
+        def peak_of(n):
+            if n == "i2sdf_weight_grads" and eng.wgrad_bf16x3 and eng.wgrad_bf16x2:
+                return PEAK_BF16 / 3
+            return PEAK_X3 if x3.get(n) else PEAK
         roof = None
         if dom:
             # the MLP kernels are dense contractions at ~1e6 FLOP per 12-byte point -> the roof is the MFMA peak of
             # the datatype used.  achieved = algorithmic FLOPs (fp32 products, SURVEY per-point figures x points) / mean duration.
             ach = kern[dom]["tflops"]
-            peak = PEAK_X3 if x3.get(dom) else PEAK
+            peak = peak_of(dom)
             npts = {"i2sdf_rgb_forward": M_main, "i2sdf_rgb_backward": M_main}.get(dom, M_sdf)
             design_bytes = bytes_per_point(cfg).get(dom, 0) * npts
             t_launch = kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1e-9) * 1e-3
@@ -446,7 +452,7 @@ def main():
                     "frac_vs_fp32_mfma_peak": round(ach / PEAK, 4),
                     # every MFMA-bound entry point against the same kind of peak (the dominant one above is simply the longest of them)
                     "entry_points": {n: {"ms": round(kern[n]["ms_per_step"], 4), "tflops": round(kern[n]["tflops"], 2),
-                                         "frac": round(kern[n]["tflops"] / (PEAK_X3 if x3.get(n) else PEAK), 4)} for n in mfma_names},
+                                         "frac": round(kern[n]["tflops"] / peak_of(n), 4)} for n in mfma_names},
                     # what the power limit leaves of the nominal peak: a pure v_mfma_f32_32x32x16_bf16 loop on random operands holds
                     # 1.95 GHz at 95 % matrix-pipe occupancy on this chip = 1933 TFLOP/s (scripts/ubench, profiles/r3_ubench_mfma_stage.txt)
                     "power_limited_bf16_peak_measured": {"tflops": 1933.0, "frac_of_nominal": 0.773,
@@ -474,7 +480,9 @@ def main():
                        "backend": (args.backend if world > 1 else None), "world_size_observed": (dist.get_world_size() if world > 1 else 1)},
             "rays_per_s": round(head_B * world / (dt / K), 1),
             "step_tflops": round(total_flops * world / (dt / K) / 1e12, 2),
-            "frac_bf16x3_mfma_roofline_whole_step": round(total_flops / (dt / K) / 1e12 / PEAK_X3, 4) if any_x3 else None,   # per GPU
+            # time the step's FLOPs need at each entry point's own MFMA roof (bf16x3: 2500/6, bf16x2 weight gradients: 2500/3, fp32: 157.3
+            # TFLOP/s) over the measured step time, per GPU
+            "frac_bf16x3_mfma_roofline_whole_step": round(sum(launch_flops[n] / (peak_of(n) * 1e12) for n in launch_flops) / (dt / K), 4) if any_x3 else None,
             "frac_fp32_mfma_roofline_whole_step": round(total_flops / (dt / K) / 1e12 / PEAK, 4),   # per GPU (weak scaling)
             "final_loss": head["loss"],
             "roofline": roof, "kernels": {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in kern.items()},

@@ -125,29 +125,6 @@ struct WStreamT {
 #endif
     return lds + cur * STG;
   }
-  // Counted form: the DMA pieces of the stage about to be read were issued in the FIRST groups of the previous stage (issue_piece),
-  // and at most `n_after` vector-memory instructions were issued behind the last of them.  VMEM operations retire in order, so
-  // "at most n_after outstanding" already means that every piece has landed -- the loads issued since (operands of the next k-chunks)
-  // stay in flight across the barrier instead of being drained by a vmcnt(0).  n_after must be a LOWER bound of the true count
-  // (a smaller value only waits longer); it is a constant after unrolling, the switch folds to one s_waitcnt.
-  __device__ __forceinline__ const float* advance_barrier_n(int n_after) {
-#ifndef I2SDF_ABL_NOBARRIER
-#define I2SDF_VMCNT(n) case n: __builtin_amdgcn_s_waitcnt(0x0F70 | ((n) & 15) | (((n) >> 4) << 14)); break;
-    switch (n_after < 0 ? 0 : (n_after > 23 ? 23 : n_after)) {
-      I2SDF_VMCNT(0) I2SDF_VMCNT(1) I2SDF_VMCNT(2) I2SDF_VMCNT(3) I2SDF_VMCNT(4) I2SDF_VMCNT(5) I2SDF_VMCNT(6) I2SDF_VMCNT(7)
-      I2SDF_VMCNT(8) I2SDF_VMCNT(9) I2SDF_VMCNT(10) I2SDF_VMCNT(11) I2SDF_VMCNT(12) I2SDF_VMCNT(13) I2SDF_VMCNT(14) I2SDF_VMCNT(15)
-      I2SDF_VMCNT(16) I2SDF_VMCNT(17) I2SDF_VMCNT(18) I2SDF_VMCNT(19) I2SDF_VMCNT(20) I2SDF_VMCNT(21) I2SDF_VMCNT(22) I2SDF_VMCNT(23)
-      default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-    }
-#undef I2SDF_VMCNT
-    __syncthreads();
-#endif
-    return lds + cur * STG;
-  }
-  // pieces of the X3_EARLY protocol (x3.h): the wait + barrier of advance_barrier_n() on its own, and the buffer the NEXT stage is in
-  // (the one the pieces issued during the current stage are filling)
-  __device__ __forceinline__ void barrier_n(int n_after) { (void)advance_barrier_n(n_after); }
-  __device__ __forceinline__ const float* next_stage() const { return lds + (cur ^ 1) * STG; }
   __device__ __forceinline__ void advance_issue(int tid) {
     if (left > 0) { issue(lds + (cur ^ 1) * STG, tid); --left; }
     cur ^= 1;

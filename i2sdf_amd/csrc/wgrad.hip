@@ -245,24 +245,9 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
-#ifndef W3_KO
-#define W3_KO 0                          // TIMING EXPERIMENTS ONLY (wrong results): knock out 1 epilogue stores, 2 loop loads, 4 split VALU, 8 stage barrier, 16 plane writes
-#endif
-#ifndef W3_TRACE
-#define W3_TRACE 0                       // development: per-workgroup timestamps of wgrad3p into g_w3_trace (i2sdf_debug_w3_trace reads them)
-#endif
-#ifndef W3_ASM_MFMA
-#define W3_ASM_MFMA 1                    // wgrad3p: the MFMA as inline asm with the accumulator tile constrained to AGPRs, see w3_mfma
-#endif
-#ifndef W3_RING3
-#define W3_RING3 0                       // wgrad3p: three plane slots, rows split TWO stages ahead, the next stage's operands fetched from LDS
-#endif                                   // during the last phase -> no read burst behind the stage barrier (see the stage lambda).  Measured
-                                         // (round 3, same box, alternating): 660 vs 604 us per launch, 20 vs 11.5 % parked wave cycles --
-                                         // the LDS traffic of a stage (11 operand reads + 12 plane writes per wave) is squeezed into its last
-                                         // phase; off.  DESIGN.md
-#ifndef W3_INTERLEAVE
-#define W3_INTERLEAVE 1                  // wgrad3p: lanes of the two 32-lane halves load the two points of one 128-B line (see vnext)
-#endif
+// (Round 3 carried development knobs here -- wrong-result knock-outs for timing, a per-workgroup trace, a three-slot plane ring that
+// measured slower: 660 vs 604 us per launch -- and compile-time alternatives of the MFMA / point interleave forms.  Round 4 removed them
+// from the production source; git history and profiles/r3_wgrad3p_experiments.txt keep the measurements.)
 
 // ---------------------------------------------------------------------------------------------------------------
 // bf16x3 variant (x3.h) for full 256x256 blocks: one workgroup of 4 waves (2x2 tiles of 128x128) per block and chunk.
@@ -275,8 +260,8 @@ constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group 
 //   LDS: plane ring 2 x 48 KB = 96 KB.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int W3P_PL = 4 * 4 * 3 * 256;                   // floats per plane stage: 4 quarters x 4 tiles x 3 planes x 1 KB (48 KB)
-constexpr int W3P_SLOTS = W3_RING3 ? 3 : 2;
-constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 144 KB (96 KB without W3_RING3) of the CU's 160 KB
+constexpr int W3P_SLOTS = 2;
+constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 96 KB of the CU's 160 KB
 
 // BLKA / BLKB: the A / B operand of this workgroup's chunk is in the blocked layout (compile-time: a runtime select inside the
 // stage costs 5 % through a worse instruction stream).
@@ -305,14 +290,9 @@ constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 144 KB (96 KB with
 // separated from the first MFMA by the whole job prologue.  (s_waitcnt for the LDS-loaded A / B operands is the compiler's, as before.)
 #define W3_ALL_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
 __device__ __forceinline__ void w3_mfma(int k, f32x16& c, u32x4 a, u32x4 b) {
-#if W3_ASM_MFMA
   (void)c;                                         // k is a constant after unrolling
   asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" :: "n"(16 * k), "n"(16 * k + 15), "v"(a), "v"(b) : W3_ALL_AGPRS);
-#else
-  c = mfma_bf16(a, b, c);
-#endif
 }
-#if W3_ASM_MFMA
 __device__ __forceinline__ void w3_acc_zero() {
   asm volatile(".set w3i, 0\n.rept 256\n\tv_accvgpr_write_b32 a[w3i], 0\n\t.set w3i, w3i+1\n.endr" ::: W3_ALL_AGPRS);
 }
@@ -321,40 +301,19 @@ __device__ __forceinline__ float w3_acc_read(int n) {       // element n & 15 of
   asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(n));
   return x;
 }
-#endif
 __device__ __forceinline__ void w3_mfma_drain() {
-#if W3_ASM_MFMA
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#endif
 }
-#if W3_TRACE
-constexpr int W3_TRACE_MAX = 32768;
-__device__ unsigned long long g_w3_trace[W3_TRACE_MAX * 8];
-__device__ unsigned g_w3_trace_n;
-#define W3_STAMP(k) do { if (tr) tr[k] = (unsigned long long)wall_clock64(); } while (0)
-#else
-#define W3_STAMP(k) do { } while (0)
-#endif
 template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
-__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsigned long long* tr = nullptr) {
+__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   float* plb = lds;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x + L.chunk0;
-#if W3_ASM_MFMA
   f32x16 acc_unused;                       // (the tiles are in a[0:255], see w3_mfma)
   w3_acc_zero();
-#else
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-#endif
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
   for (int jb = 0; jb < t.njobs; ++jb) {
@@ -377,17 +336,13 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
     const float* ubase = blk ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * wb) * 512
                              : (opB ? job.B : job.A) + m_lo * dld + 128 * wb;
     unsigned voff[4];                           // bytes, row 8*kg + 2i; the pair's second row is `vnext` further
-#if W3_INTERLEAVE
     // the MFMA reduction index is the point, and any point <-> k-slot map will do as long as A and B use the same one: with the two
     // 32-lane halves taking the two points of a 128-B line (rows 4i + kg and 4i + 2 + kg) every load instruction moves whole lines
     // instead of half of each of twice as many
     const unsigned vnext = 2u * 4u * (unsigned)(blk ? 16 : dld);
-#else
-    const unsigned vnext = 4u * (unsigned)(blk ? 16 : dld);
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = W3_INTERLEAVE ? 4 * i + kg : 8 * kg + 2 * i;
+      const int r = 4 * i + kg;
       voff[i] = 4u * (unsigned)(blk ? r * 16 + (i32 >> 2) * 512 + 4 * (i32 & 3) : r * dld + 4 * i32);
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
@@ -404,9 +359,9 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
     auto prep = [&](int s, int i, float lo, float hi_, float& x0, float& x1) __attribute__((always_inline)) {
       if (PLAIN) { x0 = lo; x1 = hi_; return; }
-      const int p0 = s * W3_PTS + (W3_INTERLEAVE ? 4 * i + kg : 8 * kg + 2 * i);
+      const int p0 = s * W3_PTS + (4 * i + kg);
       x0 = p0 < rows ? fmaxf(lo, relu_lo) : 0.f;
-      x1 = p0 + (W3_INTERLEAVE ? 2 : 1) < rows ? fmaxf(hi_, relu_lo) : 0.f;
+      x1 = p0 + (2) < rows ? fmaxf(hi_, relu_lo) : 0.f;
     };
     // (the first argument of write_tile / plane is the slot's offset in floats: slot * W3P_PL)
     auto write_tile = [&](int so, int tt, int p) __attribute__((always_inline)) {
@@ -446,101 +401,6 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
     split_all(0);                          // stage 0 is split up front
     load_all(1);
     write_all(0);
-#if W3_RING3
-    // ---- three plane slots: stage s multiplies planes(s) (slot s % 3), splits the rows of stage s+2 into slot (s+2) % 3 and, in its
-    // last phase, fetches the operands of stage s+1 (slot (s+1) % 3) into the registers its own products have released; the one A plane
-    // that is in use to the end follows in the first units of stage s+1.  ONE barrier per stage, in unit 8: by then every wave has
-    // finished stage s-1, so planes(s+1) are complete (read from the last phase of this stage on) and nobody reads planes(s-1) any more
-    // (their slot is overwritten from unit 78 of this stage on).  The MFMAs on both sides of the barrier have their operands in registers
-    // -- with two slots the barrier sat at the head of the stage, followed by a burst of 15 LDS reads per wave, all four waves at once,
-    // before the first MFMA could issue.
-    if (nst > 1) split_all(1);
-    load_all(2);
-    if (nst > 1) write_all(W3P_PL);
-    __syncthreads();
-    u32x4 ap[4][NPL], bp[2][NPL];
-#pragma unroll
-    for (int p = 0; p < NPL; ++p) {        // the opening plane loads in the order of their first use
-      bp[0][p] = plane(0, 2 + wb, 0, p);
-#pragma unroll
-      for (int ta = 0; ta < 4; ++ta) ap[ta][p] = plane(0, wa, ta, p);
-    }
-    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
-    // MORE: stage s+2 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are refilled with the rows
-    // of stage s+3 as soon as the pair has been consumed (most of a stage ahead of their use).  Pc = s % 3: the slots are compile-time
-    // constants and the loop below is written out for three stages (no copies of in-flight rows at the back edge, see the two-slot version)
-    auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
-      constexpr bool MORE = decltype(Mc)::value;
-      constexpr int P = decltype(Pc)::value;
-      constexpr int so0 = P * W3P_PL, so1 = ((P + 1) % 3) * W3P_PL, so2 = ((P + 2) % 3) * W3P_PL;      // slot offsets of stages s, s+1, s+2
-      // the product (sa, sb) of unit group q:  NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
-      // -> A plane p is last used in group LASTQ(p)
-      auto LASTQ = [](int p) constexpr { return NPL == 3 ? (p == 0 ? 3 : (p == 1 ? 5 : 4)) : (p == 0 ? 1 : 2); };
-      float x0 = 0.f, x1 = 0.f, ra = 0.f, rb = 0.f;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int g = 0; g < NM; ++g) {
-        const int tb = g / PH, gg = g % PH, q = gg / 4, ta = g % 4;
-        const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
-        const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
-        if (g == 8 && !(W3_KO & 8)) __syncthreads();
-#if W3_ASM_MFMA
-        w3_mfma(ta + 4 * tb, acc_unused, ap[ta][sa], bp[tb & 1][sb]);
-#else
-        w3_mfma(ta + 4 * tb, acc[ta][tb], ap[ta][sa], bp[tb & 1][sb]);
-#endif
-        if (g < 4) {                       // the A plane that was in use to the end of the previous stage (first needed in unit 8)
-#pragma unroll
-          for (int p = 0; p < NPL; ++p)
-            if (LASTQ(p) + 1 == NQ) ap[ta][p] = plane(so0, wa, ta, p);
-        }
-        if (MORE && !(W3_KO & 4)) {
-          // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched a stage earlier
-          const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
-          if (st == 0) prep(s + 2, i, rlo[i][tt], rhi[i][tt], x0, x1);
-          if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
-          if (NPL == 3) {
-            if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
-            if (st == 3) pl[tt][1][i] = pk_bf16(ra, rb);
-            if (st == 4) { ra -= bf16_lo(pl[tt][1][i]); rb -= bf16_hi(pl[tt][1][i]); }
-            if (st == 5) pl[tt][2][i] = pk_bf16(ra, rb);
-          } else {
-            if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
-          }
-          // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
-          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(so2, tt - 1, st);
-          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 3, i, 0);          // the pair's last value was taken in the previous unit
-          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 3, i, 1);
-        }
-        // LDS reads, one instruction per unit.  B planes of the next phase, half a phase ahead (behind the last phase: tile 0 of the
-        // next stage) ...
-        if (gg >= PH / 2 && gg < PH / 2 + NPL)
-          bp[(tb + 1) & 1][gg - PH / 2] = tb < 3 ? plane(so0, 2 + wb, tb + 1, gg - PH / 2) : plane(so1, 2 + wb, 0, gg - PH / 2);
-        // ... and in the last phase the next stage's A planes, each four units after the last MFMA that reads the register
-        if (tb == 3) {
-#pragma unroll
-          for (int p = 0; p < NPL; ++p)
-            if (LASTQ(p) + 1 < NQ && gg == 4 * (LASTQ(p) + 1) + ta) ap[ta][p] = plane(so1, wa, ta, p);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (MORE && !(W3_KO & 16)) {
-#pragma unroll
-        for (int p = 0; p < NPL; ++p) write_tile(so2, 3, p);
-      }
-    };
-    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>; using P2 = std::integral_constant<int, 2>;
-    {
-      int s = 0;
-      for (; s + 4 < nst; s += 3) { stage(s, BT{}, P0{}); stage(s + 1, BT{}, P1{}); stage(s + 2, BT{}, P2{}); }
-      const int r = nst - s;               // 1 ... 4 stages left, s % 3 == 0; stage s+k still splits iff k < r - 2
-      if (r == 1) stage(s, BF{}, P0{});
-      else if (r == 2) { stage(s, BF{}, P0{}); stage(s + 1, BF{}, P1{}); }
-      else if (r == 3) { stage(s, BT{}, P0{}); stage(s + 1, BF{}, P1{}); stage(s + 2, BF{}, P2{}); }
-      else { stage(s, BT{}, P0{}); stage(s + 1, BT{}, P1{}); stage(s + 2, BF{}, P2{}); stage(s + 3, BF{}, P0{}); }
-    }
-#else
-    if (jb == 0) { W3_STAMP(1); if (tr) tr[5] = (unsigned long long)nst; }
     // ---- two plane slots.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
     // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use)
     // (Pc = s & 1 and the loop below is written out for two stages: with ONE stage per loop iteration the rows loaded for the next stage
@@ -550,7 +410,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
     auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
       constexpr int so0 = decltype(Pc)::value * W3P_PL, so1 = W3P_PL - so0;
-      if (!(W3_KO & 8)) __syncthreads();   // planes(s) written, everyone done with stage s-1
+      __syncthreads();   // planes(s) written, everyone done with stage s-1
       u32x4 ap[4][NPL], bp[2][NPL];
       // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
       // waits for two loads, not for fifteen
@@ -568,12 +428,8 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
         // (sa, sb): NPL 3: (0,0) (0,1) (1,0) (0,2) (2,0) (1,1);  NPL 2: (0,0) (0,1) (1,0)
         const int sa = (q == 2 || q == 5) ? 1 : (q == 4 ? NPL - 1 : 0);
         const int sb = (q == 1 || q == 5) ? 1 : (q == 3 ? NPL - 1 : 0);
-#if W3_ASM_MFMA
         w3_mfma(ta + 4 * tb, acc_unused, ap[ta][sa], bp[tb & 1][sb]);
-#else
-        w3_mfma(ta + 4 * tb, acc[ta][tb], ap[ta][sa], bp[tb & 1][sb]);
-#endif
-        if (MORE && !(W3_KO & 4)) {
+        if (MORE) {
           // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
           const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
           if (st == 0) prep(s + 1, i, rlo[i][tt], rhi[i][tt], x0, x1);
@@ -587,15 +443,15 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
             if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
           }
           // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
-          if (it >= 13 && st < NPL && !(W3_KO & 16)) write_tile(so1, tt - 1, st);
-          if (tt == 3 && st == 1 && !(W3_KO & 2)) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
-          if (tt == 3 && st == 2 && !(W3_KO & 2)) gload(s + 2, i, 1);
+          if (it >= 13 && st < NPL) write_tile(so1, tt - 1, st);
+          if (tt == 3 && st == 1) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2) gload(s + 2, i, 1);
         }
         // LDS reads of the next phase, one instruction per unit, half a phase ahead
         if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(so0, 2 + wb, tb + 1, gg - PH / 2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (MORE && !(W3_KO & 16)) {
+      if (MORE) {
 #pragma unroll
         for (int p = 0; p < NPL; ++p) write_tile(so1, 3, p);
       }
@@ -607,23 +463,16 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds, unsi
       if (s + 1 < nst) { stage(s, BT{}, P0{}); stage(s + 1, BF{}, P1{}); }
       else stage(s, BF{}, P0{});
     }
-#endif
   }
   w3_mfma_drain();
-  W3_STAMP(2);
   float* out = L.partials + chunk * L.chunk_stride;
   const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
-  if ((W3_KO & 1) && L.n >= 0) return;
 #pragma unroll
   for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ri = (r & 3) + 8 * (r >> 2) + 4 * kg;
-#if W3_ASM_MFMA
       const f32x4 v = {w3_acc_read(16 * ta + r), w3_acc_read(16 * (ta + 4) + r), w3_acc_read(16 * (ta + 8) + r), w3_acc_read(16 * (ta + 12) + r)};
-#else
-      const f32x4 v = {acc[ta][0][r], acc[ta][1][r], acc[ta][2][r], acc[ta][3][r]};
-#endif
       *reinterpret_cast<f32x4*>(out + toff + (int64_t)(4 * ri + ta) * t.ldo + 4 * i32) = v;
     }
   if (t.has_bias != 0 && !opB) {           // waves 0 / 1 hold the column sums of A half 0 / 1
@@ -644,36 +493,17 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
     const int64_t left = t.j[jb].m_count - m_lo;
     plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
   }
-#if W3_TRACE
-  unsigned long long trbuf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long* tr = threadIdx.x == 0 ? trbuf : nullptr;
-  W3_STAMP(0);
-#else
-  unsigned long long* tr = nullptr;
-#endif
   if (plain) {
-    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds, tr);
-    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds, tr);
-    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds, tr);
-    else wgrad3p_body<false, false, NPL, true>(L, lds, tr);
+    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
+    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
+    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
+    else wgrad3p_body<false, false, NPL, true>(L, lds);
   } else {
-    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds, tr);
-    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds, tr);
-    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds, tr);
-    else wgrad3p_body<false, false, NPL, false>(L, lds, tr);
+    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
+    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
+    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
+    else wgrad3p_body<false, false, NPL, false>(L, lds);
   }
-#if W3_TRACE
-  if (threadIdx.x == 0) {
-    __threadfence();
-    trbuf[3] = (unsigned long long)wall_clock64();
-    trbuf[4] = ((unsigned long long)blockIdx.y << 32) | (unsigned long long)(blockIdx.x + L.chunk0);
-    trbuf[6] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    trbuf[7] = ((unsigned long long)(plain ? 1 : 0) << 8) | (unsigned long long)((ba ? 1 : 0) | (bb ? 2 : 0)) | ((unsigned long long)t.njobs << 16);
-    const unsigned slot = atomicAdd(&g_w3_trace_n, 1u);
-    if (slot < (unsigned)W3_TRACE_MAX)
-      for (int k = 0; k < 8; ++k) g_w3_trace[(size_t)slot * 8 + k] = trbuf[k];
-  }
-#endif
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
@@ -973,18 +803,3 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   return i2sdf_hip_check(hipGetLastError(), "weight_grads launch");
 }
 
-#if W3_TRACE
-// development only (variant builds with -DW3_TRACE=1): copy out and reset the per-workgroup records of wgrad3p.
-// record = {t_start, t_first_job_prologue_done, t_loop_done, t_end (100 MHz ticks), task<<32 | chunk, stages of job 0, xcc<<32 | HW_ID, flags}
-extern "C" int i2sdf_debug_w3_trace(unsigned long long* dst, int max_records) {
-  unsigned n = 0;
-  if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_w3_trace_n), sizeof(n)) != hipSuccess) return -1;
-  if (n > (unsigned)W3_TRACE_MAX) n = W3_TRACE_MAX;
-  if ((int)n > max_records) n = (unsigned)max_records;
-  if (dst != nullptr && n > 0 && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_w3_trace), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
-  const unsigned zero = 0;
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_w3_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
-  return (int)n;
-}
-#endif

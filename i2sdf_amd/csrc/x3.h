@@ -27,27 +27,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // global loads of the B-operand sources are issued X3_AHEAD k-chunks before their use (ring of X3_RING register slots):
-// measured: a distance of 1 is enough (3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
+// measured: a distance of 1 is enough (2 spills, 3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
 // STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
-#ifndef X3_AHEAD
-#define X3_AHEAD 1
-#define X3_RING 2
-#endif
-#ifndef X3_PIECES_PER_GROUP
-#define X3_PIECES_PER_GROUP 2   // 2: the pieces are out after four groups, so more of a stage's operand loads are issued BEHIND them (X3_COUNTED)
-#endif
-#ifndef X3_EARLY
-#define X3_EARLY 0      // (needs X3_DMA_SPREAD) a stage's barrier taken PFP groups before the previous stage ends, see dense_x3g: measured +0.02 ms (no gain), off
-#endif
-#ifndef X3_COUNTED
-#define X3_COUNTED 1    // (needs X3_DMA_SPREAD) stage barriers wait vmcnt(n) for the DMA pieces only, not for the operand loads issued behind them
-#endif
-#ifndef X3_DMA_SPREAD
-#define X3_DMA_SPREAD 1 // the weight DMA of the following stage as one piece per MFMA group (WStream::issue_piece) instead of one burst
-#endif
-#ifndef X3_DEFER
-#define X3_DEFER 1      // 4 MFMAs per pair group instead of 6 / 4 / 2 (dense_x3g)
-#endif
+constexpr int X3_AHEAD = 1, X3_RING = 2;
 __host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -117,20 +99,15 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   // Stores of the source (saved tensors) are not issued where their values become known but right after the next stage
   // barrier: the barrier's vmcnt(0) drain (needed for the LDS DMA) would otherwise wait for stores issued moments before it.
   float sv[2][8], sx[2][8];
-  u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // X3_DEFER: the weights of the sp = 0 group, kept for the deferred W0*h2 pair
+  u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
-  int vm_after = 0;                     // X3_COUNTED: VMEM instructions issued behind the last DMA piece of the next stage (compile-time)
-  bool counting = false;
   auto flush = [&]() __attribute__((always_inline)) {
     if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
     if (pk1 >= 0) { src.done(pk1, sv[1], sx[1]); pk1 = -1; }
   };
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
-    if (u == 0 && kc + X3_AHEAD < KC16) {
-      src.ahead(kc + X3_AHEAD);
-      if (counting) vm_after += Src::nld(kc + X3_AHEAD);      // loads issued behind the last DMA piece of the stage (advance_barrier_n)
-    }
+    if (u == 0 && kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
     if (u < 8) v[u] = src.value(kc, u, vx[u]);
     else {
       if (u == 8 && Src::STORES) {
@@ -160,23 +137,13 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   auto first_pair = [](int s) { return (s * SC < NB) ? ((NB - s * SC < SC) ? (NB - s * SC) / 2 : SC / 2) : 0; };
   auto end_pair = [](int s) { return (NB + NW - s * SC < SC) ? ((NB + NW - s * SC > 0) ? (NB + NW - s * SC) / 2 : 0) : SC / 2; };
   u32x4 ring[PFP][2];                   // A operands (one pair of tiles, one split plane) read PFP groups ahead of their MFMAs
-  bool early = false;                   // the barrier of this stage was already taken inside the previous one (X3_EARLY)
-  const u32x4* nxt = nullptr;
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int p0 = first_pair(s), p1 = end_pair(s);
-    const u32x4* cur;
-    if (early) {
-      cur = nxt;                        // barrier taken, first PFP pairs already in `ring`
-    } else {
-#if X3_COUNTED
-      // the first barrier of an op follows another op's code: full drain; later ones let the loads issued behind the last piece fly on
-      cur = reinterpret_cast<const u32x4*>(ws.advance_barrier_n((s > 0 && counting) ? vm_after : 0)) + lane;
-      counting = false; vm_after = 0;
-#else
-      cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
-#endif
-    }
+    // every stage barrier drains vmcnt(0): the DMA pieces must have landed, and hipcc cannot be trusted to wait for them by itself
+    // (common.h: WStream::advance).  Counted waits that let operand loads fly across the barrier and an early barrier that hides the
+    // first LDS reads of a stage were built in round 3 and measured inside the noise; round 4 removed them (git history).
+    const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
     flush();
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
@@ -187,24 +154,11 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         acc[nt][4 * q + 0] = b.x; acc[nt][4 * q + 1] = b.y; acc[nt][4 * q + 2] = b.z; acc[nt][4 * q + 3] = b.w;
       }
     }
-    if (!early) {
 #pragma unroll
-      for (int i = 0; i < PFP; ++i)
-        if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
-    }
+    for (int i = 0; i < PFP; ++i)
+      if (p0 + i < p1) { ring[i][0] = cur[(2 * (p0 + i)) * 64]; ring[i][1] = cur[(2 * (p0 + i) + 1) * 64]; }
     __builtin_amdgcn_sched_barrier(0);
-    // X3_EARLY: the barrier of stage s+1 is taken PFP groups before stage s ends -- from there on this wave reads no more of stage s's
-    // buffer (the A operands of its last PFP groups are in `ring`), so the first reads of stage s+1 can be issued right behind the
-    // barrier and their LDS latency, like the barrier itself, is covered by the last 4 PFP MFMAs of stage s instead of standing
-    // bare at the head of stage s+1.  Needs: every DMA piece of stage s+1 issued before that point, an even group count (ring slots
-    // line up) and a next stage of the same op with at least PFP groups.
-    const int p0n = s + 1 < NS ? first_pair(s + 1) : 0, p1n = s + 1 < NS ? end_pair(s + 1) : 0;
-    const bool can_early = X3_EARLY && X3_DMA_SPREAD && s + 1 < NS && (p1 - p0) % PFP == 0 && p1n - p0n >= PFP &&
-                           (p1 - p0 - PFP) * X3_PIECES_PER_GROUP >= WStream::NPIECE;
-    early = false;
-    bool issued = false;
     int npiece = 0;
-    (void)issued; (void)npiece;
 #pragma unroll
     for (int jp = 0; jp < SC / 2; ++jp) {
       if (jp >= p0 && jp < p1) {
@@ -215,18 +169,6 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         if (jp + PFP < p1) {
           ring[(jp - p0) % PFP][0] = cur[(2 * (jp + PFP)) * 64];
           ring[(jp - p0) % PFP][1] = cur[(2 * (jp + PFP) + 1) * 64];
-        } else if (can_early) {
-          if (jp + PFP == p1) {         // first group without a refill from this stage: take the next stage's barrier now
-            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's last reads of the buffer about to be recycled have returned
-            ws.barrier_n(counting ? vm_after : 0);
-            counting = false; vm_after = 0;
-            nxt = reinterpret_cast<const u32x4*>(ws.next_stage()) + lane;
-            early = true;
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          const int i2 = jp + PFP - p1;              // pair i2 of the next stage goes into the slot this group has just emptied
-          ring[(jp - p0) % PFP][0] = nxt[(2 * (p0n + i2)) * 64];
-          ring[(jp - p0) % PFP][1] = nxt[(2 * (p0n + i2) + 1) * 64];
         }
         acc[nt] = mfma_bf16(a0, b[0], acc[nt]);
         acc[nt + 1] = mfma_bf16(a1, b[0], acc[nt + 1]);
@@ -234,7 +176,6 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
           acc[nt] = mfma_bf16(a0, b[1], acc[nt]);
           acc[nt + 1] = mfma_bf16(a1, b[1], acc[nt + 1]);
         }
-#if X3_DEFER
         // Four MFMAs in every group: the W0*h2 pair of the sp = 0 group (six products) is issued two groups later, in the sp = 2
         // group (two products of its own), with the sp = 0 weights kept in registers meanwhile.  Every group carries the same share
         // of the B preparation (one softplus or one split item, 7-11 VALU) and two LDS reads: behind two MFMAs they do not fit the
@@ -244,22 +185,11 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
           acc[nt] = mfma_bf16(d0, b[2], acc[nt]);
           acc[nt + 1] = mfma_bf16(d1, b[2], acc[nt + 1]);
         }
-#else
-        if (sp == 0) {
-          acc[nt] = mfma_bf16(a0, b[2], acc[nt]);
-          acc[nt + 1] = mfma_bf16(a1, b[2], acc[nt + 1]);
-        }
-#endif
-#if X3_DMA_SPREAD
 #pragma unroll
-        for (int q = 0; q < X3_PIECES_PER_GROUP; ++q)
-          if (npiece < WStream::NPIECE) {       // next stage's DMA: X3_PIECES_PER_GROUP pieces per group, from the first group on
+        for (int q = 0; q < 2; ++q)
+          if (npiece < WStream::NPIECE) {       // next stage's DMA: 2 pieces per group, from the first group on
             ws.issue_piece(npiece, tid); ++npiece;
-            if (npiece == WStream::NPIECE) { __builtin_amdgcn_sched_barrier(0); counting = true; vm_after = 0; }      // (no load may be moved in front of the last piece)
           }
-#else
-        if (!issued) { ws.advance_issue(tid); issued = true; }
-#endif
         {
           const int pi = w % PPK;
 #pragma unroll
@@ -269,14 +199,10 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#if X3_DMA_SPREAD
 #pragma unroll
     for (int i = 0; i < WStream::NPIECE; ++i)
-      if (i >= npiece) { ws.issue_piece(i, tid); counting = false; }      // pieces issued at the stage end: nothing is behind them
+      if (i >= npiece) ws.issue_piece(i, tid);
     ws.advance_done();
-#else
-    if (!issued) ws.advance_issue(tid);
-#endif
   }
   flush();
 #pragma unroll
@@ -305,7 +231,6 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
-  static constexpr int nld(int) { return 0; }    // vector-memory loads ahead(kc) issues for sure (a lower bound: dense_x3g, X3_COUNTED)
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) {
@@ -323,7 +248,6 @@ struct X3FwdSrc {
 template <int NREG>
 struct X3RegSrc {
   static constexpr bool STORES = false;
-  static constexpr int nld(int) { return 0; }
   const float (&r)[NREG];
   __device__ __forceinline__ void ahead(int) {}
   __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
@@ -333,7 +257,6 @@ struct X3RegSrc {
 template <int NT>
 struct X3RevSrc {
   static constexpr bool STORES = true;
-  static constexpr int nld(int) { return 2; }
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
@@ -368,7 +291,6 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
 template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
-  static constexpr int nld(int kc) { return kc < KACC ? 4 : 0; }
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2], aq[X3_RING][2];
@@ -391,7 +313,6 @@ struct X3Sweep1Src {
 template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
-  static constexpr int nld(int) { return TOP ? 6 : 4; }
   const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
@@ -415,7 +336,6 @@ struct X3Sweep2Src {
 // a point-major row in global memory (or zeros) as B operand
 struct X3RowSrc {
   static constexpr bool STORES = false;
-  static constexpr int nld(int) { return 0; }      // (loads only when `on`: a run-time condition, so none are counted)
   const float* row; int hi; bool on;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {

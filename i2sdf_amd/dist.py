@@ -15,7 +15,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -30,7 +30,7 @@ class RcclComm:
     """`i2sdf_comm` of the C ABI: created collectively by all ranks of `group`; the 128-byte unique id travels through the
     torch.distributed group (any backend).  The calling thread's current device must be this rank's GPU."""
 
-    def __init__(self, group=None, device=None, init_timeout_s: float = 180.0):
+    def __init__(self, group=None, device=None, init_timeout_s: Optional[float] = 180.0):
         self._lib = L.load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         # i2sdf_comm_init_rank binds the communicator to the calling thread's CURRENT device: pin it to the module's device, so a
@@ -54,18 +54,24 @@ class RcclComm:
         import threading
 
         def _abort():
-            print(f"[i2sdf_amd.dist] rank {self.rank}: i2sdf_comm_init_rank did not return within {init_timeout_s} s "
-                  "(a peer rank is missing or RCCL cannot reach it): aborting the process", flush=True)
+            print(f"[i2sdf_amd.dist] rank {self.rank} of {self.world} (device {self.device}): i2sdf_comm_init_rank did not return within "
+                  f"{init_timeout_s} s (a peer rank is missing or RCCL cannot reach it): aborting the process.  "
+                  "attach_data_parallel(init_timeout_s=...) / I2SDF_COMM_INIT_TIMEOUT_S change the limit, 0 or None disable the watchdog", flush=True)
             os._exit(3)
 
-        timer = threading.Timer(init_timeout_s, _abort)
-        timer.daemon = True
-        timer.start()
+        # the watchdog hard-kills the process (there is no way to cancel a collective init that a peer never joins): the limit is the
+        # caller's to choose -- large multi-node jobs may need more than the default, a notebook may prefer no watchdog at all
+        timer = None
+        if init_timeout_s is not None and init_timeout_s > 0:
+            timer = threading.Timer(init_timeout_s, _abort)
+            timer.daemon = True
+            timer.start()
         try:
             with torch.cuda.device(self.device):
                 L.check(self._lib.i2sdf_comm_init_rank(uid, self.world, self.rank, C.byref(h)), "i2sdf_comm_init_rank")
         finally:
-            timer.cancel()
+            if timer is not None:
+                timer.cancel()
         self._h = h
         self._ex = L.Exchange()
         L.check(self._lib.i2sdf_comm_as_exchange(self._h, C.byref(self._ex)), "i2sdf_comm_as_exchange")
@@ -141,13 +147,21 @@ class DataParallelState:
         self.enabled = True
 
 
-def attach_data_parallel(net, group=None, equivalent: bool = False, native=None):
+def attach_data_parallel(net, group=None, equivalent: bool = False, native=None, init_timeout_s="env"):
     """Make `net` (i2sdf_amd.I2SDFNetwork) average its flat gradient over the process group inside backward.
 
     native: use the library's own RCCL communicator for the collectives (default: when the group's backend is nccl); otherwise
     torch.distributed carries them.  Do not ALSO wrap the module in torch DistributedDataParallel / a Lightning DDP strategy:
     the gradients would be reduced twice -- this hook IS the data-parallel strategy of the module.  Under
-    gradient accumulation use `with no_sync(net):` for all but the last micro-batch, as with DDP."""
+    gradient accumulation use `with no_sync(net):` for all but the last micro-batch, as with DDP (in `equivalent` mode the micro-batches
+    under no_sync() use rank-local loss denominators and a rank-local sampler test: the accumulated step is then NOT the 1-GPU step on
+    the concatenated batch -- i2sdf_amd.I2SDFLoss warns once when that happens).
+
+    init_timeout_s: watchdog of the library communicator's collective init (a process that cannot join is killed instead of hanging
+    the job): seconds, 0 / None = no watchdog; default: I2SDF_COMM_INIT_TIMEOUT_S from the environment, else 180."""
+    if init_timeout_s == "env":
+        import os
+        init_timeout_s = float(os.environ.get("I2SDF_COMM_INIT_TIMEOUT_S", "180"))
     world = dist.get_world_size(group)
     explicit = native is True
     if native is None:
@@ -172,7 +186,7 @@ def attach_data_parallel(net, group=None, equivalent: bool = False, native=None)
         err = None
         try:
             dev = next((p.device for p in net.parameters() if p.is_cuda), None)
-            comm = RcclComm(group, device=dev)
+            comm = RcclComm(group, device=dev, init_timeout_s=init_timeout_s)
         except Exception as e:       # RCCL not loadable / init failed on this rank
             err = e
             print(f"[i2sdf_amd.dist] rank {dist.get_rank(group)}: library RCCL communicator failed: {e}", flush=True)

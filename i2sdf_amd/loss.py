@@ -81,6 +81,12 @@ class I2SDFLoss(nn.Module):
         st = getattr(self, "_dp_state", None)
         if self.exchange is not None and self.training and (st is None or st.enabled):
             cfg.exchange = C_.pointer(self.exchange)
+        elif self.exchange is not None and self.training and not getattr(self, "_warned_no_sync", False):
+            import warnings
+            warnings.warn("i2sdf_amd.I2SDFLoss: `equivalent` data parallelism under no_sync(): this micro-batch uses RANK-LOCAL loss denominators "
+                          "(no exchange while the gradient all-reduce is suspended), so the accumulated step is not the 1-GPU step on the "
+                          "concatenated batch; accumulate with plain (non-equivalent) data parallelism, or sync every micro-batch")
+            self._warned_no_sync = True
         surf = out.get("surface_sdf")
         gtc = dict(gt)
         if not ("depth" in gt and self.depth_weight > 0):

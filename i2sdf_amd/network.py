@@ -492,6 +492,12 @@ class I2SDFNetwork(nn.Module):
             pts = torch.empty(3 * N + n_pc, 3, device=dev)
             from . import lib as L_
             c = lambda t: t.to(torch.float32).contiguous()
+            # raw pointers go to the library from here: a tensor of the wrong size (e.g. draws made for another N through the public
+            # render()) would be an out-of-bounds device read, where the torch expression this replaced raised
+            for name, t_, numel in (("cam_loc", cam, 3 * N), ("ray dirs", dirs, 3 * N), ("z_samples_eik", z_eik, N), ("draws['eik_pts']", eik, 3 * N),
+                                    ("draws['nbr_off']", off, 3 * N)):
+                if t_.numel() != numel or t_.device != dev:
+                    raise ValueError(f"{name}: {tuple(t_.shape)} on {t_.device}, expected {numel} elements on {dev} (N = {N} rays)")
             with torch.cuda.device(dev):
                 L_.check(L_.load().i2sdf_extra_points(L_.ptr(c(cam)), L_.ptr(c(dirs)), L_.ptr(c(z_eik)), L_.ptr(c(eik)), L_.ptr(c(off)), N,
                                                      L_.ptr(pts), L_.stream_ptr()), "i2sdf_extra_points")

@@ -1,5 +1,5 @@
 """Knock-out / A-B timing with the weights held fixed: bench.py's training step WITHOUT the optimizer update, so a library variant that
-computes wrong weight gradients (scripts/ab/variant_build.sh with -DW3_KO=..., timing experiments only) still sees the same points,
+computes wrong weight gradients (a timing-only knock-out build, scripts/ab/variant_build.sh) still sees the same points,
 the same sampler decisions and the same operand values in every step.  Prints the step time and the per-entry-point times.
     I2SDF_LIB_PATH=.../libi2sdf_NAME.so I2SDF_PARTS=2 python scripts/ab/fixed_weights_time.py [steps]"""
 import argparse, os, sys

@@ -131,7 +131,7 @@ def test_eval_render_given_depths_full_size(light):
     for k in keys:
         assert_close(out[k].cpu(), ref[k], 1e-4, k)
     hit = ref["weight_sum"].reshape(-1) > 1e-2
-    assert_close(out["normal_map"].cpu()[hit], ref["normal_map"][hit], 1e-3, "normal_map (rays with weight_sum > 0.01)")
+    assert_close(out["normal_map"].cpu()[hit], ref["normal_map"][hit], 1e-4, "normal_map (rays with weight_sum > 0.01)")      # measured 1.3e-5
 
 
 def _g9_setup(z, light):
@@ -428,7 +428,7 @@ def test_train_step_given_depths_full_size(light):
     for k in ("rgb_values", "depth_values", "weight_sum", "grad_theta") + (("light_mask",) if light else ()):
         assert_close(out[k].detach().cpu(), ref_out[k], 1e-4, k)
     hit = ref_out["weight_sum"].reshape(-1) > 1e-2
-    assert_close(out["normal_values"].detach().cpu()[hit], ref_out["normal_values"][hit], 1e-3, "normal_values (weight_sum > 0.01)")
+    assert_close(out["normal_values"].detach().cpu()[hit], ref_out["normal_values"][hit], 1e-4, "normal_values (weight_sum > 0.01)")      # measured 7e-6
     assert_close(losses["loss"].detach().cpu(), ref_loss["loss"], 1e-5, "loss")
     worst = 0.0
     for n_, p in net.named_parameters():
@@ -491,7 +491,7 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
 
 @pytest.mark.parametrize("B", [40, 400])
 def test_wgrad_bf16x2_stays_inside_the_parity_bar(B):
-    """I2SDF_OPT_WGRAD_BF16X2 (opt-in): the 256x256 weight-gradient blocks with two bf16 planes per operand and three products.
+    """I2SDF_OPT_WGRAD_BF16X2 (the default since round 4): the 256x256 weight-gradient blocks with two bf16 planes per operand and three products.
     Every parameter gradient of a full-width training step against the fp64 oracle: must stay within the 1e-4 bar, and the error
     is printed next to the bf16x3 (fp32-equivalent) form's.  B = 40 is the hard case (few points to average rounding over)."""
     from i2sdf_amd import synthetic_conf, I2SDFLoss
