@@ -25,6 +25,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace i2sdf {
 
+// 16-byte accesses to the SAVED per-point tensors (written once by one kernel, read once by a later one, hundreds of MB in between):
+// I2SDF_NT = 1 marks them non-temporal, so that they do not displace the packed weight streams (4-5 MB, re-read by every workgroup)
+// from the 4 MB L2 of an XCD.
+#ifndef I2SDF_NT
+#define I2SDF_NT 1      // measured (round 4, A/B in one run): step -0.03 ms, radiance forward / backward -3 / -6 %, sweeps unchanged
+#endif
+__device__ __forceinline__ f32x4 ldg4(const float* p) {
+#if I2SDF_NT
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+  return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+__device__ __forceinline__ void stg4(float* p, f32x4 v) {
+#if I2SDF_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+  *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+
 constexpr int SC = 32;                    // chunks per LDS stage
 constexpr int CHUNK_FLOATS = 256;         // 64 lanes x 4 floats
 constexpr int STAGE_FLOATS = SC * CHUNK_FLOATS;   // 32 KB
@@ -455,7 +476,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ row, int hi, bool
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 v = {t[nt][4 * q], t[nt][4 * q + 1], t[nt][4 * q + 2], t[nt][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(row + 32 * nt + 8 * q + 4 * hi) = v;
+      stg4(row + 32 * nt + 8 * q + 4 * hi, v);
     }
 }
 // `kcs` = floats between consecutive 16-wide k-chunks of the row: 16 in the point-major layout, 512 in the blocked layout of the
@@ -466,14 +487,14 @@ __device__ __forceinline__ void store_regs(float* __restrict__ row, int hi, bool
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     f32x4 v = {r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]};
-    *reinterpret_cast<f32x4*>(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi) = v;
+    stg4(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi, v);
   }
 }
 template <int NC>
 __device__ __forceinline__ void load_regs(const float* __restrict__ row, int hi, float (&r)[NC * 4], int kcs = 16) {
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi);
+    f32x4 v = ldg4(row + (c >> 1) * kcs + (c & 1) * 8 + 4 * hi);
     r[4 * c] = v.x; r[4 * c + 1] = v.y; r[4 * c + 2] = v.z; r[4 * c + 3] = v.w;
   }
 }

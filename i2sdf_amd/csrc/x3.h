@@ -239,8 +239,8 @@ struct X3FwdSrc {
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (kc < KACC && hrow != nullptr && valid) {
-      *reinterpret_cast<f32x4*>(hrow + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(hrow + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+      stg4(hrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
+      stg4(hrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
     }
   }
 };
@@ -260,16 +260,16 @@ struct X3RevSrc {
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    hq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(hrow + kcs * kc + 4 * hi);
-    hq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(hrow + kcs * kc + 8 + 4 * hi);
+    hq[kc % X3_RING][0] = ldg4(hrow + kcs * kc + 4 * hi);
+    hq[kc % X3_RING][1] = ldg4(hrow + kcs * kc + 8 + 4 * hi);
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (abrow != nullptr && valid) {
-      *reinterpret_cast<f32x4*>(abrow + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-      *reinterpret_cast<f32x4*>(abrow + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+      stg4(abrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
+      stg4(abrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
     }
   }
 };
@@ -279,12 +279,12 @@ struct X3RevSrc {
 // two f32x4 of a row covering this lane's 8 reduction indices of k-chunk kc; kcs = floats between consecutive k-chunks of the
 // row (16: point-major [M][256]; 512: blocked [M/32][16][32][16], mlp_common.h save_row_off)
 __device__ __forceinline__ void x3_load8(const float* row, int kc, int hi, f32x4 (&q)[2], int kcs = 16) {
-  q[0] = *reinterpret_cast<const f32x4*>(row + kcs * kc + 4 * hi);
-  q[1] = *reinterpret_cast<const f32x4*>(row + kcs * kc + 8 + 4 * hi);
+  q[0] = ldg4(row + kcs * kc + 4 * hi);
+  q[1] = ldg4(row + kcs * kc + 8 + 4 * hi);
 }
 __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const float (&v)[8], int kcs = 16) {
-  *reinterpret_cast<f32x4*>(row + kcs * kc + 4 * hi) = f32x4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(row + kcs * kc + 8 + 4 * hi) = f32x4{v[4], v[5], v[6], v[7]};
+  stg4(row + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
+  stg4(row + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
 }
 // sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
 //                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]

@@ -36,6 +36,7 @@
 namespace i2sdf {
 
 constexpr int HP = 16;                    // points per wave
+constexpr int XH_AHEAD = 1, XH_RING = XH_AHEAD + 1;      // k-chunks between the global loads of a source and the B preparation that consumes them (2 measured no gain)
 constexpr int SCH = SC;                    // chunks per LDS stage (80 KB stages = 5 per 256x256 op instead of 13 measured no gain: the loss is not per barrier)
 constexpr int LDS_BYTES_H = LDS_BYTES;
 template <int NW> using WStreamH = WStreamT<NW * 64, SCH>;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
   float ra[4], rb[4], t1[2], t2[2];
   auto prep = [&](int kc, int j, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC32) return;
-    if (j == 0 && kc + 1 < KC32) src.ahead(kc + 1);
+    if (j == 0 && kc + XH_AHEAD < KC32) src.ahead(kc + XH_AHEAD);
     if (j < 24) {
       // slot s = 0..9 holds [p3(s-2)] [p2(s-1)] [p1(s)]; the 24 valid pieces in that order
       int s_ = 0, ph = 0, n = 0;
@@ -115,7 +116,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
       else if (ph == 1) t2[u & 1] = src.p2(kc, u, t1[u & 1]);
       else t1[u & 1] = src.p1(kc, u);
     } else {
-      if (j == 24 && Src::STORES) src.done(kc, v, vx);
+      if (j == 24 && Src::STORES) src.done(kc, v, vx);      // (issuing them behind the next stage barrier instead -- the 32-point kernels' stash -- measured no gain here)
       const int i = (j - 24) >> 1;
       if (((j - 24) & 1) == 0) {
         const unsigned p0 = pk_bf16(v[2 * i], v[2 * i + 1]);
@@ -128,7 +129,9 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
       }
     }
   };
-  src.ahead(0);
+#pragma unroll
+  for (int k0 = 0; k0 < XH_AHEAD; ++k0)
+    if (k0 < KC32) src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < NU; ++u) prep(0, u, bq[0]);
   auto first_pair = [](int s) { return (s * SCH < NB) ? ((NB - s * SCH < SCH) ? (NB - s * SCH) / 2 : SCH / 2) : 0; };
@@ -236,12 +239,12 @@ __device__ __forceinline__ void rowvec_h(WStreamH<NW>& ws, const float (&in)[NTK
 // two f32x4 of a saved row: this lane's 8 reduction indices of k-chunk c (kcs = floats between consecutive 16-float groups of the
 // row: 16 point-major, 512 blocked)
 __device__ __forceinline__ void x3h_load8(const float* row, int c, int kg, f32x4 (&q)[2], int kcs) {
-  q[0] = *reinterpret_cast<const f32x4*>(row + kcs * (2 * c) + 4 * kg);
-  q[1] = *reinterpret_cast<const f32x4*>(row + kcs * (2 * c + 1) + 4 * kg);
+  q[0] = ldg4(row + kcs * (2 * c) + 4 * kg);
+  q[1] = ldg4(row + kcs * (2 * c + 1) + 4 * kg);
 }
 __device__ __forceinline__ void x3h_store8(float* row, int c, int kg, const float (&v)[8], int kcs) {
-  *reinterpret_cast<f32x4*>(row + kcs * (2 * c) + 4 * kg) = f32x4{v[0], v[1], v[2], v[3]};
-  *reinterpret_cast<f32x4*>(row + kcs * (2 * c + 1) + 4 * kg) = f32x4{v[4], v[5], v[6], v[7]};
+  stg4(row + kcs * (2 * c) + 4 * kg, f32x4{v[0], v[1], v[2], v[3]});
+  stg4(row + kcs * (2 * c + 1) + 4 * kg, f32x4{v[4], v[5], v[6], v[7]});
 }
 
 // B-operand sources (the twins of x3.h's) ---------------------------------------------------------------------------------
@@ -296,11 +299,11 @@ template <int NPV>
 struct XhPeRowSrc {
   static constexpr bool STORES = false;
   const float (&pe)[NPV * 8]; const float* row; int kg;
-  f32x4 q[2][2];
-  __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3h_load8(row, kc - NPV, kg, q[kc & 1], 16); }
+  f32x4 q[XH_RING][2];
+  __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3h_load8(row, kc - NPV, kg, q[kc % XH_RING], 16); }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
-  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc & 1][u >> 2][u & 3]; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc % XH_RING][u >> 2][u & 3]; }
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
 // radiance backward: G(a_l) = (previous op's accumulators) where the saved activation r is positive; stores G(a_l)
@@ -308,11 +311,11 @@ template <int NT>
 struct XhMaskSrc {
   static constexpr bool STORES = true;
   const f32x4 (&accP)[NT]; const float* rrow; float* grow; int kg; bool valid; int kcs = 16;
-  f32x4 q[2][2];
-  __device__ __forceinline__ void ahead(int kc) { x3h_load8(rrow, kc, kg, q[kc & 1], kcs); }
+  f32x4 q[XH_RING][2];
+  __device__ __forceinline__ void ahead(int kc) { x3h_load8(rrow, kc, kg, q[kc % XH_RING], kcs); }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
-  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc & 1][u >> 2][u & 3] > 0.f ? accP[2 * kc + (u >> 2)][u & 3] : 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc % XH_RING][u >> 2][u & 3] > 0.f ? accP[2 * kc + (u >> 2)][u & 3] : 0.f; }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (valid) x3h_store8(grow, kc, kg, v, kcs);
   }
@@ -323,12 +326,12 @@ template <int NTK>
 __device__ __forceinline__ void store_regs_h(float* __restrict__ row, int kg, bool valid, const float (&r)[NTK * 4], int kcs) {
   if (!valid) return;
 #pragma unroll
-  for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + nt * kcs + 4 * kg) = f32x4{r[4 * nt], r[4 * nt + 1], r[4 * nt + 2], r[4 * nt + 3]};
+  for (int nt = 0; nt < NTK; ++nt) stg4(row + nt * kcs + 4 * kg, f32x4{r[4 * nt], r[4 * nt + 1], r[4 * nt + 2], r[4 * nt + 3]});
 }
 template <int NTK>
 __device__ __forceinline__ void store_tile_h(float* __restrict__ row, int kg, bool valid, const f32x4 (&t)[NTK]) {
   if (!valid) return;
 #pragma unroll
-  for (int nt = 0; nt < NTK; ++nt) *reinterpret_cast<f32x4*>(row + 16 * nt + 4 * kg) = t[nt];
+  for (int nt = 0; nt < NTK; ++nt) stg4(row + 16 * nt + 4 * kg, t[nt]);
 }
 }  // namespace i2sdf

@@ -1,6 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 {
-timeout 900 python -m pytest tests/test_gpu_network.py -q -s --tb=line 2>&1 | grep -E "MEASURED|passed|failed"
-timeout 300 python scripts/ab/r4_time.py step 1024 c=2 2>&1 | grep -v amdgpu
-} 2>&1 | tee gpurun_out/r4_call18.log
+for rep in 1 2; do
+for v in NEW ahead2; do
+  if [ $v = NEW ]; then unset I2SDF_LIB_PATH; else export I2SDF_LIB_PATH=$PWD/i2sdf_amd/lib/ab/libi2sdf_$v.so; fi
+  echo "== $v"; timeout 300 python scripts/ab/r4_time.py step 1024 c=2 2>&1 | grep "round [12]"; timeout 300 python scripts/ab/r4_time.py entries 2>&1 | grep "round 1"
+done
+done
+} 2>&1 | tee gpurun_out/r4_call21.log
