@@ -399,7 +399,7 @@ void i2sdf_tail_join(const i2sdf_plan* p, hipStream_t st, hipStream_t side) {
 
 // ---- point ranges (plan.h: PartRun) ---------------------------------------------------------------------------------
 namespace {
-constexpr int64_t PART_ALIGN = 1024;          // == i2sdf_wgrad_chunk_points(): a weight-gradient chunk never straddles two ranges
+constexpr int64_t PART_ALIGN = I2SDF_WG_CH;          // == i2sdf_wgrad_chunk_points(): a weight-gradient chunk never straddles two ranges
 
 bool parts_resources(const i2sdf_plan* p) {
   for (int q = 0; q < I2SDF_MAX_PARTS; ++q)

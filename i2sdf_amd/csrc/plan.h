@@ -111,6 +111,10 @@ bool i2sdf_parts_begin(const i2sdf_plan* p, hipStream_t st, int64_t M, PartRun* 
 void i2sdf_parts_end(const i2sdf_plan* p, hipStream_t st, PartRun* pr);
 void i2sdf_parts_join_all(const i2sdf_plan* p, hipStream_t st);        // `st` waits for every side stream (also inside a chain)
 void i2sdf_parts_fence(const i2sdf_plan* p, hipStream_t st);           // every side stream waits for what is enqueued on `st`
+// points per split-M chunk of the weight-gradient GEMMs == alignment of the point ranges (a chunk never straddles two ranges)
+#ifndef I2SDF_WG_CH
+#define I2SDF_WG_CH 2048      // (round 4: 2048 instead of 1024 halves the per-chunk partial sums -- wn_backward reads 220 instead of 440 MB -- step -0.04 ms)
+#endif
 inline bool i2sdf_parts_on(const i2sdf_plan* p) { return p->parts >= 2; }
 // An entry point that does NOT cut its batch into ranges (its kernel family is not on the ranged path, e.g. rgb_bf16x3 off while the SDF
 // flags are on) called inside a chain: the side streams still hold un-joined work of the previous entry point, and the next one will run

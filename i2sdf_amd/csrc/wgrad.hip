@@ -12,7 +12,7 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 
 namespace {
 
-constexpr int WG_CH = 1024;          // points per split-M chunk (plan.cpp: PART_ALIGN -- point ranges are cut at chunk boundaries)
+constexpr int WG_CH = I2SDF_WG_CH;   // points per split-M chunk (plan.h; plan.cpp: PART_ALIGN -- point ranges are cut at chunk boundaries)
 constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
 

@@ -41,7 +41,7 @@ def test_version_and_error_strings(lib):
     assert h.i2sdf_version() == 100
     assert h.i2sdf_strerror(0) == b"ok"
     assert b"invalid" in h.i2sdf_strerror(-1)
-    assert h.i2sdf_wgrad_chunk_points() == 1024
+    assert h.i2sdf_wgrad_chunk_points() == 2048
     assert h.i2sdf_sampler_workspace_floats(10) > 10 * 640 * 6
 
 
