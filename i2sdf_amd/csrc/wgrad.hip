@@ -137,6 +137,174 @@ __device__ __forceinline__ void wgrad_accumulate(const WgTask& t, int64_t lo, in
   }
 }
 
+// ---- accumulator tiles as hidden AGPR state (used by wgrad_accumulate_x below and by wgrad3p, where the comment block explains why) ----
+#define W3_ALL_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
+__device__ __forceinline__ void w3_mfma(int k, f32x16& c, u32x4 a, u32x4 b) {
+  (void)c;                                         // k is a constant after unrolling
+  asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" :: "n"(16 * k), "n"(16 * k + 15), "v"(a), "v"(b) : W3_ALL_AGPRS);
+}
+__device__ __forceinline__ void w3_acc_zero() {
+  asm volatile(".set w3i, 0\n.rept 256\n\tv_accvgpr_write_b32 a[w3i], 0\n\t.set w3i, w3i+1\n.endr" ::: W3_ALL_AGPRS);
+}
+__device__ __forceinline__ float w3_acc_read(int n) {       // element n & 15 of tile n >> 4
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(n));
+  return x;
+}
+__device__ __forceinline__ void w3_mfma_drain() {
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+// the same MFMA behind a VALU producer of its operands: the two wait states the hazard recognizer would insert between a VALU write
+// and an MFMA read of the same register are part of the statement (the compiler does not know that the asm is an MFMA)
+__device__ __forceinline__ void w3_mfma_valu(int k, u32x4 a, u32x4 b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" :: "n"(16 * k), "n"(16 * k + 15), "v"(a), "v"(b) : W3_ALL_AGPRS);
+}
+
+// The same accumulation in bf16 split arithmetic (NPL = 2 or 3 planes per operand: three or six products per block, x3.h): the point
+// is the reduction index of v_mfma_f32_32x32x16_bf16, 16 points per MFMA where the fp32 form takes 2.  Lane (i32, hi) holds the points
+// 2q + hi (q = 0..7) of a 16-point stage -- the two halves of a wave read the two points of a 128-B line, as in wgrad3p -- in BOTH
+// operands, so the product does not depend on the point <-> k-slot map; column masks, optional ReLU and the bias sums (fp32 VALU adds
+// over the raw values) are those of wgrad_accumulate, and so is the accumulator layout (wgrad_store is shared).  Addressing: a per-lane
+// byte offset per k-slot computed once per job (an out-of-range value for a masked column: the buffer load returns 0) plus ONE scalar
+// offset per stage; no selects or branches in the stage loop; the rows of a ragged last stage are zeroed after the load.
+template <int AM, int BM, int NPL>
+__device__ __forceinline__ void wgrad_accumulate_x(const WgTask& t, int64_t lo, int64_t hi_cap, int lane,
+                                                   f32x16 (&acc)[AM ? 1 : 4][BM ? BM : 4], float (&bsum)[AM ? 1 : 4]) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NBV = BM ? BM : 1;
+  const int i32 = lane & 31, hi = lane >> 5;
+  // The accumulator tiles live in a[16 k : 16 k + 15], k = ta + 4 tb, as state the compiler does not see (w3_mfma_valu / w3_acc_zero /
+  // w3_acc_read): left to the register allocator they were shuttled between AGPRs and VGPRs ~1200 times per kernel and spilled
+  // (the kernel ran 25 % SLOWER than its fp32 twin).  A tile is srcC again TA*TB >= 4 MFMAs after it was written.
+  w3_acc_zero();
+#pragma unroll
+  for (int a = 0; a < TA; ++a) bsum[a] = 0.f;
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const WgJob job = t.j[jb];
+    const int64_t m_lo = lo;
+    const int64_t m_hi = (hi_cap < job.m_count) ? hi_cap : job.m_count;
+    if (m_hi <= m_lo) continue;
+    const int rows = (int)(m_hi - m_lo);
+    const int nst = (rows + 15) / 16;
+    const unsigned OOB = 0x7fffffffu;
+    const bool ablk = !AM && m_lo < job.a_blk, bblk = !BM && m_lo < job.b_blk;
+    // descriptors over "everything behind the first row of this wave's range" (the column offset a_c0 / b_c0 of a 128-column tile is
+    // folded into the per-lane offset for the blocked layout, where columns are not contiguous)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A - (AM ? 0 : job.a_c0) + m_lo * job.lda), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.B - (BM ? 0 : job.b_c0) + m_lo * job.ldb), 0, 0x7ffffff0, 0x00020000);
+    // per-lane byte offsets of the 8 k-slots (point 2q + hi of a stage), stage 0
+    unsigned aoff[8], boff[8][NBV];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned c = (unsigned)(2 * q + hi);
+      if (AM) aoff[q] = (i32 < job.a_w) ? (c * (unsigned)job.lda + (unsigned)i32) * 4u : OOB;
+      else {
+        const unsigned col = (unsigned)(job.a_c0 + 4 * i32);
+        aoff[q] = (4 * i32 < job.a_w) ? (ablk ? ((col >> 4) * 512u + (col & 15u) + c * 16u) * 4u : (c * (unsigned)job.lda + col) * 4u) : OOB;
+      }
+      if (BM) {
+#pragma unroll
+        for (int tb = 0; tb < NBV; ++tb) boff[q][tb] = (i32 + 32 * tb < job.b_w) ? (c * (unsigned)job.ldb + (unsigned)(i32 + 32 * tb)) * 4u : OOB;
+      } else {
+        const unsigned col = (unsigned)(job.b_c0 + 4 * i32);
+        boff[q][0] = (4 * i32 < job.b_w) ? (bblk ? ((col >> 4) * 512u + (col & 15u) + c * 16u) * 4u : (c * (unsigned)job.ldb + col) * 4u) : OOB;
+      }
+    }
+    // scalar byte offset of stage s: 16 points further -- blocked: 32-point blocks of 8192 floats, 16 floats per point inside
+    auto stage_off = [&](int s, bool blk, int ld) -> unsigned {
+      return blk ? (unsigned)(((s >> 1) * 8192 + (s & 1) * 256) * 4) : (unsigned)(s * 16 * ld * 4);
+    };
+    const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;
+    const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;
+    float A0[8][TA], B0[8][TB], A1[8][TA], B1[8][TB];           // raw values of two stages: [k-slot q][tile]
+    auto load_stage = [&](float (&A)[8][TA], float (&Bv)[8][TB], int s) __attribute__((always_inline)) {
+      const unsigned sa = stage_off(s, ablk, job.lda), sb = stage_off(s, bblk, job.ldb);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (AM) A[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aoff[q], sa, 0));
+        else {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], sa, 0));
+#pragma unroll
+          for (int ta = 0; ta < TA; ++ta) A[q][ta] = x[ta];
+        }
+        if (BM) {
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, boff[q][tb < NBV ? tb : 0], sb, 0));
+        } else {
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, boff[q][0], sb, 0));
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = x[tb];
+        }
+      }
+    };
+    auto split = [&](const float (&X)[8], u32x4 (&pl)[NPL]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (NPL == 2) { unsigned p0, p1; split2_pair(X[2 * i], X[2 * i + 1], p0, p1); pl[0][i] = p0; pl[1][i] = p1; }
+        else { unsigned p0, p1, p2; split3_pair(X[2 * i], X[2 * i + 1], p0, p1, p2); pl[0][i] = p0; pl[1][i] = p1; pl[NPL - 1][i] = p2; }
+      }
+    };
+    // nv = valid points of the stage (16, or fewer in the ragged last stage: those rows exist in the padded tensors but are not data)
+    auto compute_stage = [&](float (&A)[8][TA], float (&Bv)[8][TB], int nv) __attribute__((always_inline)) {
+      if (nv < 16) {                            // (wave-uniform: the ragged last stage of a job; selects, not per-lane branches)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const bool ok = 2 * q + hi < nv;
+#pragma unroll
+          for (int ta = 0; ta < TA; ++ta) A[q][ta] = ok ? A[q][ta] : 0.f;
+#pragma unroll
+          for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = ok ? Bv[q][tb] : 0.f;
+        }
+      }
+      u32x4 pa[TA][NPL], pb[TB][NPL];
+#pragma unroll
+      for (int ta = 0; ta < TA; ++ta) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { x[q] = A[q][ta]; bsum[ta] = fmaf(x[q], bias_w, bsum[ta]); }
+        split(x, pa[ta]);
+      }
+#pragma unroll
+      for (int tb = 0; tb < TB; ++tb) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = fmaxf(Bv[q][tb], relu_lo);
+        split(x, pb[tb]);
+      }
+      // products of combined order < NPL: a0b0, a0b1, a1b0 (+ a1b1, a0b2, a2b0 with three planes); consecutive MFMAs on different tiles
+#pragma unroll
+      for (int pa_i = 0; pa_i < NPL; ++pa_i)
+#pragma unroll
+        for (int pb_i = 0; pb_i < NPL; ++pb_i) {
+          if (pa_i + pb_i >= NPL) continue;
+#pragma unroll
+          for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) w3_mfma_valu(ta + 4 * tb, pa[ta][pa_i], pb[tb][pb_i]);
+        }
+    };
+    // the look-ahead loads never leave the job's rows (these descriptors do no range checking for us): beyond the last stage they
+    // re-read it, and those values are not used
+    load_stage(A0, B0, 0);
+    for (int s = 0; s < nst; s += 2) {
+      load_stage(A1, B1, s + 1 < nst ? s + 1 : nst - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute_stage(A0, B0, rows - 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
+      load_stage(A0, B0, s + 2 < nst ? s + 2 : nst - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < nst) compute_stage(A1, B1, rows - 16 * (s + 1));
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  w3_mfma_drain();
+#pragma unroll
+  for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+    for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ta][tb][r] = w3_acc_read(16 * (ta + 4 * tb) + r);
+}
+
 // one wave writes its tile (and, for the first column tile of a block, the column sums of A = the bias gradient) to the chunk's partials
 template <int AM, int BM>
 __device__ __forceinline__ void wgrad_store(const WgTask& t, float* __restrict__ out, int lane,
@@ -192,13 +360,15 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
 constexpr int PFN = 8;               // 128 point pairs per wave = 8 groups of 16
 constexpr int WGN_LDS_BYTES = 3 * (8 * 16 + 4) * 64 * 4;
 
-template <int AM, int BM>
+// NPL = 0: fp32-input MFMA (wgrad_accumulate); 2 / 3: bf16 split arithmetic with that many planes per operand (wgrad_accumulate_x)
+template <int AM, int BM, int NPL>
 __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTask& t, int64_t chunk, int wave, int lane, float* lds) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NW = TA * TB * 16 + TA;
   f32x16 acc[TA][TB];
   float bsum[TA];
   const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
-  wgrad_accumulate<AM, BM, PFN>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
+  if (NPL == 0) wgrad_accumulate<AM, BM, PFN>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
+  else wgrad_accumulate_x<AM, BM, NPL == 0 ? 2 : NPL>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
   if (wave > 0) {
     float* dst = lds + (wave - 1) * NW * 64 + lane;
 #pragma unroll
@@ -233,15 +403,16 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTas
   }
 }
 
+template <int NPL>
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float wgn_lds[];
   // wave index as a scalar: the buffer descriptors built from it must be wave-uniform (else every load becomes a waterfall loop)
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x + L.chunk0;
-  if (t.variant == 1) wgrad_narrow_body<1, 0>(L, t, chunk, wave, lane, wgn_lds);
-  else if (t.variant == 2) wgrad_narrow_body<0, 1>(L, t, chunk, wave, lane, wgn_lds);
-  else wgrad_narrow_body<0, 2>(L, t, chunk, wave, lane, wgn_lds);
+  if (t.variant == 1) wgrad_narrow_body<1, 0, NPL>(L, t, chunk, wave, lane, wgn_lds);
+  else if (t.variant == 2) wgrad_narrow_body<0, 1, NPL>(L, t, chunk, wave, lane, wgn_lds);
+  else wgrad_narrow_body<0, 2, NPL>(L, t, chunk, wave, lane, wgn_lds);
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
@@ -288,22 +459,6 @@ constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 96 KB of the CU's 
 // What the hazard recognizer does not see and this code provides: (1) a tile is the srcC of an MFMA again four MFMAs (128 cycles) after it
 // was written -- more than the 8 passes of the instruction; (2) the epilogue's reads come behind w3_mfma_drain(); (3) the zero fill is
 // separated from the first MFMA by the whole job prologue.  (s_waitcnt for the LDS-loaded A / B operands is the compiler's, as before.)
-#define W3_ALL_AGPRS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127","a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159","a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191","a192","a193","a194","a195","a196","a197","a198","a199","a200","a201","a202","a203","a204","a205","a206","a207","a208","a209","a210","a211","a212","a213","a214","a215","a216","a217","a218","a219","a220","a221","a222","a223","a224","a225","a226","a227","a228","a229","a230","a231","a232","a233","a234","a235","a236","a237","a238","a239","a240","a241","a242","a243","a244","a245","a246","a247","a248","a249","a250","a251","a252","a253","a254","a255"
-__device__ __forceinline__ void w3_mfma(int k, f32x16& c, u32x4 a, u32x4 b) {
-  (void)c;                                         // k is a constant after unrolling
-  asm volatile("v_mfma_f32_32x32x16_bf16 a[%0:%1], %2, %3, a[%0:%1]" :: "n"(16 * k), "n"(16 * k + 15), "v"(a), "v"(b) : W3_ALL_AGPRS);
-}
-__device__ __forceinline__ void w3_acc_zero() {
-  asm volatile(".set w3i, 0\n.rept 256\n\tv_accvgpr_write_b32 a[w3i], 0\n\t.set w3i, w3i+1\n.endr" ::: W3_ALL_AGPRS);
-}
-__device__ __forceinline__ float w3_acc_read(int n) {       // element n & 15 of tile n >> 4
-  float x;
-  asm volatile("v_accvgpr_read_b32 %0, a[%1]" : "=v"(x) : "n"(n));
-  return x;
-}
-__device__ __forceinline__ void w3_mfma_drain() {
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-}
 template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
 __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
   float* plb = lds;
@@ -758,8 +913,17 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       } else if (var == 0) {
         wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       } else {
-        (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
-        wgrad_narrow_kernel<<<grid, 256, WGN_LDS_BYTES, st>>>(L);
+        // the narrow blocks in the arithmetic of the 256x256 ones: bf16 split with two / three planes, else fp32-input MFMA
+        if (p->wgrad_bf16x3 && p->wgrad_bf16x2) {
+          (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
+          wgrad_narrow_kernel<2><<<grid, 256, WGN_LDS_BYTES, st>>>(L);
+        } else if (p->wgrad_bf16x3) {
+          (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
+          wgrad_narrow_kernel<3><<<grid, 256, WGN_LDS_BYTES, st>>>(L);
+        } else {
+          (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
+          wgrad_narrow_kernel<0><<<grid, 256, WGN_LDS_BYTES, st>>>(L);
+        }
       }
     }
   };
