@@ -93,3 +93,48 @@ def test_wgrad3p_stage_loops_do_not_copy_rows_in_flight(isa):
             assert not any(re.search(r"v_accvgpr", x) for x in v), (name, k)
             low = [x.strip() for x in v if re.search(r"s_waitcnt vmcnt\([0-3]\)", x)]
             assert not low, (name, k, low)               # eight row loads per stage in flight: the waits are vmcnt(5) ... vmcnt(7)
+
+
+def test_wgrad_narrow_bf16_accumulator_window(isa):
+    """wgrad_narrow_kernel<2|3> (bf16 split form of the narrow blocks, round 4) keeps its accumulator tiles in a[...] as hidden state too,
+    but only DURING the accumulation: zero fill -> inline-asm MFMAs -> read-out, after which the cross-wave reduction is ordinary code in
+    which the compiler may use AGPRs again.  Inside that window -- per instantiated body -- there must be no compiler-owned AGPR reference
+    (it would overwrite a tile: the clobber lists only say that the asm destroys the registers, not that they carry state between the
+    statements), and every MFMA must be one of the asm statements."""
+    lines, _ = isa
+    ks, cur = {}, None
+    for ln in lines:
+        m = re.match(r"^(_Z\w*wgrad_narrow_kernelILi[23]E\w*):", ln)
+        if m:
+            cur = m.group(1); ks[cur] = []
+        elif cur is not None:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                ks[cur].append(ln)
+    assert len(ks) == 2, list(ks)
+    for name, body in ks.items():
+        in_asm, events = False, []                      # (kind, text): Z zero fill, M asm MFMA, R asm read-out, C compiler AGPR reference
+        for ln in body:
+            if "#ASMSTART" in ln:
+                in_asm = True; continue
+            if "#ASMEND" in ln:
+                in_asm = False; continue
+            code = ln.split(";")[0].strip()
+            if not code or code.startswith("."):
+                continue
+            if in_asm:
+                if code.startswith("v_mfma"):
+                    events.append(("M", code))
+                elif code.startswith("v_accvgpr_read"):
+                    events.append(("R", code))
+                elif code.startswith("v_accvgpr_write") or code.startswith(".rept"):
+                    events.append(("Z", code))
+            else:
+                assert "v_mfma" not in code, f"{name}: an MFMA outside the inline asm: {code}"
+                if re.search(r"[ ,]a(\[\d+|\d+)", " " + code):
+                    events.append(("C", code))
+        kinds = "".join(k for k, _ in events)
+        runs = re.sub(r"(.)\1+", r"\1", kinds)          # e.g. ZMRCZMRCZMRC: three operand-shape variants of the body
+        assert re.fullmatch(r"(ZMRC?)+", runs), f"{name}: unexpected order of zero fill / MFMAs / read-out / compiler AGPR uses: {runs}"
+        assert kinds.count("M") >= 3 * 12, (name, kinds.count("M"))
