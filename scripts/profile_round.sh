@@ -1,7 +1,7 @@
 #!/bin/bash
 # Refresh profiles/: rocprofv3 kernel stats of the default bench command + PMC passes (counters only, separate runs).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r3}
+R=${1:-r4}
 BARGS="--no-cpu-baseline --no-extras --scaling weak --windows 1 --profile-steps 0 --no-live-traffic"     # the headline workload only (same kernels and launch shapes as the timed windows of the default command)
 O=gpurun_out/profiles_$R
 mkdir -p $O
