@@ -39,6 +39,9 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 #endif
 }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) {
+#ifdef I2SDF_ABL_NOSTORE      // timing-only knock-out (wrong results): what do the saved-tensor stores cost a kernel?
+  (void)p; (void)v; return;
+#endif
 #if I2SDF_NT
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
@@ -114,7 +117,9 @@ struct WStreamT {
 #ifndef I2SDF_ABL_NOBARRIER
     // (a) my DMA pieces of this stage have landed: hipcc usually drains vmcnt in front of the barrier by itself, but it
     // tracks LDS DMA per address and was seen to leave the wait out (wgrad.hip) -- the protocol must not depend on that
+#ifndef I2SDF_ABL_NOVMWAIT      // timing-only knock-out (stale weights): what does draining the wave's own stores at every stage cost?
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+#endif
     __syncthreads();
 #endif
     // 
@@ -141,7 +146,9 @@ struct WStreamT {
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
   __device__ __forceinline__ const float* advance_barrier() {
 #ifndef I2SDF_ABL_NOBARRIER
+#ifndef I2SDF_ABL_NOVMWAIT
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), see advance()
+#endif
     __syncthreads();
 #endif
     return lds + cur * STG;

@@ -593,7 +593,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
             if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
             if (st == 3) pl[tt][1][i] = pk_bf16(ra, rb);
             if (st == 4) { ra -= bf16_lo(pl[tt][1][i]); rb -= bf16_hi(pl[tt][1][i]); }
-            if (st == 5) pl[tt][2][i] = pk_bf16(ra, rb);
+            if (st == 5) pl[tt][NPL - 1][i] = pk_bf16(ra, rb);
           } else {
             if (st == 2) pl[tt][1][i] = pk_bf16(x0 - bf16_lo(pl[tt][0][i]), x1 - bf16_hi(pl[tt][0][i]));
           }
@@ -913,11 +913,11 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       } else if (var == 0) {
         wgrad_kernel<0, 0><<<grid, 64, 0, st>>>(L);
       } else {
-        // the narrow blocks in the arithmetic of the 256x256 ones: bf16 split with two / three planes, else fp32-input MFMA
-        if (p->wgrad_bf16x3 && p->wgrad_bf16x2) {
-          (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
-          wgrad_narrow_kernel<2><<<grid, 256, WGN_LDS_BYTES, st>>>(L);
-        } else if (p->wgrad_bf16x3) {
+        // the narrow blocks (PE columns of layer 0 / the skip layer, the output rows): bf16 split with THREE planes whenever the 256x256
+        // blocks run in split arithmetic, else fp32-input MFMA.  Also under I2SDF_OPT_WGRAD_BF16X2: the kernel is bound by its operand
+        // reads (4.0-4.7 TB/s, matrix pipe 8-16 % busy), so the third plane costs little and these few blocks keep fp32-equivalent
+        // gradients (measured: 107 us per launch with two planes, 127 us with three: +0.03 ms per step).
+        if (p->wgrad_bf16x3) {
           (void)hipFuncSetAttribute((const void*)wgrad_narrow_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WGN_LDS_BYTES);
           wgrad_narrow_kernel<3><<<grid, 256, WGN_LDS_BYTES, st>>>(L);
         } else {
@@ -942,7 +942,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       if (pr.hi[q] <= pr.lo[q]) continue;
       c_lo = (int)(pr.lo[q] / WG_CH); c_hi = (int)((pr.hi[q] + WG_CH - 1) / WG_CH);
       st = pr.st[q];
-      launch(sel_narrow, 1);
+      launch(sel_narrow, 1);               // (the narrow blocks behind the 256x256 ones instead: +0.02 ms, measured)
       launch(sel_blocks[0], 4);
       launch(sel_blocks[1], 0);
     }

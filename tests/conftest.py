@@ -11,6 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "wgrad_independent: a test of a dual-mode module that computes no parameter gradient (or sets both "
+                                       "weight-gradient modes itself): it runs once")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -37,6 +39,8 @@ WGRAD_MODE_MODULES = {"test_gpu_backward", "test_gpu_baseline_sizes", "test_gpu_
 
 
 def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("wgrad_independent"):
+        return
     if metafunc.module.__name__.split(".")[-1] in WGRAD_MODE_MODULES and "wgrad_mode" in metafunc.fixturenames:
         metafunc.parametrize("wgrad_mode", ["wgrad-bf16x2", "wgrad-bf16x3"], indirect=True)
 

@@ -233,3 +233,15 @@ def explain_by_relu_flips(err, deltas, scale, max_flips=4):
         res[n] = float(e[off:off + k].abs().max())
         off += k
     return chosen, res
+
+
+_MEMO = {}
+
+
+def memo(key, fn):
+    """Results of the ORACLE that do not depend on the weight-gradient mode under test (tests/conftest.py runs the gradient modules once
+    per mode): computed by the first parametrisation, reused by the second.  Only oracle-side values go in here -- never anything the
+    library produced."""
+    if key not in _MEMO:
+        _MEMO[key] = fn()
+    return _MEMO[key]

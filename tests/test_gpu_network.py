@@ -38,6 +38,7 @@ def _eval_rays(tvec, B=1024, W=32, H=32, f=30.0):
     return {"uv": uv, "intrinsics": K.unsqueeze(0), "pose": pose.unsqueeze(0)}
 
 
+@pytest.mark.wgrad_independent
 def test_state_dict_keys_and_order_match_reference(golden):
     from i2sdf_amd import I2SDFNetwork, plumbing_conf
     z = golden("g9_train_light")
@@ -59,6 +60,7 @@ def _spread(a, b, keys, hit=None):
     return out
 
 
+@pytest.mark.wgrad_independent
 @pytest.mark.parametrize("tag", ["in", "out"])
 def test_eval_forward_vs_reference_golden(golden, tag):
     """Sampler in the loop.  Individual depths are ill-conditioned where the inverse CDF is flat, so the bound used per output
@@ -89,6 +91,7 @@ def test_eval_forward_vs_reference_golden(golden, tag):
             assert_close(out[k].cpu(), z[f"{tag}.out.{k}"], tol, k)
 
 
+@pytest.mark.wgrad_independent
 @pytest.mark.parametrize("tag", ["in", "out"])
 def test_eval_render_given_reference_depths_golden(golden, tag):
     """The reference's OWN eval depths (G7 z_vals) through render(): every output of the reference's recorded render (G8) at 1e-4."""
@@ -109,6 +112,7 @@ def test_eval_render_given_reference_depths_golden(golden, tag):
     assert_close(out["normal_map"].cpu()[hit], t(z[f"{tag}.out.normal_map"])[hit], 1e-4, "normal_map (rays with weight_sum > 0.01)")
 
 
+@pytest.mark.wgrad_independent
 @pytest.mark.parametrize("light", [False, True])
 def test_eval_render_given_depths_full_size(light):
     """z override: identical samples on both sides -> 1e-4 parity of every output (incl. light mask)."""
@@ -285,7 +289,7 @@ def test_full_width_train_step_vs_reference_golden(golden, name, light):
     The strict arithmetic check of the backward kernels against fp64 is test_train_step_given_depths_full_size /
     test_gpu_backward.py (well-conditioned seeds)."""
     from i2sdf_amd import synthetic_conf, I2SDFLoss
-    from helpers import full_width_state_dict, measured_spread, network_of, relu_flip_analysis, explain_by_relu_flips
+    from helpers import full_width_state_dict, measured_spread, memo, network_of, relu_flip_analysis, explain_by_relu_flips
     z = golden(name)
     ocfg, sd = full_width_state_dict(z, light)
     ocfg.use_normal = True
@@ -322,14 +326,17 @@ def test_full_width_train_step_vs_reference_golden(golden, name, light):
                                            z_override=(t(z["ref.z_vals"]).to(dt), t(z["ref.z_eik"]).to(dt)))
         return g_
 
-    spread = measured_spread(run, sd)
+    spread = memo(("g14 spread", name), lambda: measured_spread(run, sd))      # oracle only: the same for both weight-gradient modes
     by_net = {}
     for n_, v in spread.items():
         by_net[network_of(n_)] = max(by_net.get(network_of(n_), 0.0), v)
     print("measured conditioning (max deviation among fp64 / noisy-fp32 oracle runs) per network:", by_net)
     stride = int(z["grad_stride"])
     samp = lambda g_: (g_.detach().cpu().reshape(-1) if g_.numel() <= 1024 else g_.detach().cpu().reshape(-1)[::stride])
-    _, cands, deltas = relu_flip_analysis(lambda: run(sd, torch.float32), tau=1e-6)
+    def flips_of_the_oracle():
+        r = relu_flip_analysis(lambda: run(sd, torch.float32), tau=1e-6)
+        return r, relu_flip_analysis.pre
+    (_, cands, deltas), oracle_pre = memo(("g14 flips", name), flips_of_the_oracle)
     err, scale = {}, {}
     for n_, p in net.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -356,13 +363,14 @@ def test_full_width_train_step_vs_reference_golden(golden, name, light):
     node = out["rgb_values"].grad_fn                     # the autograd node of the render core keeps the saved tensors it used
     M_main = node.M_main
     rs_pm = eng.saved_to_point_major(node.rs, eng.blocked_points(1, M_main, node.rs.shape[1]))[:, :M_main]
-    flips, worst = hip_mask_flips(rs_pm, relu_flip_analysis.pre)
+    flips, worst = hip_mask_flips(rs_pm, oracle_pre)
     print(f"ReLU backward masks that differ between the HIP path and the fp32 oracle: {sorted(flips)} (largest |pre-activation| among them {worst:.1e})")
     assert worst < 1e-6, f"a backward mask differs at a unit whose pre-activation is {worst:.2e}: not a rounding-level flip"
     for i in chosen:
         assert (cands[i][0], cands[i][1], cands[i][2]) in flips, f"flip {cands[i]} explains the gradient difference but the HIP mask of that unit equals the oracle's"
 
 
+@pytest.mark.wgrad_independent
 def test_full_width_eval_vs_reference_golden(golden):
     """G15: synthetic.yml networks, eval.  (i) the reference's depths through render(): 1e-4; (ii) sampler in the loop: the
     iteration count is exact and outputs agree within the oracle's measured fp32-vs-fp64 spread."""
@@ -478,8 +486,9 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
     d64 = orc.Draws(eik_pts=dr.eik_pts.to(D), nbr_off=dr.nbr_off.to(D))
     gt64 = {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}
-    ref_out, ref_loss, ref_g = orc.training_step_grads({k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64,
-                                                       lc, d64, step=10, z_override=(z_all.to(D), z_eik.to(D)))
+    from helpers import memo
+    ref_out, ref_loss, ref_g = memo(("x3 vs fp32 kernels: fp64 oracle", B), lambda: orc.training_step_grads(
+        {k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64, lc, d64, step=10, z_override=(z_all.to(D), z_eik.to(D))))
     for k in ("rgb_values", "depth_values", "weight_sum", "grad_theta"):
         assert_close(o3[k], o1[k], 1e-5, k + " (bf16x3 vs fp32 kernels)")
         assert_close(o3[k], ref_out[k], 1e-4, k + " (bf16x3 vs fp64)")
@@ -489,6 +498,7 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     print(f"worst relative parameter-gradient error vs fp64: bf16x3 kernels {e3:.2e}, fp32-MFMA kernels {e1:.2e}")
 
 
+@pytest.mark.wgrad_independent
 @pytest.mark.parametrize("B", [40, 400])
 def test_wgrad_bf16x2_stays_inside_the_parity_bar(B):
     """I2SDF_OPT_WGRAD_BF16X2 (the default since round 4): the 256x256 weight-gradient blocks with two bf16 planes per operand and three products.

@@ -96,7 +96,7 @@ def test_wgrad3p_stage_loops_do_not_copy_rows_in_flight(isa):
 
 
 def test_wgrad_narrow_bf16_accumulator_window(isa):
-    """wgrad_narrow_kernel<2|3> (bf16 split form of the narrow blocks, round 4) keeps its accumulator tiles in a[...] as hidden state too,
+    """wgrad_narrow_kernel<3> (bf16 split form of the narrow blocks, round 4; always three planes) keeps its accumulator tiles in a[...] as hidden state too,
     but only DURING the accumulation: zero fill -> inline-asm MFMAs -> read-out, after which the cross-wave reduction is ordinary code in
     which the compiler may use AGPRs again.  Inside that window -- per instantiated body -- there must be no compiler-owned AGPR reference
     (it would overwrite a tile: the clobber lists only say that the asm destroys the registers, not that they carry state between the
@@ -104,7 +104,7 @@ def test_wgrad_narrow_bf16_accumulator_window(isa):
     lines, _ = isa
     ks, cur = {}, None
     for ln in lines:
-        m = re.match(r"^(_Z\w*wgrad_narrow_kernelILi[23]E\w*):", ln)
+        m = re.match(r"^(_Z\w*wgrad_narrow_kernelILi3E\w*):", ln)
         if m:
             cur = m.group(1); ks[cur] = []
         elif cur is not None:
@@ -112,7 +112,7 @@ def test_wgrad_narrow_bf16_accumulator_window(isa):
                 cur = None
             else:
                 ks[cur].append(ln)
-    assert len(ks) == 2, list(ks)
+    assert len(ks) == 1, list(ks)
     for name, body in ks.items():
         in_asm, events = False, []                      # (kind, text): Z zero fill, M asm MFMA, R asm read-out, C compiler AGPR reference
         for ln in body:
