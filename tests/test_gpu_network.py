@@ -318,15 +318,17 @@ def test_full_width_train_step_vs_reference_golden(golden, name, light):
     # ---- conditioning of the gradients on this fixture, measured with the oracle
     lc = _oracle_lc(lk)
 
-    def run(sd_, dt):
-        cast = lambda v: v.to(dt) if v.dtype.is_floating_point else v
-        dr = orc.Draws(eik_pts=t(z["draw.eik_pts"]).to(dt), nbr_off=t(z["draw.nbr_off"]).to(dt))
+    def run(sd_, dt, dev="cpu"):
+        cast = lambda v: (v.to(dt) if v.dtype.is_floating_point else v).to(dev)
+        dr = orc.Draws(eik_pts=cast(t(z["draw.eik_pts"])), nbr_off=cast(t(z["draw.nbr_off"])))
         _, _, g_ = orc.training_step_grads({k_: cast(v) for k_, v in sd_.items()}, ocfg, {k_: cast(v) for k_, v in inp.items()},
                                            {k_: cast(v) for k_, v in gt.items()}, lc, dr, step=10,
-                                           z_override=(t(z["ref.z_vals"]).to(dt), t(z["ref.z_eik"]).to(dt)))
+                                           z_override=(cast(t(z["ref.z_vals"])), cast(t(z["ref.z_eik"]))))
         return g_
 
-    spread = memo(("g14 spread", name), lambda: measured_spread(run, sd))      # oracle only: the same for both weight-gradient modes
+    # oracle only: the same for both weight-gradient modes.  How far correct evaluations of the algorithm are apart does not depend on
+    # where they run: the four of them as eager ops on the GPU (the mask analysis below stays on the host, fp32 = the reference's arithmetic)
+    spread = memo(("g14 spread", name), lambda: measured_spread(lambda s_, d_: run(s_, d_, "cuda"), sd))
     by_net = {}
     for n_, v in spread.items():
         by_net[network_of(n_)] = max(by_net.get(network_of(n_), 0.0), v)
@@ -445,6 +447,17 @@ def test_train_step_given_depths_full_size(light):
     print("worst relative parameter-gradient error", worst)
 
 
+def _oracle_fp64_on_gpu(sd, ocfg, inp, gt64, lc, d64, z_all, z_eik, step=10):
+    """The fp64 restatement of a training step as stock PyTorch-ROCm eager ops on the GPU (the oracle is device-agnostic torch code; on
+    the host's cores the same call takes ~8 s at 400 rays).  Returns CPU tensors."""
+    D, g = torch.float64, (lambda v: v.cuda() if torch.is_tensor(v) else v)
+    dr = orc.Draws(eik_pts=d64.eik_pts.cuda(), nbr_off=d64.nbr_off.cuda())
+    out, losses, grads = orc.training_step_grads({k: v.to(D).cuda() for k, v in sd.items()}, ocfg, {k: v.to(D).cuda() for k, v in inp.items()},
+                                                 {k: g(v) for k, v in gt64.items()}, lc, dr, step=step, z_override=(z_all.to(D).cuda(), z_eik.to(D).cuda()))
+    c = lambda x: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in x.items()}
+    return c(out), c(losses), c(grads)
+
+
 def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     """The same training step (identical depths and draws) with every bf16x3 kernel enabled (the default) and with the plain
     fp32-MFMA kernels (`bf16x3: false`): outputs agree to 1e-5, and outputs and all parameter gradients of BOTH are within the 1e-4
@@ -487,8 +500,7 @@ def test_train_step_bf16x3_matches_fp32_kernels(B=400):
     d64 = orc.Draws(eik_pts=dr.eik_pts.to(D), nbr_off=dr.nbr_off.to(D))
     gt64 = {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}
     from helpers import memo
-    ref_out, ref_loss, ref_g = memo(("x3 vs fp32 kernels: fp64 oracle", B), lambda: orc.training_step_grads(
-        {k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64, lc, d64, step=10, z_override=(z_all.to(D), z_eik.to(D))))
+    ref_out, ref_loss, ref_g = memo(("x3 vs fp32 kernels: fp64 oracle", B), lambda: _oracle_fp64_on_gpu(sd, ocfg, inp, gt64, lc, d64, z_all, z_eik))
     for k in ("rgb_values", "depth_values", "weight_sum", "grad_theta"):
         assert_close(o3[k], o1[k], 1e-5, k + " (bf16x3 vs fp32 kernels)")
         assert_close(o3[k], ref_out[k], 1e-4, k + " (bf16x3 vs fp64)")
@@ -518,8 +530,7 @@ def test_wgrad_bf16x2_stays_inside_the_parity_bar(B):
     lc = orc.LossCfg(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
     d64 = orc.Draws(eik_pts=dr.eik_pts.to(D), nbr_off=dr.nbr_off.to(D))
     gt64 = {k: (v.to(D) if v.dtype.is_floating_point else v) for k, v in gt.items()}
-    _, _, ref_g = orc.training_step_grads({k: v.to(D) for k, v in sd.items()}, ocfg, {k: v.to(D) for k, v in inp.items()}, gt64, lc, d64,
-                                          step=10, z_override=(z_all.to(D), z_eik.to(D)))
+    _, _, ref_g = _oracle_fp64_on_gpu(sd, ocfg, inp, gt64, lc, d64, z_all, z_eik)
     worst = {}
     for x2 in (False, True):
         net = build(synthetic_conf(False), sd, train=True)

@@ -38,23 +38,27 @@ def test_training_curves_match_oracle(light):
     lc = orc.LossCfg(**lkw)
     n_row = ocfg.sampler.N_samples_eval + ocfg.sampler.N_samples
 
-    # --- oracle run ---------------------------------------------------------------------------
-    params = {k: v.clone() for k, v in sd.items()}
-    leaves = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
-    opt_o = torch.optim.Adam(list(leaves.values()), lr=LR, eps=1e-15)
-    psnr_o, loss_o = [], []
-    for step in range(STEPS):
-        inp = camera_inputs(B, (0.0, 0.0, -2.0), W=32, H=32, f=30.0, seed=100 + step)
-        gt = make_gt(B, seed=step, light=light)
-        dr = make_draws(ocfg, B, n_row=n_row, seed=1000 + step)
-        cur = {k: p.detach() for k, p in leaves.items()}
-        out, losses, grads = orc.training_step_grads(cur, ocfg, inp, gt, lc, dr, step=step)
-        psnr_o.append(float(orc.get_psnr(out["rgb_values"].detach(), gt["rgb"])))
-        loss_o.append(float(losses["loss"].detach()))
-        opt_o.zero_grad()
-        for k, p in leaves.items():
-            p.grad = grads[k].reshape(p.shape).clone()
-        opt_o.step()
+    # --- oracle run (does not depend on the weight-gradient mode of the library: computed once, tests/helpers.py: memo) -----------
+    def oracle_run():
+        leaves = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}
+        opt_o = torch.optim.Adam(list(leaves.values()), lr=LR, eps=1e-15)
+        psnr_o, loss_o = [], []
+        for step in range(STEPS):
+            inp = camera_inputs(B, (0.0, 0.0, -2.0), W=32, H=32, f=30.0, seed=100 + step)
+            gt = make_gt(B, seed=step, light=light)
+            dr = make_draws(ocfg, B, n_row=n_row, seed=1000 + step)
+            cur = {k: p.detach() for k, p in leaves.items()}
+            out, losses, grads = orc.training_step_grads(cur, ocfg, inp, gt, lc, dr, step=step)
+            psnr_o.append(float(orc.get_psnr(out["rgb_values"].detach(), gt["rgb"])))
+            loss_o.append(float(losses["loss"].detach()))
+            opt_o.zero_grad()
+            for k, p in leaves.items():
+                p.grad = grads[k].reshape(p.shape).clone()
+            opt_o.step()
+        return psnr_o, loss_o, {k: p.detach().clone() for k, p in leaves.items()}
+
+    from helpers import memo
+    psnr_o, loss_o, leaves = memo(("24-step oracle run", light), oracle_run)
 
     # --- HIP run ------------------------------------------------------------------------------
     net = build(plumbing_conf(skip=True, light=light), sd, train=True)
