@@ -468,7 +468,7 @@ def main():
             "timing": f"median of {len(head['dts'])} windows of exactly {K} steps each (barrier + synchronize around every window, max over ranks)",
             "vs_baseline": None,
             "dtype": "f32" if not any_x3 else ("f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate"
-                                                + ("; weight-gradient GEMMs: 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
+                                                + ("; the 256x256 weight-gradient GEMM blocks: 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
                                                    if eng.wgrad_bf16x2 else ")")),
             "data": "synthetic" if not mock else "mock (launch-logic self-test on the CPU stand-in core: value / ms_per_step carry NO throughput claim)",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
