@@ -1,5 +1,10 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 {
-T0=$(date +%s); timeout 600 python -m pytest tests/test_gpu_network.py tests/test_gpu_training_parity.py -q -s -k "full_width_train or training_curves" 2>&1 | grep -E "grad |conditioning|ReLU|passed|failed|Error|PSNR" | cut -c1-250; echo "wall $(( $(date +%s) - T0 )) s"
-} 2>&1 | tee gpurun_out/r4_call30.log
+run() { timeout 200 python scripts/ab/r4_time.py step 1024 c=2 2>&1 | grep "round 2"; timeout 100 python scripts/ab/r4_time.py fwd 2>&1 | tail -1; }
+for rep in 1 2 3; do
+  echo "== head"; I2SDF_LIB_PATH=$GRAFT_REPO_ROOT/i2sdf_amd/lib/ab/libi2sdf_head.so run
+  echo "== x3hcarry"; I2SDF_LIB_PATH=$GRAFT_REPO_ROOT/i2sdf_amd/lib/ab/libi2sdf_x3hcarry.so run
+  echo "== all (carry + prefetch hooks + drain)"; run
+done
+} 2>&1 | tee gpurun_out/r4_call33.log
