@@ -407,7 +407,8 @@ class RenderEngine:
         dev = z_all.device
         M = B * n
         o = {"sdf_bar": sdf_bar_out if sdf_bar_out is not None else torch.empty(M, device=dev), "rgb_bar": torch.empty(M, 3, device=dev)}
-        o["grad_bar"] = (grad_bar_out if grad_bar_out is not None else torch.empty(M, 3, device=dev)) if g_normal is not None else None
+        # (a caller-provided grad_bar is written even without g_normal -- zeros for the rays' rows -- so that it never stays uninitialised)
+        o["grad_bar"] = grad_bar_out if grad_bar_out is not None else (torch.empty(M, 3, device=dev) if g_normal is not None else None)
         o["lmask_bar"] = torch.empty(M, device=dev) if g_lmask is not None else None
         part = torch.empty(B, device=dev)
         c = lambda t: None if t is None else t.contiguous()

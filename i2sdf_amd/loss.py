@@ -42,10 +42,13 @@ class _FusedLossFn(torch.autograd.Function):
             grads[5] = None      # smoothness term inactive (:347-349): its gradient is identically zero -- let autograd skip that branch
         ctx.grads = grads
         ctx.mark_non_differentiable(losses)
+        ctx.set_materialize_grads(False)      # no zero tensor (one fill launch) for the gradient slot of the non-differentiable `losses`
         return total, losses
 
     @staticmethod
     def backward(ctx, g, _g_items):
+        if g is None:
+            return (None,) * (4 + len(ctx.grads))
         live = [gr for gr in ctx.grads if gr is not None]
         scaled = iter(torch._foreach_mul(live, g))          # one launch for all of them
         out = [None, None, None, None] + [(next(scaled) if gr is not None else None) for gr in ctx.grads]

@@ -114,6 +114,9 @@ class _RenderFn(torch.autograd.Function):
         comp = eng.composite_forward(beta_param, st["z_all"], fw["sdf"], rgb, fw["grad"], lm, st["dnorm"], want_normal=st["want_normal"])
         ctx.net, ctx.st, ctx.fw, ctx.rgb, ctx.rs, ctx.pev, ctx.lm, ctx.hl, ctx.comp = net, st, fw, rgb, rs, pev, lm, hl, comp
         ctx.M_main = M_main
+        # outputs the loss does not use (weight_sum without a mask term, ...) arrive in backward as None instead of as zero tensors that
+        # autograd would fill with one launch each; the kernels take NULL for them (include/i2sdf.h)
+        ctx.set_materialize_grads(False)
         outs = [comp["rgb"], comp["depth"], comp["wsum"]]
         outs.append(comp["normal"] if st["want_normal"] else torch.zeros(0, device=rgb.device))
         outs.append(comp["lmask"] if net.use_light else torch.zeros(0, device=rgb.device))
@@ -141,14 +144,18 @@ class _RenderFn(torch.autograd.Function):
         sbar = torch.empty(M_sdf, device=dev)
         nbar = torch.empty(M_sdf, 3, device=dev)
         from . import lib as L_
-        ge = g_eik.contiguous() if n_eik else None
-        gs = g_surf.reshape(-1).contiguous() if n_pc else None
+        if g_rgb is None:                      # a loss without a colour term: the compositing backward wants the pointer
+            g_rgb = torch.zeros_like(comp["rgb"])
+        if net.use_light and g_lmask is None:
+            g_lmask = torch.zeros_like(comp["lmask"])
+        ge = g_eik.contiguous() if (n_eik and g_eik is not None) else None
+        gs = g_surf.reshape(-1).contiguous() if (n_pc and g_surf is not None) else None
         with torch.cuda.device(dev):
             L_.check(L_.load().i2sdf_backward_seeds(L_.ptr(gflat[off_beta:]), flat.numel() - off_beta, L_.ptr(sbar), L_.ptr(nbar), M_main, M_sdf,
                                                    L_.ptr(ge) if ge is not None else None, n_eik, L_.ptr(gs) if gs is not None else None, n_pc,
                                                    0 if want_normal else 1, L_.stream_ptr()), "i2sdf_backward_seeds")
         cb = eng.composite_backward(flat[off_beta:], st["z_all"], fw["sdf"], ctx.rgb, fw["grad"], st["dnorm"], comp["nsum"],
-                                    g_rgb, g_depth, g_wsum.reshape(-1), g_normal if want_normal else None,
+                                    g_rgb, g_depth, None if g_wsum is None else g_wsum.reshape(-1), g_normal if want_normal else None,
                                     g_lmask.reshape(-1) if net.use_light else None, beta_grad_accum=gflat[off_beta:],
                                     sdf_bar_out=sbar, grad_bar_out=nbar if want_normal else None)
         light = None
