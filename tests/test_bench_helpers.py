@@ -31,10 +31,14 @@ def test_committed_profile_is_used_only_with_matching_sources():
     h = bench.source_hash()
     assert len(h) == 16 and h == bench.source_hash()
     val, src = bench.profiled_traffic("i2sdf_weight_grads")
-    stamp_file = os.path.join(ROOT, "profiles", "r3_source_hash.txt")
+    import glob
+    import re
+    rounds = sorted({int(re.match(r"r(\d+)_", os.path.basename(f)).group(1)) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_summary.csv"))})
+    newest = f"r{rounds[-1]}"                  # the newest committed round is the one bench.py looks at
+    stamp_file = os.path.join(ROOT, "profiles", f"{newest}_source_hash.txt")
     stamp = open(stamp_file).read().split()[0] if os.path.exists(stamp_file) else None
     if stamp == h:
-        assert val is not None and val > 1e9 and "profiles/r3_pmc" in src        # GB-scale traffic of the weight gradients
+        assert val is not None and val > 1e9 and f"profiles/{newest}_pmc" in src        # GB-scale traffic of the weight gradients
     else:
         assert val is None and "other kernel sources" in src                      # stale profile: refused, and it says why
 
