@@ -167,9 +167,9 @@ __device__ __forceinline__ void w3_mfma_valu(int k, u32x4 a, u32x4 b) {
 // over the raw values) are those of wgrad_accumulate, and so is the accumulator layout (wgrad_store is shared).  Addressing: a per-lane
 // byte offset per k-slot computed once per job (an out-of-range value for a masked column: the buffer load returns 0) plus ONE scalar
 // offset per stage; no selects or branches in the stage loop; the rows of a ragged last stage are zeroed after the load.
+// (core: leaves the tiles in a[16 k : 16 k + 15], k = ta + 4 tb, drained; wgrad_accumulate_x below reads them out)
 template <int AM, int BM, int NPL>
-__device__ __forceinline__ void wgrad_accumulate_x(const WgTask& t, int64_t lo, int64_t hi_cap, int lane,
-                                                   f32x16 (&acc)[AM ? 1 : 4][BM ? BM : 4], float (&bsum)[AM ? 1 : 4]) {
+__device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t lo, int64_t hi_cap, int lane, float (&bsum)[AM ? 1 : 4]) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NBV = BM ? BM : 1;
   const int i32 = lane & 31, hi = lane >> 5;
   // The accumulator tiles live in a[16 k : 16 k + 15], k = ta + 4 tb, as state the compiler does not see (w3_mfma_valu / w3_acc_zero /
@@ -297,6 +297,12 @@ __device__ __forceinline__ void wgrad_accumulate_x(const WgTask& t, int64_t lo, 
     }
   }
   w3_mfma_drain();
+}
+template <int AM, int BM, int NPL>
+__device__ __forceinline__ void wgrad_accumulate_x(const WgTask& t, int64_t lo, int64_t hi_cap, int lane,
+                                                   f32x16 (&acc)[AM ? 1 : 4][BM ? BM : 4], float (&bsum)[AM ? 1 : 4]) {
+  constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4;
+  wgrad_accumulate_x_core<AM, BM, NPL>(t, lo, hi_cap, lane, bsum);
 #pragma unroll
   for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
@@ -358,7 +364,8 @@ __global__ __launch_bounds__(64) void wgrad_kernel(WgLaunch L) {
 // workgroups took 0.62 ms per step.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int PFN = 8;               // 128 point pairs per wave = 8 groups of 16
-constexpr int WGN_LDS_BYTES = 3 * (8 * 16 + 4) * 64 * 4;
+constexpr int WGW_SLOT = (16 * 16 + 4) * 64;               // floats of one wave's partial 128x128 tile (+ 4 bias sums) in LDS
+constexpr int WGN_LDS_BYTES = 2 * WGW_SLOT * 4;            // two such slots (wgrad_wide_body) > three narrow partials (3 * (8 * 16 + 4) * 64 * 4)
 
 // NPL = 0: fp32-input MFMA (wgrad_accumulate); 2 / 3: bf16 split arithmetic with that many planes per operand (wgrad_accumulate_x)
 template <int AM, int BM, int NPL>
@@ -403,6 +410,67 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTas
   }
 }
 
+// A 128 x 128 tile of a block that is not 256 x 256 (the light-mask head's 128 x 256 layer: A = G(a_0), B = relu(feature)) in the same
+// 4-wave form and split arithmetic.  Sixteen accumulator tiles are the whole AGPR file, so they are never held in VGPRs all at once: the
+// partial tiles go through LDS tile by tile straight from a[...] -- waves 2 and 3 write theirs, wave 1 adds its own onto wave 3's, wave 0
+// sums (w0 + w2) + (w1 + w3) and stores (a fixed order: deterministic).  As single-wave fp32-input MFMA tasks (wgrad_kernel<0, 0>, 50 waves
+// on the chip for half a batch) these two tiles were the LONGEST kernel of a cfg-3 step: 650 us per launch.
+template <int NPL>
+__device__ __forceinline__ void wgrad_wide_body(const WgLaunch& L, const WgTask& t, int64_t chunk, int wave, int lane, float* lds) {
+  float bsum[4];
+  const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
+  wgrad_accumulate_x_core<0, 0, NPL>(t, lo, lo + WG_CH / 4, lane, bsum);
+  if (wave >= 2) {
+    float* d = lds + (wave - 2) * WGW_SLOT + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[(k * 16 + r) * 64] = w3_acc_read(16 * k + r);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) d[(256 + a) * 64] = bsum[a];
+  }
+  __syncthreads();
+  if (wave == 1) {
+    float* d = lds + WGW_SLOT + lane;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) d[(k * 16 + r) * 64] += w3_acc_read(16 * k + r);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) d[(256 + a) * 64] += bsum[a];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const float* s0 = lds + lane;
+    const float* s1 = lds + WGW_SLOT + lane;
+    const int i32 = lane & 31, hi = lane >> 5;
+    float* out = L.partials + chunk * L.chunk_stride;
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        f32x4 v;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          const int k = ta + 4 * tb;
+          v[tb] = (w3_acc_read(16 * (ta + 4 * tb) + r) + s0[(k * 16 + r) * 64]) + s1[(k * 16 + r) * 64];
+        }
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * hi, n = 4 * ri + ta;          // as wgrad_store<0, 0>
+        if (n < t.rows_store && 4 * i32 < t.cols_store) *reinterpret_cast<f32x4*>(out + t.out_off + (int64_t)n * t.ldo + 4 * i32) = v;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (t.has_bias) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        bsum[a] = (bsum[a] + s0[(256 + a) * 64]) + s1[(256 + a) * 64];
+        bsum[a] += __shfl_xor(bsum[a], 32);
+      }
+      if (hi == 0 && 4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = f32x4{bsum[0], bsum[1], bsum[2], bsum[3]};
+    }
+  }
+}
+
 template <int NPL>
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float wgn_lds[];
@@ -410,7 +478,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const WgTask& t = L.t[blockIdx.y];
   const int64_t chunk = blockIdx.x + L.chunk0;
-  if (t.variant == 1) wgrad_narrow_body<1, 0, NPL>(L, t, chunk, wave, lane, wgn_lds);
+  if (NPL != 0 && t.variant == 0) wgrad_wide_body<NPL == 0 ? 3 : NPL>(L, t, chunk, wave, lane, wgn_lds);      // (only the split form gets such tasks)
+  else if (t.variant == 1) wgrad_narrow_body<1, 0, NPL>(L, t, chunk, wave, lane, wgn_lds);
   else if (t.variant == 2) wgrad_narrow_body<0, 1, NPL>(L, t, chunk, wave, lane, wgn_lds);
   else wgrad_narrow_body<0, 2, NPL>(L, t, chunk, wave, lane, wgn_lds);
 }
@@ -928,11 +997,16 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     }
   };
   std::vector<WgTask> sel_narrow, sel_blocks[2];
+  // in split arithmetic the 128 x 128 tiles of blocks that are not 256 x 256 (variant 0: the light-mask head) join the 4-wave launch,
+  // in front (the longest tasks): wgrad_wide_body
+  const bool wide_in_narrow = p->wgrad_bf16x3 != 0;
+  if (wide_in_narrow)
+    for (const WgTask& x : tl.tasks) if (x.variant == 0) sel_narrow.push_back(x);
   for (int var : {3, 1, 2})      // all narrow tiles in one launch, the longest (most MFMAs per point pair, two jobs) first
     for (int nj = 2; nj >= 1; --nj)
       for (const WgTask& x : tl.tasks) if (x.variant == var && x.njobs == nj) sel_narrow.push_back(x);
   for (int v = 0; v < 2; ++v) {
-    for (const WgTask& x : tl.tasks) if (x.variant == (v == 0 ? 4 : 0)) sel_blocks[v].push_back(x);
+    for (const WgTask& x : tl.tasks) if (x.variant == (v == 0 ? 4 : 0) && !(v == 1 && wide_in_narrow)) sel_blocks[v].push_back(x);
     std::stable_sort(sel_blocks[v].begin(), sel_blocks[v].end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
   }
   PartRun pr;
