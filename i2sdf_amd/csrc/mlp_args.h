@@ -69,3 +69,12 @@ void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st);
 void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st);
+// light-mask head forward on 16-point waves (mlp_x3h.hip): lm = sigmoid(W1 softplus100(W0 relu(feature) + b0) + b1), hl = the softplus activations
+struct LightFwd3hArgs {
+  const float* fwd; int n_fwd;
+  const float* feat;                    // (Mp, F)
+  int64_t M;
+  float* lm;                            // (M)
+  float* hl;                            // (Mp, HL) point-major, or nullptr
+};
+void i2sdf_launch_light_fwd3h(const LightFwd3hArgs& a, unsigned grid, hipStream_t st);

@@ -574,6 +574,14 @@ extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, con
   a.feat = feat; a.M = M; a.Mp = Mp; a.lm = lm; a.hl = hl;
   hipStream_t st = (hipStream_t)stream;
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
+  if (p->rgb_bf16x3 && HL == 128 && F == 256 && p->light.fwd3h_chunks > 0) {      // bf16x3 split arithmetic with the radiance net's option
+    LightFwd3hArgs x{};
+    x.fwd = packed + p->scale_floats + p->light.fwd3h_chunk0 * CHUNK_FLOATS;
+    x.n_fwd = (int)(p->light.fwd3h_chunks / SCH);
+    x.feat = feat; x.M = M; x.lm = lm; x.hl = hl;
+    i2sdf_launch_light_fwd3h(x, (unsigned)((M + 8 * HP - 1) / (8 * HP)), st);
+    return i2sdf_hip_check(hipGetLastError(), "light_forward launch");
+  }
   if (HL == 128 && F == 256) launch_lds(light_fwd_kernel<128, 256>, grid, st, a);
   else if (HL == 32 && F == 64) launch_lds(light_fwd_kernel<32, 64>, grid, st, a);
   else return I2SDF_EINVAL;

@@ -166,6 +166,33 @@ __global__ __launch_bounds__(NW * 64, 2) void rgb_fwd3h_kernel(RgbFwdArgs a) {
   }
 }
 
+// light-mask head (model/network/__init__.py:29-32,162-170; fp32-MFMA twin: mlp_train.hip light_fwd_kernel): HL hidden units from F features
+template <int HL, int F, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void light_fwd3h_kernel(LightFwd3hArgs a) {
+  constexpr int NT = HL / 16, KF32 = F / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kg = lane >> 4;
+  const int64_t m = ((int64_t)blockIdx.x * NW + wave) * HP + (lane & 15);
+  const bool valid = m < a.M;
+  const int64_t mc = valid ? m : a.M - 1;
+  WStreamH<NW> ws;
+  ws.begin(a.fwd, lds, a.n_fwd, tid);
+  f32x4 acc[NT];
+  {
+    XhRowSrc<true> src{a.feat + mc * F, kg};
+    dense_x3h<NT, KF32, 1, NW>(ws, src, acc, tid);
+  }
+  float h[NT * 4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[nt * 4 + r] = softplus100(acc[nt][r]);
+  if (a.hl) store_regs_h<NT>(a.hl + m * HL, kg, valid, h, 16);
+  float o[1];
+  rowvec_h<1, NT, NW>(ws, h, o, tid);
+  if (valid && kg == 0) a.lm[m] = 1.0f / (1.0f + expf(-o[0]));
+}
+
 template <int H, int F, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void rgb_bwd3h_kernel(RgbBwdArgs a) {
   constexpr int NT = H / 16, KH32 = H / 32, FT = F / 16;
@@ -255,4 +282,5 @@ void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, 
 }
 void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8>, grid, st, a); }
 void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8>, grid, st, a); }
+void i2sdf_launch_light_fwd3h(const LightFwd3hArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(8 * 64, light_fwd3h_kernel<128, 256, 8>, grid, st, a); }
 void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_bwd3h_kernel<256, 256, 8>, grid, st, a); }

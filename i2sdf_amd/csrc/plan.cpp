@@ -283,6 +283,13 @@ int build_light(i2sdf_plan* p, Builder& b) {
   np.rev_chunk0 = b.chunk;
   emit_rowvec(b, np, 1, 1, H / 8, ColMap{HUGE_SPLIT, 0, H, 0, 0});
   np.rev_chunks = b.chunk - np.rev_chunk0;
+  // the forward on 16-point waves (mlp_x3h.hip: light_fwd3h_kernel), shapes of the shipped config only
+  np.fwd3h_chunk0 = b.chunk;
+  if (H == 128 && F == 256) {
+    emit_dense_fwd3h(b, np, 0, H / 16, F / 32, ColMap{HUGE_SPLIT, 0, F, 0, 0}, 1.0f, 0, H);
+    emit_rowvec_h(b, np, 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  }
+  np.fwd3h_chunks = b.chunk - np.fwd3h_chunk0;
   return I2SDF_OK;
 }
 

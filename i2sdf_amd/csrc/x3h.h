@@ -306,6 +306,21 @@ struct XhPeRowSrc {
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc % XH_RING][u >> 2][u & 3]; }
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
+// a point-major row in global memory as B operand, optionally through ReLU (the light-mask head's input: relu(feature))
+template <bool RELU>
+struct XhRowSrc {
+  static constexpr bool STORES = false;
+  const float* row; int kg;
+  f32x4 q[XH_RING][2];
+  __device__ __forceinline__ void ahead(int kc) { x3h_load8(row, kc, kg, q[kc % XH_RING], 16); }
+  __device__ __forceinline__ float p1(int, int) { return 0.f; }
+  __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
+  __device__ __forceinline__ float p3(int kc, int u, float, float, float&) {
+    const float x = q[kc % XH_RING][u >> 2][u & 3];
+    return RELU ? relu0(x) : x;
+  }
+  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+};
 // radiance backward: G(a_l) = (previous op's accumulators) where the saved activation r is positive; stores G(a_l)
 template <int NT>
 struct XhMaskSrc {

@@ -91,7 +91,8 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
 #define I2SDF_OPT_TRAIN_FWD_BF16X3 4
 /*   I2SDF_OPT_SDF_BWD_BF16X3: the full workgroups of i2sdf_sdf_backward (both sweeps, 256-wide nets). */
 #define I2SDF_OPT_SDF_BWD_BF16X3 8
-/*   I2SDF_OPT_RGB_BF16X3: the full workgroups of i2sdf_rgb_forward / i2sdf_rgb_backward (256-wide nets). */
+/*   I2SDF_OPT_RGB_BF16X3: the full workgroups of i2sdf_rgb_forward / i2sdf_rgb_backward (256-wide nets), and i2sdf_light_forward of the
+ *   128-unit light-mask head on 256 features. */
 #define I2SDF_OPT_RGB_BF16X3 16
 /*   I2SDF_OPT_TAIL_OVERLAP: the split-K tail workgroups of i2sdf_sdf_forward_grad and i2sdf_sdf_backward (the partial last
  *   round of a launch) and the narrow blocks of i2sdf_weight_grads run on a side stream owned by the plan,
