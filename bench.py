@@ -79,6 +79,10 @@ def parse():
                     help="N>1: who carries the gradient all-reduce -- the library's own RCCL communicator (i2sdf_allreduce_grads; auto = this when the "
                          "backend is nccl, with fallback to torch if it cannot be created on every rank) or torch.distributed.all_reduce")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: all ranks use cuda:0 (needs --backend gloo)")
+    ap.add_argument("--equivalent", action="store_true",
+                    help="N>1: 1-GPU-equivalent data parallelism (i2sdf_amd.dist.attach_data_parallel(equivalent=True) + attach_loss: the sampler's "
+                         "convergence flag is MAX-reduced per iteration, rank 0's randperm columns are broadcast, the loss denominators are "
+                         "averaged); throughput runs leave it off")
     ap.add_argument("--cpu-rays", type=int, default=512)
     ap.add_argument("--fused-adam", type=int, default=1, help="1: i2sdf_amd.FusedAdam (one HIP launch over the flat buffer); 0: torch.optim.Adam")
     ap.add_argument("--bf16x3", type=int, default=-1,
@@ -163,7 +167,10 @@ class Workload:
         else:
             self.opt = torch.optim.Adam(self.net.get_param_groups(5.0e-4), eps=1e-15)
         if world > 1:
-            i2dist.attach_data_parallel(self.net, native={"auto": None, "library": True, "torch": False}[args.dp_transport])
+            i2dist.attach_data_parallel(self.net, native={"auto": None, "library": True, "torch": False}[args.dp_transport],
+                                        equivalent=bool(getattr(args, "equivalent", False)))
+            if getattr(args, "equivalent", False):
+                i2dist.attach_loss(self.loss_fn, self.net)
         self.step_no = 0
 
     def inputs(self, B, seed):
@@ -186,10 +193,14 @@ class Workload:
             self.torch.distributed.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0):
+    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0, no_sync=False):
         """-> dict(dt = median over `windows` windows of the seconds for `steps` steps (each max over ranks), dts, loss, iters, ktimes).
-        dense > 0: `dense` uniform samples per ray, sampler bypassed (the dense-128 convention)."""
+        dense > 0: `dense` uniform samples per ray, sampler bypassed (the dense-128 convention).
+        no_sync: the same steps with the gradient all-reduce suspended (i2sdf_amd.dist.no_sync) -- what the collective costs a step."""
         torch, net = self.torch, self.net
+        import contextlib
+        from i2sdf_amd import dist as i2dist
+        sync_ctx = (lambda: i2dist.no_sync(net)) if no_sync else contextlib.nullcontext
         inp, gt = self.inputs(B, seed)
         net.force_iters = k_iters
         zs = None
@@ -200,10 +211,11 @@ class Workload:
             zs = (c, d, nrm, z, z[:, dense // 2:dense // 2 + 1].contiguous())
 
         def step():
-            out = net.render(inp, *zs) if zs else net(inp)
-            losses = self.loss_fn(out, gt, self.step_no)
-            self.opt.zero_grad(set_to_none=True)
-            losses["loss"].backward()
+            with sync_ctx():
+                out = net.render(inp, *zs) if zs else net(inp)
+                losses = self.loss_fn(out, gt, self.step_no)
+                self.opt.zero_grad(set_to_none=True)
+                losses["loss"].backward()
             self.opt.step()
             self.step_no += 1
             return losses["loss"]
@@ -267,23 +279,41 @@ class MockWorkload(Workload):
         self.net = HostStubNetwork(synthetic_conf())
         self.net._ensure_flat()
         self.opt = torch.optim.SGD(self.net.parameters(), lr=1e-3)
+        self.xchg_calls = 0
         if world > 1:
-            i2dist.attach_data_parallel(self.net)
+            i2dist.attach_data_parallel(self.net, equivalent=bool(getattr(args, "equivalent", False)))
         self.step_no = 0
         self.eng = _MockEngine()
         self.net.last_sampler_iters = torch.tensor([args.sampler_iters or 5])
         self.net._engine_for = lambda dev_: self.eng
 
     def loss_fn(self, out, gt, step):
+        st = getattr(self.net, "dp_state", None)
+        if st is not None and st.equivalent and st.enabled:
+            # `equivalent` mode without kernels: the exchanges the device-side hooks of a real step issue, in their order and count, through
+            # the same TorchExchange object and process group -- one MAX of the sampler's 4-byte convergence flag per enqueued sampler
+            # iteration (sampler.hip), then one AVG of the loss denominators (loss.hip) -- so that a rank that issued a different sequence
+            # would hang or mis-reduce HERE, on the CPU box, and not in the first N-GPU run
+            from i2sdf_amd import lib as L_
+            torch = self.torch
+            for it in range(5):                                   # max_total_iters iterations are always enqueued
+                flag = torch.tensor([1 if (self.rank + it + self.step_no) % self.world == 0 else 0], dtype=torch.int32)
+                st.xchg.reduce_(flag, L_.XCHG_MAX)
+                assert int(flag.item()) == 1, "MAX over the ranks: exactly one rank raised the flag in this iteration"
+            cnt = torch.tensor([64.0, 0.0, float(10 + self.rank), float(20 + 2 * self.rank)])
+            st.xchg.reduce_(cnt, L_.XCHG_AVG)
+            w = self.world
+            assert abs(float(cnt[2]) - (10 + (w - 1) / 2.0)) < 1e-5 and abs(float(cnt[3]) - (20 + (w - 1))) < 1e-5, cnt
+            self.xchg_calls = st.xchg.calls
         return {"loss": ((out["rgb_values"] - gt["rgb"]) ** 2).mean()}
 
     def fence(self):
         if self.world > 1:
             self.torch.distributed.barrier()
 
-    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0):
+    def run(self, B, seed, k_iters, steps, warmup, dense=0, timing=False, windows=1, profile_steps=0, no_sync=False):
         self.args_dense = dense
-        return Workload.run(self, min(B, 64), seed, k_iters, steps, warmup, dense=0, timing=timing, windows=windows, profile_steps=0)
+        return Workload.run(self, min(B, 64), seed, k_iters, steps, warmup, dense=0, timing=timing, windows=windows, profile_steps=0, no_sync=no_sync)
 
 
 def main():
@@ -391,6 +421,23 @@ def main():
         extras["allreduce_us"] = allreduce_alone(wl, dev, world)
     elif mock and world > 1:
         extras["allreduce_us"] = allreduce_alone(wl, dev, world)      # the launch self-test exercises the record the first N-GPU run will carry
+    if world > 1 and weak is not None:
+        # what the one collective of a step costs THE STEP (not the collective timed alone): the headline step once more with the gradient
+        # all-reduce suspended (i2sdf_amd.dist.no_sync); exposed = headline - that.  The ranks' weights drift apart meanwhile (every rank
+        # applies its own gradient): rank 0's parameters are broadcast again afterwards.  Last of the timed runs on purpose.
+        from i2sdf_amd import dist as i2dist
+        ns = wl.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW, no_sync=True)
+        i2dist.broadcast_parameters(wl.net)
+        extras["step_ms_without_allreduce"] = round(ns["dt"] / K * 1e3, 4)
+        extras["exposed_allreduce_ms"] = round((weak["dt"] - ns["dt"]) / K * 1e3, 4)
+        extras["exposed_allreduce_note"] = ("ms_per_step minus the same step under no_sync() (median of %d windows each, max over ranks); next to "
+                                            "allreduce_us (the collective alone) it says how much of the collective the step does not hide" % SW)
+    if world > 1 and getattr(args, "equivalent", False):
+        st_ = getattr(wl.net, "dp_state", None)
+        xc = getattr(st_, "xchg", None)
+        extras["equivalent"] = {"on": bool(st_ is not None and st_.equivalent),
+                                "exchange_calls": int(getattr(xc, "calls", 0)) if xc is not None and hasattr(xc, "calls") else None,
+                                "note": "1-GPU-equivalent mode: MAX of the sampler flag per iteration + AVG of the loss denominators per step through the exchange hook"}
 
     result = None
     live = live_traffic(args) if (rank == 0 and world == 1) else None
@@ -459,6 +506,8 @@ def main():
                                                          "frac_of_it": round(ach * 6 / 1933.0, 4) if x3.get(dom) else None},
                     "all_mfma_kernels_tflops": round(sum(launch_flops[n] * kern[n]["launches_per_step"] for n in mfma_names)
                                                      / (sum(kern[n]["ms_per_step"] for n in mfma_names) * 1e-3) / 1e12, 2)}
+        if roof is not None and live:
+            roof["dominant_kernel"] = dominant_kernel(live, cfg, fp, eng, head_B, M_main, M_sdf, max(iters, 1), PEAK, PEAK_BF16)
         total_flops = sum(launch_flops.values())
         any_x3 = any(x3.values())
         result = {
@@ -477,7 +526,8 @@ def main():
                            "" if world == 1 else (": library RCCL communicator, i2sdf_allreduce_grads" if getattr(wl.net.dp_state, "comm", None) is not None
                                                   else ": torch.distributed all_reduce")) + ")",
                        "optimizer": "i2sdf_amd.FusedAdam (1 launch)" if args.fused_adam else "torch.optim.Adam",
-                       "backend": (args.backend if world > 1 else None), "world_size_observed": (dist.get_world_size() if world > 1 else 1)},
+                       "backend": (args.backend if world > 1 else None), "world_size_observed": (dist.get_world_size() if world > 1 else 1),
+                       "equivalent": bool(world > 1 and getattr(args, "equivalent", False))},
             "rays_per_s": round(head_B * world / (dt / K), 1),
             "step_tflops": round(total_flops * world / (dt / K) / 1e12, 2),
             # time the step's FLOPs need at each entry point's own MFMA roof (bf16x3: 2500/6, bf16x2 weight gradients: 2500/3, fp32: 157.3
@@ -585,6 +635,48 @@ def allreduce_alone(wl, dev, world, reps=20):
     return {"value": round(float(t.item()), 2), "unit": "us", "bytes": n * 4, "reps": reps,
             "transport": "library RCCL communicator (i2sdf_allreduce_grads)" if getattr(st, "comm", None) is not None else "torch.distributed.all_reduce",
             "note": f"mean of {reps} back-to-back all-reduces of the flat fp32 gradient buffer, max over ranks; in a step it runs once, behind the weight-norm backward"}
+
+
+def dominant_kernel(live, cfg, fp, eng, B, M_main, M_sdf, iters, PEAK, PEAK_BF16):
+    """The single rocprofv3 kernel with the largest share of a step's kernel time (the entry-point figure above it prices a whole
+    C-ABI call, which may be several kernels): algorithmic FLOPs per step of THAT kernel (SURVEY 8d per-point figures x points)
+    / its summed duration in the PMC pass (kernels serialised there: each launch alone on the chip), against the MFMA roof of its arithmetic."""
+    sdf = cfg.sdf.dims
+    mac_fwd_hidden = sum(o * i for o, i in sdf[:-1])
+    per_step = {   # kernel-name fragment -> (algorithmic FLOPs per step, bf16 MFMAs per fp32 product block (0 = fp32-input MFMA))
+        "sdf_fwd3h_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
+        "sdf_fwd3_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
+        "sdf_fwd4_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
+        "sdf_train_fwd3h_kernel": (2 * (mac_fwd_hidden + sdf[-1][0] * sdf[-1][1]) * M_sdf, 6),
+        "sdf_igrad3_kernel": ((fp["sdf_forward_grad"] - 2 * (mac_fwd_hidden + sdf[-1][0] * sdf[-1][1])) * M_sdf, 6),
+        "sdf_bwd3_sweep1_kernel": (2 * mac_fwd_hidden * M_sdf, 6),
+        "sdf_bwd3_sweep2_kernel": ((fp["sdf_backward"] - 2 * mac_fwd_hidden) * M_sdf, 6),
+        "rgb_fwd3h_kernel": (fp["rgb_forward"] * M_main, 6),
+        "rgb_bwd3h_kernel": (fp["rgb_backward"] * M_main, 6),
+        # the 256x256 blocks: 7 SDF layers x 2 products over all points, the feature block + 4 radiance blocks over the ray samples
+        "wgrad3p_kernel": (2 * 65536 * (14 * M_sdf + 5 * M_main), 3 if eng.wgrad_bf16x2 else 6),
+    }
+    best = None
+    for k, v in live.items():
+        t = v.get("us", 0.0) * v.get("n", 0.0)
+        if t > 0 and (best is None or t > best[0]):
+            best = (t, k, v)
+    if best is None:
+        return None
+    tot_us = sum(v.get("us", 0.0) * v.get("n", 0.0) for v in live.values())
+    t, k, v = best
+    short = _short(k)
+    rec = {"kernel": short, "us_per_launch": round(v["us"], 1), "launches_per_step": round(v["n"], 2), "share_of_kernel_time": round(t / tot_us, 4),
+           "mfma_busy": round(v.get("mfma_busy", 0.0), 3) or None, "hbm_bytes_per_launch": round(v["fetch"] + v["write"]),
+           "hbm_gbs": round((v["fetch"] + v["write"]) / v["us"] / 1e3, 1) if v["us"] > 0 else None,
+           "source": "the rocprofv3 --pmc passes of this run (kernels serialised: a ranged kernel is a half-batch launch alone on the chip)"}
+    for frag, (flops, nmf) in per_step.items():
+        if frag in short:
+            ach = flops / (t * 1e-6) / 1e12
+            peak = PEAK_BF16 / nmf if nmf else PEAK
+            rec.update({"algorithmic_flops_per_step": int(flops), "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(ach / peak, 4)})
+            break
+    return rec
 
 
 ENTRY_KERNELS = {"i2sdf_weight_grads": ("wgrad", "wn_backward"), "i2sdf_sdf_backward": ("sdf_bwd",), "i2sdf_sdf_forward_grad": ("sdf_train_fwd", "sdf_igrad"),

@@ -39,9 +39,6 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) {
 #endif
 }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) {
-#ifdef I2SDF_ABL_NOSTORE      // timing-only knock-out (wrong results): what do the saved-tensor stores cost a kernel?
-  (void)p; (void)v; return;
-#endif
 #if I2SDF_NT
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
@@ -98,9 +95,6 @@ struct WStreamT {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16, tid * 16, stage_off + i * (NTHR * 16), 0, 0);
   }
   __device__ __forceinline__ void issue(float* dst, int tid) {
-#ifdef I2SDF_ABL_NODMA
-    goff += STG * 4; (void)dst; return;
-#endif
 #pragma unroll
     for (int i = 0; i < STG / (NTHR * 4); ++i) piece(dst, goff, i, tid);
     goff += STG * 4;
@@ -114,16 +108,10 @@ struct WStreamT {
   }
   // Returns the LDS buffer holding the next stage.  All 4 waves must call this in lock step.
   __device__ __forceinline__ const float* advance(int tid) {
-#ifndef I2SDF_ABL_NOBARRIER
     // (a) my DMA pieces of this stage have landed: hipcc usually drains vmcnt in front of the barrier by itself, but it
     // tracks LDS DMA per address and was seen to leave the wait out (wgrad.hip) -- the protocol must not depend on that
-#ifndef I2SDF_ABL_NOVMWAIT      // timing-only knock-out (stale weights): what does draining the wave's own stores at every stage cost?
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-#endif
-    __syncthreads();
-#endif
-    // 
-                          // (b) every wave's did, (c) every wave finished reading the other buffer
+    __syncthreads();         // (b) every wave's did, (c) every wave finished reading the other buffer
     const float* ret = lds + cur * STG;
     if (left > 0) { issue(lds + (cur ^ 1) * STG, tid); --left; }
     cur ^= 1;
@@ -145,12 +133,8 @@ struct WStreamT {
   }
   // split form: barrier now, DMA of the following stage a little later (from inside the MFMA stream)
   __device__ __forceinline__ const float* advance_barrier() {
-#ifndef I2SDF_ABL_NOBARRIER
-#ifndef I2SDF_ABL_NOVMWAIT
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), see advance()
-#endif
     __syncthreads();
-#endif
     return lds + cur * STG;
   }
   __device__ __forceinline__ void advance_issue(int tid) {

@@ -22,9 +22,11 @@ struct LossArgs {
   const float *gt_rgb, *gt_depth, *gt_normal, *gt_mask, *gt_lmask;
   const uint8_t *depth_mask, *normal_mask;
   float* partial;      // (LOSS_BLOCKS, S_N)
-  float* sums;         // (S_N)
-  float* cnt;          // (C_N)
-  int* arrived;        // workgroups of the reduction launch that have written their partial sums (0 on entry, 0 again on exit)
+  float* sums;         // (S_N)   only written / read on the data-parallel path (reduced = 1)
+  float* cnt;          // (C_N)   likewise: the denominators the exchange hook averages over the ranks
+  int nb;              // workgroups of the reduction launch = rows of `partial`
+  int reduced;         // 1: sums / cnt are in memory (loss_reduce_kernel + exchange ran); 0: every workgroup of the gradient launch adds the
+                       //    block partials up itself, in block order -- no counter, no state in the scratch, nothing to initialise
   float* losses;       // (10): loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask
   float* loss_value;   // (1) | NULL: the total once more, as a tensor of its own
   float *g_rgb, *g_depth, *g_wsum, *g_normal, *g_grad_theta, *g_diff_norm, *g_surface, *g_lmask;
@@ -77,40 +79,44 @@ __global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
   }
   __syncthreads();
   if (threadIdx.x < S_N) a.partial[blockIdx.x * S_N + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
-  // The workgroup that arrives last adds the block partials up -- in block order, whoever it is, so the sums do not depend on the
-  // schedule -- and sets the local denominators (what used to be a launch of its own).
-  __shared__ int last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(a.arrived, 1) == (int)gridDim.x - 1);
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
+}
+
+// The block partials added up in BLOCK ORDER (so the sums do not depend on any schedule) + the local denominators.  Round 4 had the
+// last-arriving workgroup of the reduction launch do this behind an atomic arrival counter kept in the caller's scratch: a scratch that
+// was not zeroed once, an aborted launch or two streams sharing one scratch left the counter off and the sums silently stale (ADVICE
+// r4).  Now nothing persists between calls: every workgroup of the gradient launch runs this itself (<= 64 x 10 floats from L2), or --
+// data parallel, where the denominators go through the exchange hook between the launches -- one workgroup of loss_reduce_kernel.
+__device__ __forceinline__ void loss_reduce(const LossArgs& a, float (&tot)[S_N], float (&cnt)[C_N]) {
   if (threadIdx.x < S_N) {
     float v = 0.f;
-    for (int b = 0; b < (int)gridDim.x; ++b) v += a.partial[b * S_N + threadIdx.x];
-    a.sums[threadIdx.x] = v;
-    if (threadIdx.x == S_DEPTH_CNT) a.cnt[C_DEPTH] = v;
-    if (threadIdx.x == S_NORMAL_CNT) a.cnt[C_NORMAL] = v;
+    for (int b = 0; b < a.nb; ++b) v += a.partial[b * S_N + threadIdx.x];
+    tot[threadIdx.x] = v;
+    if (threadIdx.x == S_DEPTH_CNT) cnt[C_DEPTH] = v;
+    if (threadIdx.x == S_NORMAL_CNT) cnt[C_NORMAL] = v;
   }
-  if (threadIdx.x == 0) { a.cnt[C_B] = (float)a.B; a.cnt[C_NPC] = (float)a.n_pc; *a.arrived = 0; }
+  if (threadIdx.x == 0) { cnt[C_B] = (float)a.B; cnt[C_NPC] = (float)a.n_pc; }
+}
+
+__global__ __launch_bounds__(64) void loss_reduce_kernel(LossArgs a) {
+  __shared__ float tot[S_N], cnt[C_N];
+  loss_reduce(a, tot, cnt);
+  __syncthreads();
+  if (threadIdx.x < S_N) a.sums[threadIdx.x] = tot[threadIdx.x];
+  if (threadIdx.x < C_N) a.cnt[threadIdx.x] = cnt[threadIdx.x];
 }
 
 // the reported values (workgroup 0 of the gradient launch)
-__device__ __forceinline__ void loss_finalize(const LossArgs& a) {
-  __shared__ float tot[S_N];
-  if (threadIdx.x < S_N) tot[threadIdx.x] = a.sums[threadIdx.x];
-  __syncthreads();
+__device__ __forceinline__ void loss_finalize(const LossArgs& a, const float (&tot)[S_N], const float (&cnt)[C_N]) {
   if (threadIdx.x == 0) {
-    const float B = a.cnt[C_B];
+    const float B = cnt[C_B];
     const float rgb = tot[S_RGB] / (3.0f * B);
     const float eik = a.grad_theta ? tot[S_EIK] / (2.0f * B) : 0.f;
     const float smooth = (a.diff_norm && a.c.smooth_on && a.c.smooth_w > 0.f) ? tot[S_SMOOTH] / B : 0.f;
     const float mask = (a.gt_mask && a.c.mask_w > 0.f) ? tot[S_MASK] / B : 0.f;
-    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / a.cnt[C_DEPTH] : 0.f;
-    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / a.cnt[C_NORMAL] : 0.f;
+    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / cnt[C_DEPTH] : 0.f;
+    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / cnt[C_NORMAL] : 0.f;
     const float normal = a.c.normal_w > 0.f ? nl1 : 0.f, angular = a.c.angular_w > 0.f ? nl1 : 0.f;
-    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / a.cnt[C_NPC] : 0.f;
+    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / cnt[C_NPC] : 0.f;
     const float light = (a.lmask && a.gt_lmask && a.c.light_w > 0.f) ? tot[S_LIGHT] / B : 0.f;
     a.losses[0] = rgb + a.c.eikonal_w * eik + a.c.smooth_w * smooth + a.c.mask_w * mask + a.c.depth_w * depth + a.c.normal_w * normal +
                   a.c.angular_w * angular + a.c.bubble_w * bubble + a.c.light_w * light;
@@ -121,9 +127,17 @@ __device__ __forceinline__ void loss_finalize(const LossArgs& a) {
 }
 
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
-  if (blockIdx.x == 0) loss_finalize(a);
+  __shared__ float tot[S_N], cnt[C_N];
+  if (a.reduced) {
+    if (threadIdx.x < S_N) tot[threadIdx.x] = a.sums[threadIdx.x];
+    if (threadIdx.x < C_N) cnt[threadIdx.x] = a.cnt[threadIdx.x];
+  } else {
+    loss_reduce(a, tot, cnt);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) loss_finalize(a, tot, cnt);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const float B = a.cnt[C_B];
+  const float B = cnt[C_B];
   if (i < a.B) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
       a.g_rgb[i * 3 + k] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (3.0f * B);
     }
     float gd = 0.f;
-    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / a.cnt[C_DEPTH];
+    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / cnt[C_DEPTH];
     a.g_depth[i] = gd;
     float gw = 0.f;
     if (a.gt_mask && a.c.mask_w > 0.f) { float d; (void)bce(a.wsum[i], a.gt_mask[i], d); gw = a.c.mask_w * d / B; }
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
     if (a.g_normal) {
       float g0 = 0.f, g1 = 0.f, g2 = 0.f;
       if (a.gt_normal && a.normal && a.normal_mask[i]) {
-        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / a.cnt[C_NORMAL];
+        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / cnt[C_NORMAL];
         const float n0 = a.gt_normal[i * 3], n1 = a.gt_normal[i * 3 + 1], n2 = a.gt_normal[i * 3 + 2];
         const float u = 1.0f - (a.normal[i * 3] * n0 + a.normal[i * 3 + 1] * n1 + a.normal[i * 3 + 2] * n2);
         const float sg = u > 0.f ? -1.f : (u < 0.f ? 1.f : 0.f);          // d|1-dot| / d dot
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
   }
   if (a.g_surface && i < a.n_pc) {
     const float sv = a.surface[i];
-    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / a.cnt[C_NPC] : 0.f;
+    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / cnt[C_NPC] : 0.f;
   }
 }
 
@@ -257,16 +271,18 @@ extern "C" int i2sdf_loss_forward_backward(const i2sdf_loss_cfg* cfg, int64_t B,
   a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.normal = normal; a.grad_theta = grad_theta; a.diff_norm = diff_norm; a.surface = surface;
   a.lmask = lmask; a.gt_rgb = gt_rgb; a.gt_depth = gt_depth; a.gt_normal = gt_normal; a.gt_mask = gt_mask; a.gt_lmask = gt_lmask;
   a.depth_mask = depth_mask; a.normal_mask = normal_mask;
-  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.cnt = a.sums + S_N; a.arrived = (int*)(a.cnt + C_N); a.losses = losses;
+  a.partial = scratch; a.sums = scratch + LOSS_BLOCKS * S_N; a.cnt = a.sums + S_N; a.losses = losses;
   a.loss_value = loss_value;
   a.g_rgb = g_rgb; a.g_depth = g_depth; a.g_wsum = g_wsum; a.g_normal = g_normal; a.g_grad_theta = g_grad_theta; a.g_diff_norm = g_diff_norm;
   a.g_surface = g_surface; a.g_lmask = g_lmask;
   hipStream_t st = (hipStream_t)stream;
   const int64_t work = std::max<int64_t>(2 * B, a.n_pc);
   const int nb = (int)std::min<int64_t>(LOSS_BLOCKS, (work + 255) / 256);
+  a.nb = nb; a.reduced = cfg->exchange ? 1 : 0;
   loss_partial_kernel<<<nb, 256, 0, st>>>(a);
   if (cfg->exchange) {       // data parallel: denominators -> their mean over the ranks (global count / world)
     if (!cfg->exchange->allreduce) return I2SDF_EINVAL;
+    loss_reduce_kernel<<<1, 64, 0, st>>>(a);
     const int rc = cfg->exchange->allreduce(cfg->exchange->ctx, a.cnt, C_N, I2SDF_XCHG_F32, I2SDF_XCHG_AVG, stream);
     if (rc) return rc;
   }

@@ -44,6 +44,11 @@ inline int64_t split_bulk_points(int64_t M, int n_cu) {
   const int64_t n_wg = (M + PTS_PER_WG - 1) / PTS_PER_WG;
   const int64_t full = (n_wg / n_cu) * n_cu, rem = n_wg - full;
   if (full == 0 || rem == 0 || rem * 4 > n_cu) return 0;      // nothing to gain, or the tail would not fit one round
+  // the bulk is also where the blocked layout of the saved tensors ends, and the weight-gradient kernels pick an operand's layout once
+  // per split-M chunk: a chunk must not straddle that boundary (n_cu * 128 is a multiple of the 2048-point chunk only when n_cu % 16 == 0
+  // -- true for the 256 CUs of an MI355X, not for every partition of it).  No split then: every point goes through the full
+  // workgroups, every saved tensor is blocked throughout.
+  if ((full * PTS_PER_WG) % I2SDF_WG_CH != 0) return 0;
   return full * PTS_PER_WG;
 }
 

@@ -573,6 +573,9 @@ extern "C" int i2sdf_light_forward(const i2sdf_plan* p, const float* packed, con
   a.n_fwd = (op_chunks(HL / 32, F / 8) + rowvec_chunks(HL / 8, 1)) / SC;
   a.feat = feat; a.M = M; a.Mp = Mp; a.lm = lm; a.hl = hl;
   hipStream_t st = (hipStream_t)stream;
+  // the head's kernels are never cut into point ranges: called INSIDE a chain (a C caller may; the module calls it outside) the entry
+  // point joins the ranges into `st` first -- `feat` is written by the ranges of i2sdf_sdf_forward_grad -- and fences them behind itself
+  ChainGuard guard(p, st, false);
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (p->rgb_bf16x3 && HL == 128 && F == 256 && p->light.fwd3h_chunks > 0) {      // bf16x3 split arithmetic with the radiance net's option
     LightFwd3hArgs x{};
@@ -599,6 +602,7 @@ extern "C" int i2sdf_light_backward(const i2sdf_plan* p, const float* packed, co
   a.n_rev = rowvec_chunks(HL / 8, 1) / SC;
   a.M = M; a.Mp = Mp; a.lm = const_cast<float*>(lm); a.lm_bar = lm_bar; a.hl = const_cast<float*>(hl); a.gal0 = gal0; a.gal_last = gal_last;
   hipStream_t st = (hipStream_t)stream;
+  ChainGuard guard(p, st, false);         // as in i2sdf_light_forward: whole-batch launches on `st`, joined / fenced when called inside a chain
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
   if (HL == 128) launch_lds(light_bwd_kernel<128>, grid, st, a);
   else if (HL == 32) launch_lds(light_bwd_kernel<32>, grid, st, a);

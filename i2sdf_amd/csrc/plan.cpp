@@ -513,7 +513,10 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_SDF_FWD_BF16X3) {
-    if (value && p->sdf.fwd3_chunks == 0) return I2SDF_EINVAL;      // no bf16x3 stream for this shape
+    // the option is accepted only where a bf16x3 kernel will actually run (mlp_fwd.hip: launch_sdf_fwd): 256-wide nets on the 16-point-wave
+    // stream, 64-wide nets on the 32-point stream -- a shape with neither would otherwise report success and fall through to fp32 MFMA
+    const bool runs = (p->H == 256 && p->F == 256 && p->sdf.fwd3h_chunks > 0) || (p->H == 64 && p->F == 64 && p->sdf.fwd3_chunks > 0);
+    if (value && !runs) return I2SDF_EINVAL;
     p->sdf_fwd_bf16x3 = value ? 1 : 0;
     return I2SDF_OK;
   }

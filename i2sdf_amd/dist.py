@@ -119,20 +119,25 @@ class TorchExchange:
 
         def cb(ctx, buf, n, dtype, op, stream):
             try:
-                t = torch.as_tensor(_DevView(buf, n, "<i4" if dtype == L.XCHG_I32 else "<f4"), device="cuda")
-                if op == L.XCHG_MAX:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                else:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                    if op == L.XCHG_AVG:
-                        t.div_(self.world)
-                self.calls += 1
+                self.reduce_(torch.as_tensor(_DevView(buf, n, "<i4" if dtype == L.XCHG_I32 else "<f4"), device="cuda"), op)
                 return 0
             except Exception:      # never let an exception cross the C boundary
                 return -5
 
         self._cb = L.EXCHANGE_FN(cb)              # keep the trampoline alive as long as the hook is installed
         self._ex = L.Exchange(self._cb, None)
+
+    def reduce_(self, t: torch.Tensor, op: int):
+        """the hook's collective on a tensor, in place (MAX / SUM / AVG over the group) -- what the C callback does with the device buffer
+        it is handed; bench.py --selftest-launch --equivalent calls it directly on host tensors (no kernels on a CPU box)"""
+        if op == L.XCHG_MAX:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if op == L.XCHG_AVG:
+                t.div_(self.world)
+        self.calls += 1
+        return t
 
     def exchange(self) -> L.Exchange:
         return self._ex

@@ -27,7 +27,7 @@ class RenderEngine:
         self.pack_floats = int(self._lib.i2sdf_plan_pack_floats(plan))
         self.wgrad_floats = int(self._lib.i2sdf_plan_wgrad_floats(plan))
         self.packed = torch.zeros(self.pack_floats, dtype=torch.float32, device=self.device)
-        self._pack_stream, self._pack_event = None, None
+        self._pack_stream, self._pack_event, self._pack_readers = None, None, {}
         self.F = cfg.feature_size
         self.sdf_forward_bf16x3 = False
         self.wgrad_bf16x3 = False
@@ -134,17 +134,32 @@ class RenderEngine:
         side = self._pack_stream
         if side is None:
             side = self._pack_stream = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        cur = torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        # streams that read `packed` since the previous pack (entry points issued on other streams than the one calling pack()): the
+        # new pack must not overwrite the weight streams under them
+        for sid, st in getattr(self, "_pack_readers", {}).items():
+            if sid != cur.cuda_stream:
+                side.wait_stream(st)
         with torch.cuda.stream(side):
             L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
             self._pack_event = side.record_event()
+        # the side stream reads the flat parameter buffer: the caching allocator must not hand its memory out again (module.to(), a
+        # re-flattened buffer) while the pack is still reading it
+        flat_params.record_stream(side)
+        self._pack_readers = {}
 
     def _pk(self):
-        """pointer to the packed weight streams, after making the current stream wait for a pack still in flight"""
+        """pointer to the packed weight streams, after making the CURRENT stream wait for the last pack.  The event is kept until the next
+        pack(): every stream that has not waited for it yet does so once (an eval render or an autograd backward on another stream than
+        the first entry point's reads the same weight streams -- ADVICE r4)."""
         ev = self._pack_event
         if ev is not None:
-            torch.cuda.current_stream(self.packed.device).wait_event(ev)
-            self._pack_event = None
+            cur = torch.cuda.current_stream(self.packed.device)
+            readers = self.__dict__.setdefault("_pack_readers", {})
+            if cur.cuda_stream not in readers:
+                cur.wait_event(ev)
+                readers[cur.cuda_stream] = cur
         return L.ptr(self.packed)
 
     def set_sdf_forward_bf16x3(self, on: bool):

@@ -68,7 +68,7 @@ class I2SDFLoss(nn.Module):
         if self.bubble_weight > 0 and self.max_bubble_iter is not None and self.smooth_iter < self.max_bubble_iter:
             self.smooth_iter = self.max_bubble_iter
         self.light_mask_weight = light_mask_weight
-        self._scratch = {}         # per device: the reduction scratch, zeroed once (its arrival counter resets itself, include/i2sdf.h)
+        self._scratch = {}         # per (device, stream): the reduction workspace (stateless, include/i2sdf.h: i2sdf_loss_forward_backward)
         self.exchange = None       # i2sdf_amd.dist.attach_loss: lib.Exchange hook -> global denominators (1-GPU-equivalent data parallelism)
         self._dp_state = None      # the attached module's DataParallelState (its `enabled` flag: no_sync())
 
@@ -102,9 +102,10 @@ class I2SDFLoss(nn.Module):
             gtc.pop("light_mask", None)
         import ctypes as C
         dev = out["rgb_values"].device
-        scratch = self._scratch.get(dev)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # calls in flight on different streams must not share the workspace
+        scratch = self._scratch.get(key)
         if scratch is None:
-            scratch = self._scratch[dev] = torch.zeros(int(L.load().i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
+            scratch = self._scratch[key] = torch.empty(int(L.load().i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
         total, vec = _FusedLossFn.apply(C.byref(cfg), 0 if surf is None else surf.shape[0], gtc, scratch, out["rgb_values"], out["depth_values"],
                                  out["weight_sum"].reshape(-1), out.get("normal_values"), out.get("grad_theta"), out.get("diff_norm"),
                                  None if surf is None else surf.reshape(-1),

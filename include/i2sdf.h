@@ -144,7 +144,8 @@ int i2sdf_chain_fence(const i2sdf_plan* plan, void* stream);
 int i2sdf_chain_end(const i2sdf_plan* plan, void* stream);
 /* floats of device memory the packed weight streams need (pass to i2sdf_pack_weights) */
 int64_t i2sdf_plan_pack_floats(const i2sdf_plan* plan);
-/* floats of the effective-weight gradient buffer i2sdf_weightnorm_backward consumes */
+/* floats of ONE split-M chunk of effective-weight gradient partial sums: i2sdf_weight_grads takes n_chunks x this many floats of
+ * workspace (`partials`) and reduces them, fused with the weight-norm backward, into the flat gradient */
 int64_t i2sdf_plan_wgrad_floats(const i2sdf_plan* plan);
 
 /* ------------------------------------------------------------------------------------------------
@@ -435,10 +436,12 @@ int i2sdf_light_backward(const i2sdf_plan* plan, const float* packed, const floa
  * gt_lmask (B)|NULL.  `smooth_on` = the reference's `smooth_iter is None or step > smooth_iter` (:347).
  *   -> losses[10] = {loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask} (device), loss_value (1)|NULL = the
  *      total once more as a tensor of its own (a scalar for autograd without a select on the vector),
- *      g_* = d loss / d (same-named input); scratch: i2sdf_loss_scratch_floats() floats, of which the LAST FOUR must be zero on entry
- *      and are zero again on exit (an arrival counter: a buffer zeroed once can be reused by every call on one stream).
- *   Two launches: per-block partial sums whose last-arriving workgroup reduces them (in block order: deterministic), [the exchange
- *   hook], then the reported values + every gradient.
+ *      g_* = d loss / d (same-named input); scratch: i2sdf_loss_scratch_floats() floats of workspace, contents irrelevant on entry
+ *      (nothing persists in it between calls: no counter, nothing to zero; calls in flight on DIFFERENT streams need different
+ *      scratch buffers, calls on one stream can share one).
+ *   Two launches: per-block partial sums; then the reported values + every gradient, where every workgroup first adds the block
+ *   partials up itself, in block order (deterministic, no atomics).  With an exchange hook a one-workgroup reduction and the hook's
+ *   collective sit between the two.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct i2sdf_loss_cfg {
   float eikonal_w, smooth_w, mask_w, depth_w, normal_w, angular_w, bubble_w, light_w;

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Timing-only KNOCK-OUT builds (wrong results on purpose), kept OUT of the production sources.
+
+    python scripts/ab/knockout_build.py NAME KO[,KO...] file1.hip [file2.hip ...] [-- extra hipcc flags]
+
+copies i2sdf_amd/csrc to i2sdf_amd/.ab_src_NAME/ (a sibling, so that the relative includes still resolve; removed afterwards), applies the named source patches below to the COPY (every patch must
+match exactly once: a drifted source fails loudly instead of silently timing the unpatched kernel), compiles the listed
+translation units from the copy with the production flags of csrc/build.sh, links them with the in-tree objects of everything
+else and writes i2sdf_amd/lib/ab/libi2sdf_NAME.so (select with I2SDF_LIB_PATH, as for scripts/ab/variant_build.sh).
+
+Until round 4 these were `#ifdef I2SDF_ABL_*` blocks inside csrc/common.h; round 5 moved them here so that the shipped headers
+contain no code path that computes wrong results.
+
+A knock-out answers "what would it buy if X were free" -- an upper bound, measured on a kernel that draws less power and therefore
+clocks higher than any complete variant could ("timing ablations lie on this chip"); only complete variants are compared
+for adoption.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "i2sdf_amd", "csrc")
+
+# name -> list of (file, old, new)
+PATCHES = {
+    # no saved-tensor store at all (every stg4): what do the stores cost a kernel?
+    "nostore": [("common.h", "__device__ __forceinline__ void stg4(float* p, f32x4 v) {\n",
+                 "__device__ __forceinline__ void stg4(float* p, f32x4 v) {\n  (void)p; (void)v; return;\n")],
+    # no vmcnt(0) drain in front of the stage barriers (stale weights): what does draining the wave's own stores at every stage cost?
+    "novmwait": [("common.h", "    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)\n", "\n"),
+                 ("common.h", "    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), see advance()\n", "\n")],
+    # no weight DMA (garbage weights)
+    "nodma": [("common.h", "  __device__ __forceinline__ void issue(float* dst, int tid) {\n",
+               "  __device__ __forceinline__ void issue(float* dst, int tid) {\n    goff += STG * 4; (void)dst; return;\n")],
+    # round 5, VERDICT r4 task 1 step 0: the bound on fusing the weight-gradient products into the sweeps --
+    # sweep 1 without the G(hbar) store, sweep 2 without the G(a) store (the two tensors only the weight-gradient GEMMs read) ...
+    "sweeps_no_wgrad_stores": [
+        ("x3.h", "    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v, kcs); x3_store8(g2row, kc, hi, g2, kcs); }\n",
+         "    if (kc < KACC && valid) { x3_store8(g2row, kc, hi, g2, kcs); }\n"),
+        ("x3.h", "    if (valid) x3_store8(grow, kc, hi, v, kcs);\n  }\n};\n// a point-major row in global memory (or zeros) as B operand",
+         "    (void)kc; (void)v;\n  }\n};\n// a point-major row in global memory (or zeros) as B operand"),
+    ],
+    # ... and the 256x256 weight-gradient kernel without its operand loads (pure split + MFMA + partial-sum flush)
+    "wgrad3p_no_loads": [
+        ("wgrad.hip", "      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);\n      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);\n",
+         "      (void)src;\n      if (half == 0) rlo[i] = f32x4{1.f + s, 2.f, 3.f, 4.f};\n      else rhi[i] = f32x4{0.5f, 0.25f + s, 0.125f, 2.5f};\n"),
+    ],
+}
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-result"]
+X3 = ["-mllvm", "-pragma-unroll-threshold=1000000"]
+EXTRA = {"mlp_x3.hip": X3, "mlp_x3h.hip": X3 + ["-fno-slp-vectorize"], "mlp_x3q.hip": X3 + ["-fno-slp-vectorize"], "wgrad.hip": X3 + ["-fno-slp-vectorize"]}
+
+
+def main():
+    argv = sys.argv[1:]
+    more = []
+    if "--" in argv:
+        i = argv.index("--")
+        argv, more = argv[:i], argv[i + 1:]
+    if len(argv) < 3:
+        sys.exit(__doc__)
+    name, kos, files = argv[0], [k for k in argv[1].split(",") if k and k != "none"], argv[2:]
+    src = os.path.join(ROOT, "i2sdf_amd", ".ab_src_" + name)
+    shutil.rmtree(src, ignore_errors=True)
+    shutil.copytree(CSRC, src)
+    for ko in kos:
+        if ko not in PATCHES:
+            sys.exit(f"unknown knock-out {ko!r}; known: {', '.join(PATCHES)}")
+        for fn, old, new in PATCHES[ko]:
+            p = os.path.join(src, fn)
+            s = open(p).read()
+            if s.count(old) != 1:
+                sys.exit(f"knock-out {ko}: the pattern in {fn} matches {s.count(old)} times (expected 1): the source has drifted")
+            open(p, "w").write(s.replace(old, new))
+    objdir = os.path.join(ROOT, "i2sdf_amd", "lib", "ab", name)
+    shutil.rmtree(objdir, ignore_errors=True)
+    os.makedirs(objdir)
+    procs = []
+    for f in files:
+        o = os.path.join(objdir, os.path.splitext(f)[0] + ".o")
+        cmd = ["hipcc"] + FLAGS + EXTRA.get(f, []) + more + ["-x", "hip", "-c", f, "-o", o]
+        procs.append((f, subprocess.Popen(cmd, cwd=src)))
+    for f, pr in procs:
+        if pr.wait() != 0:
+            sys.exit(f"compiling {f} failed")
+    skip = {os.path.splitext(f)[0] + ".o" for f in files}
+    inobj = os.path.join(ROOT, "i2sdf_amd", "lib", "obj")
+    others = [os.path.join(inobj, o) for o in sorted(os.listdir(inobj)) if o.endswith(".o") and o not in skip]
+    out = os.path.join(ROOT, "i2sdf_amd", "lib", "ab", f"libi2sdf_{name}.so")
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + [os.path.join(objdir, o) for o in sorted(os.listdir(objdir))] + others)
+    shutil.rmtree(src, ignore_errors=True)
+    print("built", out)
+
+
+if __name__ == "__main__":
+    main()

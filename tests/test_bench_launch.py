@@ -30,6 +30,11 @@ def _check(stdout, n):
         assert "torch.distributed all_reduce" in d["config"]["parallelism"] and d["config"]["backend"] == "gloo"
         ar = d["allreduce_us"]                      # the collective of a step timed alone: the record the first N-GPU run will carry
         assert ar["unit"] == "us" and ar["value"] > 0 and ar["bytes"] > 3_000_000 and "torch.distributed" in ar["transport"]
+        # round 5: what the collective costs THE STEP -- the same step under no_sync() and the difference, next to the collective alone
+        assert d["step_ms_without_allreduce"] > 0
+        assert abs(d["exposed_allreduce_ms"] - (d["ms_per_step"] - d["step_ms_without_allreduce"])) < 1e-3
+    else:
+        assert "step_ms_without_allreduce" not in d and "exposed_allreduce_ms" not in d
     assert len(d["strong"]["windows_ms_per_step"]) >= 1 and d["strong"]["us_per_ray"] > 0 and d["us_per_ray"] > 0
     return d
 
@@ -39,6 +44,19 @@ def test_self_spawned_two_ranks_print_one_line():
                         "--warmup", "1", "--windows", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     _check(r.stdout.decode(), 2)
+
+
+def test_self_spawned_two_ranks_equivalent_mode():
+    """--equivalent: attach_data_parallel(equivalent=True) in a launched job; the CPU stand-in issues the exchanges the device-side hooks of
+    a real step issue (5 MAX-flag reductions + 1 denominator average per step, asserted rank-consistent inside bench.py) through the same
+    TorchExchange object and group -- until round 5 these had only ever run inside pytest workers"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--selftest-launch", "--gpus", "2", "--backend", "gloo", "--steps", "3",
+                        "--warmup", "1", "--windows", "2", "--equivalent"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = _check(r.stdout.decode(), 2)
+    assert d["config"]["equivalent"] is True and d["equivalent"]["on"] is True
+    assert d["equivalent"]["exchange_calls"] > 0 and d["equivalent"]["exchange_calls"] % 6 == 0      # six exchanges per synced step
+    # the no_sync() windows issue no exchange: the hooks follow DataParallelState.enabled like the real loss / sampler do in training mode
 
 
 def test_self_spawned_eight_ranks_print_one_line():
