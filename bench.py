@@ -137,7 +137,7 @@ def bytes_per_point(cfg):
     row, frow = 4 * H, 4 * F
     return {
         "i2sdf_sdf_forward_grad": nh * row * 3 + frow + 160 + 28,      # write h, write abar, re-read h (chain), feature, PE, sdf/grad
-        "i2sdf_sdf_backward": nh * row * (2 + 2 + 2 + 1) + frow + 200,  # sweep 1: read h, abar, write G(hbar), G2; sweep 2: read h, G2, write G(a)
+        "i2sdf_sdf_backward": nh * row * (2 + 4) + frow + 200,  # sweep 1: read h, write G(hbar); sweep 2: read h, abar, G(hbar), write G(a) (round 5: G2 formed in sweep 2)
         "i2sdf_weight_grads": nh * row * 4 + row + frow + nr * 2 * 4 * cfg.rgb.hidden + frow + 288,   # A, A', B, B' per SDF layer; rgb G(a), r
         "i2sdf_rgb_forward": frow + nr * 4 * cfg.rgb.hidden + 128 + 12,
         "i2sdf_rgb_backward": nr * 4 * cfg.rgb.hidden * 2 + frow + 40,

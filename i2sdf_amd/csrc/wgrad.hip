@@ -371,9 +371,68 @@ constexpr int WGN_LDS_BYTES = 2 * WGW_SLOT * 4;            // two such slots (wg
 template <int AM, int BM, int NPL>
 __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTask& t, int64_t chunk, int wave, int lane, float* lds) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NW = TA * TB * 16 + TA;
+  const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
+  if constexpr (NPL != 0 && BM != 0) {
+    // split form with a narrow B operand: the tiles stay in a[...] and go through LDS / to memory ONE TILE AT A TIME (16 registers), as in
+    // wgrad_wide_body.  Read out into acc[TA][TB] all at once, the 4 x 2-tile variant (PE columns of layer 0 / the skip layer against a
+    // 128-row tile) held 128 registers of tiles next to the store loop's addresses and spilled 26 of them (108 B of scratch in the
+    // shipped round-4 binary; tests/test_wgrad3p_isa.py now holds this kernel to zero).  Same values, same summation order ((w0 + w1) + w2) + w3.
+    float bsum[TA];
+    wgrad_accumulate_x_core<AM, BM, NPL == 0 ? 2 : NPL>(t, lo, lo + WG_CH / 4, lane, bsum);
+    if (wave > 0) {
+      float* dst = lds + (wave - 1) * NW * 64 + lane;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((a * TB + b) * 16 + r) * 64] = w3_acc_read(16 * (a + 4 * b) + r);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+      for (int a = 0; a < TA; ++a) dst[(TA * TB * 16 + a) * 64] = bsum[a];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int i32 = lane & 31, hi = lane >> 5;
+      float* out = L.partials + chunk * L.chunk_stride;
+#pragma unroll
+      for (int a = 0; a < TA; ++a)
+#pragma unroll
+        for (int b = 0; b < TB; ++b) {
+          float x[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) x[r] = w3_acc_read(16 * (a + 4 * b) + r);
+#pragma unroll
+          for (int w = 0; w < 3; ++w)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[r] += lds[(w * NW + (a * TB + b) * 16 + r) * 64 + lane];
+          if (i32 + 32 * b < t.cols_store) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ri = (r & 3) + 8 * (r >> 2) + 4 * hi, n = AM ? ri : 4 * ri + a;          // as wgrad_store
+              if (n < t.rows_store) out[t.out_off + (int64_t)n * t.ldo + i32 + 32 * b] = x[r];
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (t.has_bias) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+#pragma unroll
+          for (int a = 0; a < TA; ++a) bsum[a] += lds[(w * NW + TA * TB * 16 + a) * 64 + lane];
+#pragma unroll
+        for (int a = 0; a < TA; ++a) bsum[a] += __shfl_xor(bsum[a], 32);
+        if (hi == 0) {
+          if (AM) { if (i32 < t.rows_store) out[t.bias_off + i32] = bsum[0]; }
+          else if (4 * i32 < t.rows_store) *reinterpret_cast<f32x4*>(out + t.bias_off + 4 * i32) = f32x4{bsum[0], bsum[TA > 1 ? 1 : 0], bsum[TA > 2 ? 2 : 0], bsum[TA > 3 ? 3 : 0]};
+        }
+      }
+    }
+    return;
+  }
   f32x16 acc[TA][TB];
   float bsum[TA];
-  const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
   if (NPL == 0) wgrad_accumulate<AM, BM, PFN>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
   else wgrad_accumulate_x<AM, BM, NPL == 0 ? 2 : NPL>(t, lo, lo + WG_CH / 4, lane, acc, bsum);
   if (wave > 0) {

@@ -287,38 +287,40 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
   stg4(row + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
 }
 // sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
-//                                           G2(a_l)      = G(abar_l) abar_l 100 (1 - sigma_l)  [stored to g2row]
+// Round 5: the second-order injection G2(a_l) = G(abar_l) abar_l 100 (1 - sigma_l) is no longer written here (and re-read by sweep 2): sweep 2
+// RECOVERS G(abar_l) = G(hbar_{l+1}) / sigma_l from the tensor stored above -- the same sigma bits from the same h, so the quotient is
+// G(abar_l) to one rounding -- and forms G2 itself.  One store pass of this sweep and its read of abar become one more read pass of
+// sweep 2; the knock-outs of profiles/r5_step0_knockouts.txt price a store pass of the sweeps at ~4x a load pass.
 template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
-  const float* hrow; const float* arow; float* g2row; float* gurow; int hi; bool valid; int kcs = 16;
-  f32x4 hq[X3_RING][2], aq[X3_RING][2];
+  const float* hrow; float* gurow; int hi; bool valid; int kcs = 16;
+  f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    if (kc < KACC) { x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(arow, kc, hi, aq[kc % X3_RING], kcs); }
+    if (kc < KACC) x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs);
   }
-  __device__ __forceinline__ float value(int kc, int u, float& g2) {
-    g2 = 0.f;
+  __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
     const float ga = accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u];
-    const float sg = sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
-    g2 = ga * aq[kc % X3_RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
-    return ga * sg;
+    return ga * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&g2)[8]) {
-    if (kc < KACC && valid) { x3_store8(gurow, kc, hi, v, kcs); x3_store8(g2row, kc, hi, g2, kcs); }
+  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (kc < KACC && valid) x3_store8(gurow, kc, hi, v, kcs);
   }
 };
-// sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored over G2 in grow]
+// sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored to grow]
+//          G2(a_l) = (G(hbar_{l+1}) / sigma_l) abar_l 100 (1 - sigma_l)   from sweep 1's stored G(hbar_{l+1}) (gurow) and the forward's abar_l (arow);
+//          sigma_l = 0 (h_{l+1} underflowed to 0: abar_l = 0 and G(hbar_{l+1}) = 0 as well) -> G2 = 0
 template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
-  const f32x16 (&accP)[NT]; const float* hrow; const float* g2row; float* grow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
-  f32x4 hq[X3_RING][2], gq[X3_RING][2], wq[X3_RING][2];
+  f32x4 hq[X3_RING][2], gq[X3_RING][2], aq[X3_RING][2], wq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
-    x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(g2row, kc, hi, gq[kc % X3_RING], kcs);
+    x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(gurow, kc, hi, gq[kc % X3_RING], kcs); x3_load8(arow, kc, hi, aq[kc % X3_RING], kcs);
     if (TOP) {
       wq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
       wq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
@@ -327,7 +329,10 @@ struct X3Sweep2Src {
   __device__ __forceinline__ float value(int kc, int u, float&) {
     float x = accP[kc >> 1][8 * (kc & 1) + u];
     if (TOP) x = fmaf(sb, wq[kc % X3_RING][u >> 2][u & 3], x);
-    return fmaf(x, sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]), gq[kc % X3_RING][u >> 2][u & 3]);
+    const float sg = sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
+    const float ga = sg > 0.f ? gq[kc % X3_RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
+    const float g2 = ga * aq[kc % X3_RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
+    return fmaf(x, sg, g2);
   }
   __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
     if (valid) x3_store8(grow, kc, hi, v, kcs);

@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
 # (I2SDF_OPT_WGRAD_BF16X2, i2sdf_amd/config.py); every GPU test module that computes parameter gradients runs twice, once per mode, under
 # the same bars -- the engine reads I2SDF_WGRAD_BF16X2 when it is constructed, and worker processes inherit it.
 WGRAD_MODE_MODULES = {"test_gpu_backward", "test_gpu_baseline_sizes", "test_gpu_determinism", "test_gpu_network", "test_gpu_training_parity",
-                      "test_gpu_training_curve_full", "test_gpu_dp_equivalence", "test_gpu_loss", "test_gpu_edge_cases", "test_gpu_optim",
+                      "test_gpu_training_curve_full", "test_gpu_psnr_ensemble", "test_gpu_dp_equivalence", "test_gpu_loss", "test_gpu_edge_cases", "test_gpu_optim",
                       "test_gpu_eikonal_outputs", "test_gpu_rccl"}
 
 

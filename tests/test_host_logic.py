@@ -123,3 +123,18 @@ def test_unsupported_shapes_are_refused_at_construction_with_the_reason():
         assert needle in str(e.value), (needle, str(e.value))
     NetConfig.from_conf(synthetic_conf())          # the shipped shapes pass
     NetConfig.from_conf(synthetic_conf(True))
+
+
+def test_knockout_patches_match_the_current_sources():
+    """scripts/ab/knockout_build.py patches a COPY of csrc by exact-string replacement (the shipped headers carry no knock-out code): every
+    pattern must match the current sources exactly once, or the tool would time an unpatched kernel."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("knockout_build", os.path.join(root, "scripts", "ab", "knockout_build.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for name, patches in m.PATCHES.items():
+        for fn, old, new in patches:
+            assert open(os.path.join(m.CSRC, fn)).read().count(old) == 1, (name, fn)
+    assert "I2SDF_ABL" not in open(os.path.join(m.CSRC, "common.h")).read()

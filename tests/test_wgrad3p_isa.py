@@ -138,3 +138,29 @@ def test_wgrad_narrow_bf16_accumulator_window(isa):
         runs = re.sub(r"(.)\1+", r"\1", kinds)          # e.g. ZMRCZMRCZMRC: three operand-shape variants of the body
         assert re.fullmatch(r"(ZMRC?)+", runs), f"{name}: unexpected order of zero fill / MFMAs / read-out / compiler AGPR uses: {runs}"
         assert kinds.count("M") >= 3 * 12, (name, kinds.count("M"))
+
+
+def test_wgrad_narrow_bf16_has_no_spills_in_its_loops(isa):
+    """Round 5 (VERDICT r4 task 5a): the shipped round-4 binary of wgrad_narrow_kernel<3> carried 108 B of scratch per lane (26 spilled VGPRs: the
+    4 x 2-tile variant read all eight tiles out of a[...] into VGPRs in front of its cross-wave sum and store loop).  The tiles now leave the
+    AGPRs one at a time; what may remain is a single value parked at kernel entry (<= 8 B), never a spill or reload inside a loop."""
+    lines, remarks = isa
+    m = re.search(r"Function Name: (\S*wgrad_narrow_kernelILi3E\S*)(.*?)Occupancy", remarks, re.S)
+    assert m, "no resource remark for wgrad_narrow_kernel<3>"
+    sz = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", m.group(2)).group(1))
+    assert sz <= 8, sz
+    # blocks that belong to a loop carry the assembler's "in Loop:" / "Loop Header" annotation on their label line
+    cur, in_loop, bad, n_loop_blocks = False, False, [], 0
+    for ln in lines:
+        if re.match(r"^_Z\w*wgrad_narrow_kernelILi3E\w*:", ln):
+            cur = True
+        elif cur and ln.startswith(".Lfunc_end"):
+            break
+        elif cur:
+            if re.match(r"^\.LBB\d+_\d+:", ln):
+                in_loop = "Loop" in ln
+                n_loop_blocks += in_loop
+            elif in_loop and "scratch_" in ln.split(";")[0]:
+                bad.append(ln.strip())
+    assert n_loop_blocks > 10
+    assert not bad, bad[:5]
