@@ -30,7 +30,7 @@ struct SdfBwdArgs {
   const float* nbar;                    // (M,3) d loss / d grad         (nullptr = 0)
   float* gus;                           // (L, Mp, H)  G(hbar_l): slot l = h-part of G(ubar_l), l = 1..L-1 (slot 0 unused)
   float* gpbar;                         // (Mp, PEC*8) G(pbar)
-  float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (holds G2(a_l) between the sweeps)
+  float* gas;                           // (L-1, Mp, H) G(a_l), l = 0..L-2 (the fp32 / split-K kernels of mlp_bwd.hip park G2(a_l) here between their sweeps; the bf16x3 sweeps do not: x3.h)
   float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
   float* ones4;                         // (Mp,4) {1,0,0,0}
   int kcs = 16;                         // layout of hs / abars / gus / gas for the points of this launch
