@@ -890,9 +890,11 @@ def sdf_analytic_forward(sd, cfg: SdfCfg, x: Tensor, prefix: str = "implicit_net
 
 
 def sdf_analytic_backward(sd, cfg: SdfCfg, x: Tensor, fw, sbar: Tensor, fbar: Tensor, nbar: Tensor,
-                          prefix: str = "implicit_network"):
+                          prefix: str = "implicit_network", g2_in_sweep2: bool = False):
     """A.3: parameter gradients (dW effective, db) for upstream (sbar (M,1), fbar (M,F), nbar (M,3)),
-    then weight-norm backward -> {name: grad}.  Three sweeps, exactly what the HIP backward does."""
+    then weight-norm backward -> {name: grad}.  Three sweeps, exactly what the HIP backward does.
+    g2_in_sweep2: the form the bf16x3 sweeps use since round 5 (csrc/x3.h: X3Sweep2Src) -- sweep 1 keeps only G(hbar_{l+1}) = G(abar_l) sigma_l,
+    sweep 2 recovers G(abar_l) as its quotient by sigma_l (0 where sigma_l = 0) and forms G2(a_l) = G(abar_l) abar_l 100 (1 - sigma_l)."""
     L, rs2 = cfg.n_lin, 1.0 / math.sqrt(2)
     W, a, u, abar = fw["W"], fw["a"], fw["u"], fw["abar"]
     dW = [torch.zeros_like(w) for w in W]
@@ -901,6 +903,7 @@ def sdf_analytic_backward(sd, cfg: SdfCfg, x: Tensor, fw, sbar: Tensor, fbar: Te
     Gp = pe_jacobian_forward(x, cfg.multires, nbar)
     Gh = Gp
     G2: List[Optional[Tensor]] = [None] * L
+    Ghbar: List[Optional[Tensor]] = [None] * (L + 1)          # G(hbar_l), what sweep 1 stores (gus[l])
     for l in range(L):
         Gu = torch.cat([Gh, Gp], 1) * rs2 if l in cfg.skip_in else Gh
         dW[l] += abar[l].t() @ Gu
@@ -911,11 +914,17 @@ def sdf_analytic_backward(sd, cfg: SdfCfg, x: Tensor, fw, sbar: Tensor, fbar: Te
             hbar_next = _hbar_from_chain(fw, cfg, l + 1)
             G2[l] = Gabar * hbar_next * _sp_second(a[l])
             Gh = Gabar * sig
+            Ghbar[l + 1] = Gh
     # sweep 2: ordinary backward, top-down
     Ga = torch.cat([sbar, fbar], 1)
     for l in range(L - 1, -1, -1):
         if l < L - 1:
-            Ga = Ga + G2[l]
+            if g2_in_sweep2:
+                sig = _sp_prime(a[l])
+                Gabar = torch.where(sig > 0, Ghbar[l + 1] / torch.where(sig > 0, sig, torch.ones_like(sig)), torch.zeros_like(sig))
+                Ga = Ga + Gabar * abar[l] * (SOFTPLUS_BETA * (1.0 - sig))
+            else:
+                Ga = Ga + G2[l]
         db[l] += Ga.sum(0)
         dW[l] += Ga.t() @ u[l]
         Gu = Ga @ W[l]

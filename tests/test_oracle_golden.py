@@ -47,6 +47,19 @@ def test_g2_g3_sdf_forward_grad_double_backward(golden, name, skip):
         gk = "grad." + k[len("implicit_network."):]
         if gk in z.files:
             assert_close(gv, z[gk], 5e-5, "analytic " + gk)
+    # the form of the round-5 bf16x3 sweeps: G2 formed in sweep 2 from the stored G(hbar) -- the same gradients (fp64: to rounding)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    fw64 = orc.sdf_analytic_forward(sd64, cfg, x.double())
+    args64 = (torch.ones(x.shape[0], 1, dtype=torch.float64), t(z["feat_w"]).double(), nbar.double())
+    ga, _, _ = orc.sdf_analytic_backward(sd64, cfg, x.double(), fw64, *args64)
+    gb, _, _ = orc.sdf_analytic_backward(sd64, cfg, x.double(), fw64, *args64, g2_in_sweep2=True)
+    for k in ga:
+        assert_close(gb[k], ga[k], 1e-12, "G2 in sweep 2: " + k, floor=1e-30)
+    g32, _, _ = orc.sdf_analytic_backward(sd, cfg, x, fw, torch.ones(x.shape[0], 1), t(z["feat_w"]), nbar, g2_in_sweep2=True)
+    for k, gv in g32.items():
+        gk = "grad." + k[len("implicit_network."):]
+        if gk in z.files:
+            assert_close(gv, z[gk], 5e-5, "analytic (G2 in sweep 2) " + gk)
 
 
 def test_g4_radiance_net(golden):
