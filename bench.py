@@ -421,7 +421,8 @@ def main():
         extras["allreduce_us"] = allreduce_alone(wl, dev, world)
     elif mock and world > 1:
         extras["allreduce_us"] = allreduce_alone(wl, dev, world)      # the launch self-test exercises the record the first N-GPU run will carry
-    if world > 1 and weak is not None:
+    if world > 1 and weak is not None and not getattr(args, "equivalent", False):
+        # (not in --equivalent mode: there the sampler's flag exchange keeps running under no_sync(), the pair would not isolate the all-reduce)
         # what the one collective of a step costs THE STEP (not the collective timed alone): the headline step once more with the gradient
         # all-reduce suspended (i2sdf_amd.dist.no_sync); exposed = headline - that.  The ranks' weights drift apart meanwhile (every rank
         # applies its own gradient): rank 0's parameters are broadcast again afterwards.  Last of the timed runs on purpose.
