@@ -31,15 +31,21 @@ namespace i2sdf {
 #ifndef I2SDF_NT
 #define I2SDF_NT 1      // measured (round 4, A/B in one run): step -0.03 ms, radiance forward / backward -3 / -6 %, sweeps unchanged
 #endif
+#ifndef I2SDF_NT_LD
+#define I2SDF_NT_LD I2SDF_NT      // loads and stores separately (round 5, scripts/ubench/hbm_mix.hip)
+#endif
+#ifndef I2SDF_NT_ST
+#define I2SDF_NT_ST I2SDF_NT
+#endif
 __device__ __forceinline__ f32x4 ldg4(const float* p) {
-#if I2SDF_NT
+#if I2SDF_NT_LD
   return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
 #else
   return *reinterpret_cast<const f32x4*>(p);
 #endif
 }
 __device__ __forceinline__ void stg4(float* p, f32x4 v) {
-#if I2SDF_NT
+#if I2SDF_NT_ST
   __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
 #else
   *reinterpret_cast<f32x4*>(p) = v;

@@ -260,6 +260,7 @@ struct X3RevSrc {
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ void ahead(int kc) {
+    // (non-temporal: plain loads as in the sweeps measured no change for this kernel -- it is not bound by its loads; profiles/r5_hbm_mix.txt)
     hq[kc % X3_RING][0] = ldg4(hrow + kcs * kc + 4 * hi);
     hq[kc % X3_RING][1] = ldg4(hrow + kcs * kc + 8 + 4 * hi);
   }
@@ -278,9 +279,24 @@ struct X3RevSrc {
 // ---- sources of the backward sweeps (appendix A.3) ------------------------------------------------------------------
 // two f32x4 of a row covering this lane's 8 reduction indices of k-chunk kc; kcs = floats between consecutive k-chunks of the
 // row (16: point-major [M][256]; 512: blocked [M/32][16][32][16], mlp_common.h save_row_off)
+// Loads of the sweeps' sources: PLAIN (temporal), not non-temporal like the other saved-tensor accesses (common.h: ldg4).  A lane reads its
+// point's 64-byte record of a k-chunk with TWO instructions (bytes [0, 32) and [32, 64) of the record: the MFMA D layout), so every 128-byte line
+// is touched by two instructions a few cycles apart; a non-temporal load does not keep the line for the second one.  scripts/ubench/hbm_mix.hip
+// (profiles/r5_hbm_mix.txt), pure access pattern of sweep 2 (3 tensors read, 1 written): 396 us per range with non-temporal loads, 340 us
+// with plain ones; the kernels: i2sdf_sdf_backward 1.61 -> 1.46 ms.  (Stores stay non-temporal: no difference once the loads are plain.)
+#ifndef X3_SWEEP_LD_PLAIN
+#define X3_SWEEP_LD_PLAIN 1
+#endif
+__device__ __forceinline__ f32x4 x3_ldg4(const float* p) {
+#if X3_SWEEP_LD_PLAIN
+  return *reinterpret_cast<const f32x4*>(p);
+#else
+  return ldg4(p);
+#endif
+}
 __device__ __forceinline__ void x3_load8(const float* row, int kc, int hi, f32x4 (&q)[2], int kcs = 16) {
-  q[0] = ldg4(row + kcs * kc + 4 * hi);
-  q[1] = ldg4(row + kcs * kc + 8 + 4 * hi);
+  q[0] = x3_ldg4(row + kcs * kc + 4 * hi);
+  q[1] = x3_ldg4(row + kcs * kc + 8 + 4 * hi);
 }
 __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const float (&v)[8], int kcs = 16) {
   stg4(row + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
