@@ -12,6 +12,15 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 
 namespace {
 
+// The weight-gradient kernels stream their operands once (no line is touched twice: wgrad3p's lane quads read whole 64-byte records, both
+// points of a 128-byte line in one instruction): NON-TEMPORAL loads, which leave the packed weight streams of the concurrently running
+// sweeps in L2.  Round 5, A/B in one GPU call: i2sdf_weight_grads 1.04 -> 0.99-1.00 ms (profiles/r5_hbm_mix.txt; pure pattern: 6.7 vs 6.1 TB/s).
+#ifndef WGN_AUX
+#define WGN_AUX 2      // cache policy of the narrow split kernel's buffer loads (2 = nt, 0 = plain)
+#endif
+#ifndef W3_NT_LD
+#define W3_NT_LD 1
+#endif
 constexpr int WG_CH = I2SDF_WG_CH;   // points per split-M chunk (plan.h; plan.cpp: PART_ALIGN -- point ranges are cut at chunk boundaries)
 constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
@@ -220,17 +229,17 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
       const unsigned sa = stage_off(s, ablk, job.lda), sb = stage_off(s, bblk, job.ldb);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        if (AM) A[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aoff[q], sa, 0));
+        if (AM) A[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aoff[q], sa, WGN_AUX));
         else {
-          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], sa, 0));
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], sa, WGN_AUX));
 #pragma unroll
           for (int ta = 0; ta < TA; ++ta) A[q][ta] = x[ta];
         }
         if (BM) {
 #pragma unroll
-          for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, boff[q][tb < NBV ? tb : 0], sb, 0));
+          for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, boff[q][tb < NBV ? tb : 0], sb, WGN_AUX));
         } else {
-          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, boff[q][0], sb, 0));
+          const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, boff[q][0], sb, WGN_AUX));
 #pragma unroll
           for (int tb = 0; tb < TB; ++tb) Bv[q][tb] = x[tb];
         }
@@ -635,8 +644,13 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches ahead without a branch)
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
+#if W3_NT_LD
+      if (half == 0) rlo[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+      else rhi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + vnext));
+#else
       if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
       else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
+#endif
     };
     unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
