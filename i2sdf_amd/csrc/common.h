@@ -143,6 +143,24 @@ struct WStreamT {
     __syncthreads();
     return lds + cur * STG;
   }
+  // Counted form: only what is OLDER than this stage's last DMA piece has to be complete -- `young` = number of vector-memory instructions that
+  // the wave has issued since that piece UNCONDITIONALLY (a compile-time value after unrolling; vmcnt retires in order on gfx9, so vmcnt(young)
+  // implies that the pieces have landed; a smaller `young` than the truth only waits longer).  The source loads issued ahead of their use
+  // (x3.h) then fly across the stage barrier instead of being drained at it.  scripts/ubench/mfma_paced.hip (profiles/r5_mfma_paced.txt).
+  template <int N> static __device__ __forceinline__ void wait_barrier() {
+    // one asm statement with a memory clobber: no LDS read of the new stage moves above it (__syncthreads() would add its own vmcnt(0))
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  }
+  __device__ __forceinline__ const float* advance_barrier_young(int young) {
+    switch (young < 0 ? 0 : young > 16 ? 16 : young) {
+      case 0: wait_barrier<0>(); break; case 1: wait_barrier<1>(); break; case 2: wait_barrier<2>(); break; case 3: wait_barrier<3>(); break;
+      case 4: wait_barrier<4>(); break; case 5: wait_barrier<5>(); break; case 6: wait_barrier<6>(); break; case 7: wait_barrier<7>(); break;
+      case 8: wait_barrier<8>(); break; case 9: wait_barrier<9>(); break; case 10: wait_barrier<10>(); break; case 11: wait_barrier<11>(); break;
+      case 12: wait_barrier<12>(); break; case 13: wait_barrier<13>(); break; case 14: wait_barrier<14>(); break; case 15: wait_barrier<15>(); break;
+      default: wait_barrier<16>(); break;
+    }
+    return lds + cur * STG;
+  }
   __device__ __forceinline__ void advance_issue(int tid) {
     if (left > 0) { issue(lds + (cur ^ 1) * STG, tid); --left; }
     cur ^= 1;

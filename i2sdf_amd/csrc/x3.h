@@ -30,6 +30,9 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // measured: a distance of 1 is enough (2 spills, 3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
 // STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
 constexpr int X3_AHEAD = 1, X3_RING = 2;
+#ifndef X3_COUNTED_WAIT
+#define X3_COUNTED_WAIT 1
+#endif
 __host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -76,7 +79,7 @@ __device__ __forceinline__ void x3_select_pe(const float (&full)[NC16 * 16], flo
 //   Src   : where the B operand comes from.  `float value(kc, u)` returns value u (0..7) of k-chunk kc for this lane --
 //           reduction index 16*kc + (u&3) + 8*(u>>2) + 4*hi -- and `void done(kc, v)` is called once all eight are known
 //           (global stores of the saved tensors).  Both are dealt into the MFMA shadows one k-chunk ahead of their use;
-//           `void ahead(kc)` is called two k-chunks ahead (issue global loads there).
+//           `int ahead(kc)` is called X3_AHEAD k-chunks ahead (issue global loads there; returns how many it issued unconditionally).
 // ---------------------------------------------------------------------------------------------
 template <int NT, int KC16, int BIAS, class Src>
 __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io)[NT], int tid) {
@@ -101,13 +104,14 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   float sv[2][8], sx[2][8];
   u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
+  int vm_young = 0;                     // unconditional source-load instructions since the last DMA piece (compile-time after unrolling)
   auto flush = [&]() __attribute__((always_inline)) {
     if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
     if (pk1 >= 0) { src.done(pk1, sv[1], sx[1]); pk1 = -1; }
   };
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
-    if (u == 0 && kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
+    if (u == 0 && kc + X3_AHEAD < KC16) vm_young += src.ahead(kc + X3_AHEAD);
     if (u < 8) v[u] = src.value(kc, u, vx[u]);
     else {
       if (u == 8 && Src::STORES) {
@@ -130,7 +134,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   };
 #pragma unroll
   for (int k0 = 0; k0 < X3_AHEAD; ++k0)
-    if (k0 < KC16) src.ahead(k0);
+    if (k0 < KC16) (void)src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
   // pairs [p0, p1) of stage s are weight chunks (the rest: bias chunks in front, padding behind) -- compile-time after unrolling
@@ -143,7 +147,12 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     // every stage barrier drains vmcnt(0): the DMA pieces must have landed, and hipcc cannot be trusted to wait for them by itself
     // (common.h: WStream::advance).  Counted waits that let operand loads fly across the barrier and an early barrier that hides the
     // first LDS reads of a stage were built in round 3 and measured inside the noise; round 4 removed them (git history).
+#if X3_COUNTED_WAIT
+    // the first stage of an op was fetched by the previous op (or begin()): full drain there
+    const u32x4* cur = reinterpret_cast<const u32x4*>(s == 0 ? ws.advance_barrier() : ws.advance_barrier_young(vm_young)) + lane;
+#else
     const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+#endif
     flush();
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
@@ -188,7 +197,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           if (npiece < WStream::NPIECE) {       // next stage's DMA: 2 pieces per group, from the first group on
-            ws.issue_piece(npiece, tid); ++npiece;
+            ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
           }
         {
           const int pi = w % PPK;
@@ -201,7 +210,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     }
 #pragma unroll
     for (int i = 0; i < WStream::NPIECE; ++i)
-      if (i >= npiece) ws.issue_piece(i, tid);
+      if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
     ws.advance_done();
   }
   flush();
@@ -215,10 +224,10 @@ __device__ __forceinline__ void x3_drain(Src& src) {
   float v[8], vx[8];
 #pragma unroll
   for (int k0 = 0; k0 < X3_AHEAD; ++k0)
-    if (k0 < KC16) src.ahead(k0);
+    if (k0 < KC16) (void)src.ahead(k0);
 #pragma unroll
   for (int kc = 0; kc < KC16; ++kc) {
-    if (kc + X3_AHEAD < KC16) src.ahead(kc + X3_AHEAD);
+    if (kc + X3_AHEAD < KC16) (void)src.ahead(kc + X3_AHEAD);
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u, vx[u]);
     src.done(kc, v, vx);
@@ -232,7 +241,7 @@ template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
-  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc < KACC) return softplus100(accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u]);
     return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
@@ -249,7 +258,7 @@ template <int NREG>
 struct X3RegSrc {
   static constexpr bool STORES = false;
   const float (&r)[NREG];
-  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
 };
@@ -259,10 +268,12 @@ struct X3RevSrc {
   static constexpr bool STORES = true;
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) {
+  // ahead(): returns the number of vector-memory instructions it issues unconditionally (dense_x3g's counted stage wait)
+  __device__ __forceinline__ int ahead(int kc) {
     // (non-temporal: plain loads as in the sweeps measured no change for this kernel -- it is not bound by its loads; profiles/r5_hbm_mix.txt)
     hq[kc % X3_RING][0] = ldg4(hrow + kcs * kc + 4 * hi);
     hq[kc % X3_RING][1] = ldg4(hrow + kcs * kc + 8 + 4 * hi);
+    return 2;
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
@@ -313,8 +324,9 @@ struct X3Sweep1Src {
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) {
+  __device__ __forceinline__ int ahead(int kc) {
     if (kc < KACC) x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs);
+    return kc < KACC ? 2 : 0;
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
@@ -335,12 +347,13 @@ struct X3Sweep2Src {
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
   f32x4 hq[X3_RING][2], gq[X3_RING][2], aq[X3_RING][2], wq[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) {
+  __device__ __forceinline__ int ahead(int kc) {
     x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(gurow, kc, hi, gq[kc % X3_RING], kcs); x3_load8(arow, kc, hi, aq[kc % X3_RING], kcs);
     if (TOP) {
       wq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
       wq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
     }
+    return TOP ? 8 : 6;
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     float x = accP[kc >> 1][8 * (kc & 1) + u];
@@ -359,9 +372,10 @@ struct X3RowSrc {
   static constexpr bool STORES = false;
   const float* row; int hi; bool on;
   f32x4 q[X3_RING][2];
-  __device__ __forceinline__ void ahead(int kc) {
+  __device__ __forceinline__ int ahead(int kc) {
     if (on) x3_load8(row, kc, hi, q[kc % X3_RING]);
     else { q[kc % X3_RING][0] = f32x4{0.f, 0.f, 0.f, 0.f}; q[kc % X3_RING][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    return 0;      // conditional on a run-time flag: not counted
   }
   __device__ __forceinline__ float value(int kc, int u, float&) { return q[kc % X3_RING][u >> 2][u & 3]; }
   __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}

@@ -98,9 +98,10 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
   // do.  Pieces 24..31 split the 4 value pairs, two halves each (leading plane + residuals; the two lower planes).
   constexpr int NU = 32;
   float ra[4], rb[4], t1[2], t2[2];
+  int vm_young = 0;      // unconditional source-load instructions since the last DMA piece (x3.h: the counted stage wait)
   auto prep = [&](int kc, int j, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC32) return;
-    if (j == 0 && kc + XH_AHEAD < KC32) src.ahead(kc + XH_AHEAD);
+    if (j == 0 && kc + XH_AHEAD < KC32) vm_young += src.ahead(kc + XH_AHEAD);
     if (j < 24) {
       // slot s = 0..9 holds [p3(s-2)] [p2(s-1)] [p1(s)]; the 24 valid pieces in that order
       int s_ = 0, ph = 0, n = 0;
@@ -131,7 +132,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
   };
 #pragma unroll
   for (int k0 = 0; k0 < XH_AHEAD; ++k0)
-    if (k0 < KC32) src.ahead(k0);
+    if (k0 < KC32) (void)src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < NU; ++u) prep(0, u, bq[0]);
   auto first_pair = [](int s) { return (s * SCH < NB) ? ((NB - s * SCH < SCH) ? (NB - s * SCH) / 2 : SCH / 2) : 0; };
@@ -140,7 +141,11 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int p0 = first_pair(s), p1 = end_pair(s);
+#if X3_COUNTED_WAIT
+    const u32x4* cur = reinterpret_cast<const u32x4*>(s == 0 ? ws.advance_barrier() : ws.advance_barrier_young(vm_young)) + lane;
+#else
     const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
+#endif
 #pragma unroll
     for (int j = 0; j < SCH; ++j) {
       const int c = s * SCH + j;
@@ -181,7 +186,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
         if (sp < 2) acc[nt] = mfma_bf16h(a0, b[1], acc[nt]);
         else acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
         if (npiece < WS::NPIECE) {          // next stage's DMA: one piece per group, from the first group on
-          ws.issue_piece(npiece, tid); ++npiece;
+          ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
         }
         gap(2);
         __builtin_amdgcn_sched_barrier(0);
@@ -193,7 +198,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
     }
 #pragma unroll
     for (int i = 0; i < WS::NPIECE; ++i)
-      if (i >= npiece) ws.issue_piece(i, tid);
+      if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
     ws.advance_done();
   }
 #pragma unroll
@@ -253,7 +258,7 @@ template <int NT, int KACC, int NPE, bool ST = true>
 struct XhFwdSrc {
   static constexpr bool STORES = ST;
   const f32x4 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int kg; bool valid; int kcs = 16;
-  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ int ahead(int) { return 0; }
   // softplus100 in three phases (common.h: softplus100): z = exp2(-|a| c) | l = log2(1 + z) | h = l k + max(a, 0)
   __device__ __forceinline__ float pre(int kc, int u) const { return accP[(2 * kc + (u >> 2)) < NT ? (2 * kc + (u >> 2)) : 0][u & 3]; }
   __device__ __forceinline__ float p1(int kc, int u) {
@@ -273,7 +278,7 @@ template <int NREG>
 struct XhRegSrc {
   static constexpr bool STORES = false;
   const float (&r)[NREG];
-  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return r[8 * kc + u]; }
@@ -286,7 +291,7 @@ template <int NT>
 struct XhReluSrc {
   static constexpr bool STORES = true;
   const f32x4 (&accP)[NT]; float* rrow; int kg; bool valid; int kcs = 16;
-  __device__ __forceinline__ void ahead(int) {}
+  __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return relu0(accP[2 * kc + (u >> 2)][u & 3]); }
@@ -300,7 +305,7 @@ struct XhPeRowSrc {
   static constexpr bool STORES = false;
   const float (&pe)[NPV * 8]; const float* row; int kg;
   f32x4 q[XH_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { if (kc >= NPV) x3h_load8(row, kc - NPV, kg, q[kc % XH_RING], 16); }
+  __device__ __forceinline__ int ahead(int kc) { if (kc >= NPV) x3h_load8(row, kc - NPV, kg, q[kc % XH_RING], 16); return kc >= NPV ? 2 : 0; }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc % XH_RING][u >> 2][u & 3]; }
@@ -312,7 +317,7 @@ struct XhRowSrc {
   static constexpr bool STORES = false;
   const float* row; int kg;
   f32x4 q[XH_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { x3h_load8(row, kc, kg, q[kc % XH_RING], 16); }
+  __device__ __forceinline__ int ahead(int kc) { x3h_load8(row, kc, kg, q[kc % XH_RING], 16); return 2; }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) {
@@ -327,7 +332,7 @@ struct XhMaskSrc {
   static constexpr bool STORES = true;
   const f32x4 (&accP)[NT]; const float* rrow; float* grow; int kg; bool valid; int kcs = 16;
   f32x4 q[XH_RING][2];
-  __device__ __forceinline__ void ahead(int kc) { x3h_load8(rrow, kc, kg, q[kc % XH_RING], kcs); }
+  __device__ __forceinline__ int ahead(int kc) { x3h_load8(rrow, kc, kg, q[kc % XH_RING], kcs); return 2; }
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc % XH_RING][u >> 2][u & 3] > 0.f ? accP[2 * kc + (u >> 2)][u & 3] : 0.f; }
