@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__
 
 // d sdf/dx chain of the bf16x3 path as its own launch (appendix A.2): the forward kernel above and this one each fit the
 // register file without spills; h_{L-1} is re-read from the tensor the forward saved.
-template <int H, int LF>
+// SV: a.abars is given (a backward will follow) -> its stores are unconditional instructions, counted by the stage waits (x3.h)
+template <int H, int LF, bool SV>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf_igrad3_kernel(SdfTrainFwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   for (int l = a.L - 3; l >= 1; --l) {
     const float* hrow = a.hs + l * lstride + mcrow;
-    X3RevSrc<NT> src{accA, hrow, a.abars ? a.abars + l * lstride + mrow : nullptr, hi, valid, kcs};
+    X3RevSrc<NT, SV> src{accA, hrow, (SV || a.abars) ? a.abars + l * lstride + mrow : nullptr, hi, valid, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3RevSrc<NT> src{accA, a.hs + mcrow, a.abars ? a.abars + mrow : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
+    X3RevSrc<NT, SV> src{accA, a.hs + mcrow, (SV || a.abars) ? a.abars + mrow : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
     dense_x3g<PT, KH16, 0>(ws, src, pt, tid);       // pbar += W_0^T abar_0
   }
   {
@@ -244,7 +245,10 @@ void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int 
   (void)H;
   launch_lds(sdf_fwd3_kernel<64, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
-void i2sdf_launch_igrad3(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(sdf_igrad3_kernel<256, 6>, grid, st, a); }
+void i2sdf_launch_igrad3(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) {
+  if (a.abars) launch_lds(sdf_igrad3_kernel<256, 6, true>, grid, st, a);
+  else launch_lds(sdf_igrad3_kernel<256, 6, false>, grid, st, a);
+}
 void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
   launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
   launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);

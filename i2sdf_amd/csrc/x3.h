@@ -33,6 +33,11 @@ constexpr int X3_AHEAD = 1, X3_RING = 2;
 #ifndef X3_COUNTED_WAIT
 #define X3_COUNTED_WAIT 1
 #endif
+// sources whose saved-tensor stores are UNCONDITIONAL instructions (Src::COUNTED: rows of padding points are written too -- every per-point
+// workspace has Mp >= M rows, include/i2sdf.h) are counted as well and issued behind the stage's DMA pieces: they then cross one more barrier
+#ifndef X3_COUNT_STORES
+#define X3_COUNT_STORES 1
+#endif
 __host__ __device__ constexpr int x3_op_chunks(int NT, int KC16) { return round_up(NT * 4 + KC16 * NT * 3, SC); }
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
@@ -77,7 +82,7 @@ __device__ __forceinline__ void x3_select_pe(const float (&full)[NC16 * 16], flo
 //           and acc starts at zero (backward sweeps over the forward stream); 0 = weight chunks only, acc is used as the
 //           caller left it (zeroed, or holding a running sum such as pbar).
 //   Src   : where the B operand comes from.  `float value(kc, u)` returns value u (0..7) of k-chunk kc for this lane --
-//           reduction index 16*kc + (u&3) + 8*(u>>2) + 4*hi -- and `void done(kc, v)` is called once all eight are known
+//           reduction index 16*kc + (u&3) + 8*(u>>2) + 4*hi -- and `int done(kc, v)` is called once all eight are known
 //           (global stores of the saved tensors).  Both are dealt into the MFMA shadows one k-chunk ahead of their use;
 //           `int ahead(kc)` is called X3_AHEAD k-chunks ahead (issue global loads there; returns how many it issued unconditionally).
 // ---------------------------------------------------------------------------------------------
@@ -104,10 +109,11 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   float sv[2][8], sx[2][8];
   u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
-  int vm_young = 0;                     // unconditional source-load instructions since the last DMA piece (compile-time after unrolling)
+  int vm_young = 0;                     // unconditional vector-memory instructions since the last DMA piece (compile-time after unrolling)
+  constexpr bool LATE = X3_COUNTED_WAIT && X3_COUNT_STORES && Src::COUNTED;      // stores behind the stage's DMA pieces, counted
   auto flush = [&]() __attribute__((always_inline)) {
-    if (pk0 >= 0) { src.done(pk0, sv[0], sx[0]); pk0 = -1; }
-    if (pk1 >= 0) { src.done(pk1, sv[1], sx[1]); pk1 = -1; }
+    if (pk0 >= 0) { vm_young += src.done(pk0, sv[0], sx[0]); pk0 = -1; }
+    if (pk1 >= 0) { vm_young += src.done(pk1, sv[1], sx[1]); pk1 = -1; }
   };
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
@@ -153,7 +159,8 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #else
     const u32x4* cur = reinterpret_cast<const u32x4*>(ws.advance_barrier()) + lane;
 #endif
-    flush();
+    if (!LATE) flush();
+    bool flushed = false;
 #pragma unroll
     for (int j = 0; j < SC; ++j) {
       const int c = s * SC + j;
@@ -199,6 +206,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
           if (npiece < WStream::NPIECE) {       // next stage's DMA: 2 pieces per group, from the first group on
             ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
           }
+        if (LATE && !flushed && npiece == WStream::NPIECE) { flush(); flushed = true; }
         {
           const int pi = w % PPK;
 #pragma unroll
@@ -211,6 +219,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #pragma unroll
     for (int i = 0; i < WStream::NPIECE; ++i)
       if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
+    if (LATE && !flushed) flush();
     ws.advance_done();
   }
   flush();
@@ -230,7 +239,7 @@ __device__ __forceinline__ void x3_drain(Src& src) {
     if (kc + X3_AHEAD < KC16) (void)src.ahead(kc + X3_AHEAD);
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u, vx[u]);
-    src.done(kc, v, vx);
+    (void)src.done(kc, v, vx);
   }
 }
 
@@ -240,32 +249,37 @@ __device__ __forceinline__ void x3_drain(Src& src) {
 template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
+  static constexpr bool COUNTED = false;
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc < KACC) return softplus100(accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u]);
     return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
     if (kc < KACC && hrow != nullptr && valid) {
       stg4(hrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
       stg4(hrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
     }
+    return 0;
   }
 };
 // values held in registers in the fp32 kernels' B layout (register 4*c + t <-> index 8*c + 4*hi + t)
 template <int NREG>
 struct X3RegSrc {
   static constexpr bool STORES = false;
+  static constexpr bool COUNTED = false;
   const float (&r)[NREG];
   __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+  __device__ __forceinline__ int done(int, const float (&)[8], const float (&)[8]) { return 0; }
 };
 // reverse chain: abar = (previous op's accumulators) * sigma(h) with h re-read from the saved tensor; stores abar
-template <int NT>
+// UNC: abrow is known to be a row of an (Mp, 256) tensor -> unconditional, counted stores (the training forward; eval renders pass no abars)
+template <int NT, bool UNC = false>
 struct X3RevSrc {
   static constexpr bool STORES = true;
+  static constexpr bool COUNTED = UNC;
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   // ahead(): returns the number of vector-memory instructions it issues unconditionally (dense_x3g's counted stage wait)
@@ -278,11 +292,12 @@ struct X3RevSrc {
   __device__ __forceinline__ float value(int kc, int u, float&) {
     return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (abrow != nullptr && valid) {
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (UNC || (abrow != nullptr && valid)) {
       stg4(abrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
       stg4(abrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
     }
+    return UNC ? 2 : 0;
   }
 };
 
@@ -321,6 +336,7 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
 template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
+  static constexpr bool COUNTED = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; float* gurow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
@@ -333,8 +349,9 @@ struct X3Sweep1Src {
     const float ga = accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u];
     return ga * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (kc < KACC && valid) x3_store8(gurow, kc, hi, v, kcs);
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
+    if (kc < KACC) x3_store8(gurow, kc, hi, v, kcs);
+    return kc < KACC ? 2 : 0;
   }
 };
 // sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored to grow]
@@ -343,6 +360,7 @@ struct X3Sweep1Src {
 template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
+  static constexpr bool COUNTED = true;
   const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi; bool valid;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
@@ -363,13 +381,15 @@ struct X3Sweep2Src {
     const float g2 = ga * aq[kc % X3_RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
     return fmaf(x, sg, g2);
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3_store8(grow, kc, hi, v, kcs);
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
+    x3_store8(grow, kc, hi, v, kcs);
+    return 2;
   }
 };
 // a point-major row in global memory (or zeros) as B operand
 struct X3RowSrc {
   static constexpr bool STORES = false;
+  static constexpr bool COUNTED = false;
   const float* row; int hi; bool on;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ int ahead(int kc) {
@@ -378,7 +398,7 @@ struct X3RowSrc {
     return 0;      // conditional on a run-time flag: not counted
   }
   __device__ __forceinline__ float value(int kc, int u, float&) { return q[kc % X3_RING][u >> 2][u & 3]; }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+  __device__ __forceinline__ int done(int, const float (&)[8], const float (&)[8]) { return 0; }
 };
 
 }  // namespace i2sdf

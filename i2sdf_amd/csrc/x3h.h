@@ -98,7 +98,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
   // do.  Pieces 24..31 split the 4 value pairs, two halves each (leading plane + residuals; the two lower planes).
   constexpr int NU = 32;
   float ra[4], rb[4], t1[2], t2[2];
-  int vm_young = 0;      // unconditional source-load instructions since the last DMA piece (x3.h: the counted stage wait)
+  int vm_young = 0;      // unconditional vector-memory instructions since the last DMA piece (x3.h: the counted stage wait)
   auto prep = [&](int kc, int j, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC32) return;
     if (j == 0 && kc + XH_AHEAD < KC32) vm_young += src.ahead(kc + XH_AHEAD);
@@ -117,7 +117,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
       else if (ph == 1) t2[u & 1] = src.p2(kc, u, t1[u & 1]);
       else t1[u & 1] = src.p1(kc, u);
     } else {
-      if (j == 24 && Src::STORES) src.done(kc, v, vx);      // (issuing them behind the next stage barrier instead -- the 32-point kernels' stash -- measured no gain here)
+      if (j == 24 && Src::STORES) vm_young += src.done(kc, v, vx);      // (issuing them behind the next stage barrier instead -- the 32-point kernels' stash -- measured no gain here)
       const int i = (j - 24) >> 1;
       if (((j - 24) & 1) == 0) {
         const unsigned p0 = pk_bf16(v[2 * i], v[2 * i + 1]);
@@ -254,7 +254,8 @@ __device__ __forceinline__ void x3h_store8(float* row, int c, int kg, const floa
 
 // B-operand sources (the twins of x3.h's) ---------------------------------------------------------------------------------
 // softplus100 of the previous layer's pre-activations for k-chunks < KACC, this lane's PE values beyond; stores h
-template <int NT, int KACC, int NPE, bool ST = true>
+// UNC: hrow is known to be a row of an (Mp, 256) tensor -> unconditional, counted stores (x3.h: X3_COUNT_STORES)
+template <int NT, int KACC, int NPE, bool ST = true, bool UNC = false>
 struct XhFwdSrc {
   static constexpr bool STORES = ST;
   const f32x4 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int kg; bool valid; int kcs = 16;
@@ -269,8 +270,9 @@ struct XhFwdSrc {
     if (kc < KACC) return fmaf(l, 0.693147180559945309f * 0.01f, relu0(pre(kc, u)));
     return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
   }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (kc < KACC && hrow != nullptr && valid) x3h_store8(hrow, kc, kg, v, kcs);
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (kc < KACC && (UNC || (hrow != nullptr && valid))) x3h_store8(hrow, kc, kg, v, kcs);
+    return (X3_COUNT_STORES && UNC && kc < KACC) ? 2 : 0;
   }
 };
 // values held in registers in D layout order (register 4*nt + r <-> feature 16*nt + 4*kg + r; k-chunk c = registers 8c .. 8c+7)
@@ -282,12 +284,12 @@ struct XhRegSrc {
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return r[8 * kc + u]; }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+  __device__ __forceinline__ int done(int, const float (&)[8], const float (&)[8]) { return 0; }
 };
 
 // ---- radiance net ----------------------------------------------------------------------------------------------------
 // ReLU of the previous layer's pre-activations; stores the activations r (saved tensor)
-template <int NT>
+template <int NT, bool UNC = false>
 struct XhReluSrc {
   static constexpr bool STORES = true;
   const f32x4 (&accP)[NT]; float* rrow; int kg; bool valid; int kcs = 16;
@@ -295,8 +297,9 @@ struct XhReluSrc {
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return relu0(accP[2 * kc + (u >> 2)][u & 3]); }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (rrow != nullptr && valid) x3h_store8(rrow, kc, kg, v, kcs);
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
+    if (UNC || (rrow != nullptr && valid)) x3h_store8(rrow, kc, kg, v, kcs);
+    return (X3_COUNT_STORES && UNC) ? 2 : 0;
   }
 };
 // layer-0 input of the radiance net: NPV k-chunks of PE(view dir) held in registers, then the feature row from global memory
@@ -309,7 +312,7 @@ struct XhPeRowSrc {
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return kc < NPV ? pe[8 * (kc < NPV ? kc : 0) + u] : q[kc % XH_RING][u >> 2][u & 3]; }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+  __device__ __forceinline__ int done(int, const float (&)[8], const float (&)[8]) { return 0; }
 };
 // a point-major row in global memory as B operand, optionally through ReLU (the light-mask head's input: relu(feature))
 template <bool RELU>
@@ -324,7 +327,7 @@ struct XhRowSrc {
     const float x = q[kc % XH_RING][u >> 2][u & 3];
     return RELU ? relu0(x) : x;
   }
-  __device__ __forceinline__ void done(int, const float (&)[8], const float (&)[8]) {}
+  __device__ __forceinline__ int done(int, const float (&)[8], const float (&)[8]) { return 0; }
 };
 // radiance backward: G(a_l) = (previous op's accumulators) where the saved activation r is positive; stores G(a_l)
 template <int NT>
@@ -336,8 +339,9 @@ struct XhMaskSrc {
   __device__ __forceinline__ float p1(int, int) { return 0.f; }
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return q[kc % XH_RING][u >> 2][u & 3] > 0.f ? accP[2 * kc + (u >> 2)][u & 3] : 0.f; }
-  __device__ __forceinline__ void done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (valid) x3h_store8(grow, kc, kg, v, kcs);
+  __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
+    x3h_store8(grow, kc, kg, v, kcs);
+    return X3_COUNT_STORES ? 2 : 0;
   }
 };
 

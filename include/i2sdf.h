@@ -172,7 +172,8 @@ int i2sdf_sdf_forward(const i2sdf_plan* plan, const float* packed, const float* 
  *     [ n_ray_pts points generated from rays | (M - n_ray_pts) explicit points ]
  * ray part:  x[m] = cam[r] + z[r*ldz + j]*dirs[r], r = m / n_per_ray, j = m % n_per_ray (model/network/__init__.py:103)
  * explicit:  x[m] = points[m - n_ray_pts]        (eikonal / neighbour / bubble points, :178-201)
- * Every per-point workspace below has Mp rows (Mp multiple of 128, >= M); rows >= M are never read.
+ * Every per-point workspace below has Mp rows (Mp multiple of 128, >= M); rows >= M are never read (kernels may WRITE them: the saved
+ * tensors' stores of padding points are unconditional instructions, which lets the stage waits count them -- csrc/x3.h).
  *
  * SDF network forward WITH d sdf/dx and saved activations -- ImplicitNetwork.get_outputs / .gradient
  * (mlp.py:107-143) as called by the main render pass (model/network/__init__.py:113) and the eikonal pass
