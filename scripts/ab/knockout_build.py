@@ -39,9 +39,8 @@ PATCHES = {
     "sweeps_no_wgrad_stores": [
         # (measured on the round-4 sweeps, where sweep 1 also wrote G2; since round 5 it writes G(hbar) only and sweep 2 READS it, so this
         # knock-out now also feeds sweep 2 garbage -- timing only, as ever)
-        ("x3.h", "    if (kc < KACC && valid) x3_store8(gurow, kc, hi, v, kcs);\n", "    (void)v;\n"),
-        ("x3.h", "    if (valid) x3_store8(grow, kc, hi, v, kcs);\n  }\n};\n// a point-major row in global memory (or zeros) as B operand",
-         "    (void)kc; (void)v;\n  }\n};\n// a point-major row in global memory (or zeros) as B operand"),
+        ("x3.h", "    if (kc < KACC) x3_store8(gurow, kc, hi, v, kcs);\n", "    (void)v;\n"),
+        ("x3.h", "    x3_store8(grow, kc, hi, v, kcs);\n    return 2;\n", "    (void)kc; (void)v;\n    return 2;\n"),
     ],
     # ... and the 256x256 weight-gradient kernel without its operand loads (pure split + MFMA + partial-sum flush)
     "wgrad3p_no_loads": [
