@@ -73,8 +73,9 @@ __device__ __forceinline__ void store_pe_row_h(float* __restrict__ row, int kg, 
 }
 
 // SDF forward with saves: hidden activations -> hs, sdf, feature rows (the d sdf/dx chain is sdf_igrad3_kernel, mlp_x3.hip)
-// SV: a.hs is given (every caller but a plain forward) -> its stores are unconditional instructions, counted by the stage waits (x3.h)
-template <int H, int F, int LF, int NW, bool SV>
+// (its saved-tensor stores stay predicated and uncounted by the stage waits, x3.h: as unconditional instructions they cost 8 more registers
+// at the 256-register cap of a two-waves-per-SIMD kernel -- 132 B of scratch, 310 -> 336 us per launch, profiles/r5_mfma_paced.txt)
+template <int H, int F, int LF, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwdArgs a) {
   constexpr int NT = H / 16, KH32 = H / 32, PEC = PE<LF>::PEC, PE32 = cdiv(PE<LF>::DIM, 32), NPE = PE32 * 8, FT = F / 16;
   static_assert(NT == FT, "feature tiles reuse the hidden accumulator set");
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwd
     dense_x3h<NT, PE32, 1, NW>(ws, src, accA, tid);
   }
   for (int l = 1; l < a.L - 1; ++l) {
-    float* hrow = (SV || a.hs) ? a.hs + (l - 1) * lstride + mrow : nullptr;
-    XhFwdSrc<NT, KH32, NPE, true, SV> src{accA, pe, hrow, kg, valid, kcs};
+    float* hrow = a.hs ? a.hs + (l - 1) * lstride + mrow : nullptr;
+    XhFwdSrc<NT, KH32, NPE> src{accA, pe, hrow, kg, valid, kcs};
     if (l == a.skip) dense_x3h<NT, KH32 + PE32, 1, NW>(ws, src, accB, tid);
     else dense_x3h<NT, KH32, 1, NW>(ws, src, accB, tid);
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwd
 }
 
 // radiance net (RenderingNetwork, 'nerf' mode: mlp.py:208-229) forward and backward
-template <int H, int F, int LFV, int NW, bool SV>      // SV: a.rs is given (a backward will follow), as in sdf_train_fwd3h_kernel
+template <int H, int F, int LFV, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void rgb_fwd3h_kernel(RgbFwdArgs a) {
   constexpr int NT = H / 16, KH32 = H / 32, PECV = PE<LFV>::PEC, PV32 = cdiv(PE<LFV>::DIM, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, 2) void rgb_fwd3h_kernel(RgbFwdArgs a) {
     dense_x3h<NT, PV32 + F / 32, 1, NW>(ws, src, accA, tid);
   }
   for (int l = 1; l < a.L - 1; ++l) {
-    XhReluSrc<NT, SV> src{accA, (SV || a.rs) ? a.rs + (l - 1) * lstride + mrow : nullptr, kg, valid, kcs};
+    XhReluSrc<NT> src{accA, a.rs ? a.rs + (l - 1) * lstride + mrow : nullptr, kg, valid, kcs};
     dense_x3h<NT, KH32, 1, NW>(ws, src, accB, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
@@ -281,13 +282,7 @@ void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, 
                             hipStream_t st) {
   launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8>, (unsigned)((M + 8 * HP - 1) / (8 * HP)), st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
-void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) {
-  if (a.hs) launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8, true>, grid, st, a);
-  else launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8, false>, grid, st, a);
-}
-void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st) {
-  if (a.rs) launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8, true>, grid, st, a);
-  else launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8, false>, grid, st, a);
-}
+void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8>, grid, st, a); }
+void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8>, grid, st, a); }
 void i2sdf_launch_light_fwd3h(const LightFwd3hArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(8 * 64, light_fwd3h_kernel<128, 256, 8>, grid, st, a); }
 void i2sdf_launch_rgb_bwd3h(const RgbBwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_bwd3h_kernel<256, 256, 8>, grid, st, a); }

@@ -254,8 +254,7 @@ __device__ __forceinline__ void x3h_store8(float* row, int c, int kg, const floa
 
 // B-operand sources (the twins of x3.h's) ---------------------------------------------------------------------------------
 // softplus100 of the previous layer's pre-activations for k-chunks < KACC, this lane's PE values beyond; stores h
-// UNC: hrow is known to be a row of an (Mp, 256) tensor -> unconditional, counted stores (x3.h: X3_COUNT_STORES)
-template <int NT, int KACC, int NPE, bool ST = true, bool UNC = false>
+template <int NT, int KACC, int NPE, bool ST = true>
 struct XhFwdSrc {
   static constexpr bool STORES = ST;
   const f32x4 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int kg; bool valid; int kcs = 16;
@@ -271,8 +270,8 @@ struct XhFwdSrc {
     return pe[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (kc < KACC && (UNC || (hrow != nullptr && valid))) x3h_store8(hrow, kc, kg, v, kcs);
-    return (X3_COUNT_STORES && UNC && kc < KACC) ? 2 : 0;
+    if (kc < KACC && hrow != nullptr && valid) x3h_store8(hrow, kc, kg, v, kcs);
+    return 0;      // predicated: not counted (see sdf_train_fwd3h_kernel)
   }
 };
 // values held in registers in D layout order (register 4*nt + r <-> feature 16*nt + 4*kg + r; k-chunk c = registers 8c .. 8c+7)
@@ -289,7 +288,7 @@ struct XhRegSrc {
 
 // ---- radiance net ----------------------------------------------------------------------------------------------------
 // ReLU of the previous layer's pre-activations; stores the activations r (saved tensor)
-template <int NT, bool UNC = false>
+template <int NT>
 struct XhReluSrc {
   static constexpr bool STORES = true;
   const f32x4 (&accP)[NT]; float* rrow; int kg; bool valid; int kcs = 16;
@@ -298,8 +297,8 @@ struct XhReluSrc {
   __device__ __forceinline__ float p2(int, int, float) { return 0.f; }
   __device__ __forceinline__ float p3(int kc, int u, float, float, float&) { return relu0(accP[2 * kc + (u >> 2)][u & 3]); }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (UNC || (rrow != nullptr && valid)) x3h_store8(rrow, kc, kg, v, kcs);
-    return (X3_COUNT_STORES && UNC) ? 2 : 0;
+    if (rrow != nullptr && valid) x3h_store8(rrow, kc, kg, v, kcs);
+    return 0;
   }
 };
 // layer-0 input of the radiance net: NPV k-chunks of PE(view dir) held in registers, then the feature row from global memory
