@@ -1,4 +1,5 @@
-"""CPU (hipcc cross-compiles gfx950 without a GPU): the counted stage waits of the 32-point-wave bf16x3 kernels, checked on the ISA.
+"""CPU: the counted stage waits of the 32-point-wave bf16x3 kernels, checked on the ISA (disassembly of the in-tree build: seconds; without
+one, or with a stale one, hipcc compiles mlp_x3.hip -- it cross-compiles gfx950 without a GPU -- which takes two minutes).
 
 The K-outer ops (i2sdf_amd/csrc/x3.h: dense_x3g) hand every weight stage over with `s_waitcnt vmcnt(N); s_barrier`, N = the number of
 vector-memory instructions the wave has issued UNCONDITIONALLY since the stage's last DMA piece (common.h: WStreamT::advance_barrier_young).
@@ -22,17 +23,54 @@ CSRC = os.path.join(ROOT, "i2sdf_amd", "csrc")
 KERNELS = {"sdf_igrad3_kernel": 6, "sdf_bwd3_sweep1_kernel": 12, "sdf_bwd3_sweep2_kernel": 12}      # name -> minimum number of counted barriers
 
 
+LLVM = "/opt/rocm/lib/llvm/bin"
+OBJ = os.path.join(ROOT, "i2sdf_amd", "lib", "obj", "mlp_x3.o")
+
+
+def _disassemble_in_tree(tmp):
+    """The device code of the in-tree build (seconds); None if there is none or it is older than the sources."""
+    if not os.path.exists(OBJ) or not all(os.path.exists(f"{LLVM}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
+        return None
+    import glob
+    if any(os.path.getmtime(f) > os.path.getmtime(OBJ) for f in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, "mlp_x3.hip")]):
+        return None
+    fat, co = os.path.join(tmp, "x3.fatbin"), os.path.join(tmp, "x3.co")
+    if subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", OBJ], capture_output=True).returncode != 0:
+        return None
+    if subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}",
+                       "--unbundle"], capture_output=True).returncode != 0:
+        return None
+    dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True)
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True)
+    if dis.returncode != 0:
+        return None
+    # objdump form -> the assembler-listing form the checks below read: "<name>:" labels, one instruction per line, no addresses
+    lines = []
+    for ln in dis.stdout.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(_Z\w+)>:", ln)
+        if m:
+            lines.append(".Lfunc_end:"); lines.append(m.group(1) + ":")
+        elif ln.startswith("\t"):
+            lines.append(ln.split("//")[0].rstrip())
+    return "\n".join(lines) + "\n.Lfunc_end:\n" + notes.stdout
+
+
 @pytest.fixture(scope="module")
 def isa(tmp_path_factory):
+    """(text, from_objdump).  The in-tree object when it is there and fresh; else a compile of mlp_x3.hip (~2 minutes)."""
+    tmp = tmp_path_factory.mktemp("isa")
+    text = _disassemble_in_tree(str(tmp))
+    if text is not None:
+        return text, True
     if shutil.which("hipcc") is None:
-        pytest.skip("hipcc not on PATH")
-    out = tmp_path_factory.mktemp("isa") / "mlp_x3.s"
+        pytest.skip("no in-tree build and no hipcc")
+    out = tmp / "mlp_x3.s"
     # the flags of i2sdf_amd/csrc/build.sh for mlp_x3.hip
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-result",
            "-mllvm", "-pragma-unroll-threshold=1000000", "-x", "hip", "--cuda-device-only", "-S", os.path.join(CSRC, "mlp_x3.hip"), "-o", str(out)]
     r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
-    return open(out).read()
+    return open(out).read(), False
 
 
 def _bodies(text):
@@ -59,14 +97,15 @@ VMEM = re.compile(r"^(global_load|global_store|buffer_load|buffer_store|scratch_
 
 
 def test_stage_barriers_carry_counted_waits(isa):
-    bodies = _bodies(isa)
+    text, from_objdump = isa
+    bodies = _bodies(text)
     for key, min_counted in KERNELS.items():
         names = [n for n in bodies if key in n]
         assert names, f"{key} not found in the ISA"
         for name in names:
             body = bodies[name]
             counted, since_barrier, nbar, nasm, in_asm = 0, 0, 0, 0, False
-            last_wait = None
+            last_wait, prev_op_wait = None, None
             for ln in body:
                 if "#ASMSTART" in ln:
                     in_asm, last_wait = True, None
@@ -79,20 +118,22 @@ def test_stage_barriers_carry_counted_waits(isa):
                     continue
                 if VMEM.match(op):
                     since_barrier += 1
-                if in_asm:
-                    m = re.match(r"\s*s_waitcnt\s+vmcnt\((\d+)\)", ln)
-                    if m:
-                        last_wait = int(m.group(1))
+                m = re.match(r"\s*s_waitcnt\s+vmcnt\((\d+)\)\s*$", ln.split(";")[0])
+                if in_asm and m:
+                    last_wait = int(m.group(1))
                 if op == "s_barrier":
                     nbar += 1
-                    if in_asm:      # the counted form (common.h: wait_barrier<N>): one asm statement, the wait directly in front of the barrier
+                    # the counted form (common.h: wait_barrier<N>) is ONE asm statement: in a listing it sits between the ASM markers, in a
+                    # disassembly the wait (vmcnt only) is the instruction directly in front of the barrier
+                    n = last_wait if in_asm else (prev_op_wait if from_objdump else None)
+                    if n is not None:
                         nasm += 1
-                        assert last_wait is not None, f"{name}: barrier #{nbar}: asm statement without its s_waitcnt"
                         # whatever may still be in flight was issued after the previous barrier (everything older was drained or counted there)
-                        assert last_wait <= since_barrier, \
-                            f"{name}: barrier #{nbar} allows {last_wait} instructions in flight, only {since_barrier} were issued since the last barrier"
-                        counted += last_wait > 0
+                        assert n <= since_barrier, \
+                            f"{name}: barrier #{nbar} allows {n} instructions in flight, only {since_barrier} were issued since the last barrier"
+                        counted += n > 0
                     since_barrier = 0
+                prev_op_wait = int(m.group(1)) if m else None
             assert nbar >= 20 and nasm >= nbar // 2, (name, nbar, nasm)
             assert counted >= min_counted, f"{name}: only {counted} of {nbar} stage barriers carry a counted wait"
             # no jump table left from advance_barrier_young's switch
@@ -100,6 +141,7 @@ def test_stage_barriers_carry_counted_waits(isa):
 
 
 def test_no_scratch_in_the_counted_kernels(isa):
+    isa = isa[0]
     for key in KERNELS:
         for m in re.finditer(r"\.name:\s+(\S*%s\S*)\n(?:.*\n){0,12}?\s+\.private_segment_fixed_size:\s+(\d+)" % key, isa):
             assert int(m.group(2)) == 0, (m.group(1), m.group(2))
