@@ -27,8 +27,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // global loads of the B-operand sources are issued X3_AHEAD k-chunks before their use (ring of X3_RING register slots):
-// measured: a distance of 1 is enough (2 spills, 3 changes nothing); what stalls these ops is the vmcnt(0) drain of their own global
-// STORES at every stage barrier, hence the stash/flush scheme in dense_x3g
+// measured: a distance of 1 is enough (2 and 3 change nothing, on the kernels and on a model of them: scripts/ubench/mfma_paced.hip); what stalled
+// these ops was the full vmcnt(0) drain at every stage barrier -- of the loads just issued and of the stage's stores -- hence the counted stage
+// wait below and the stash / flush scheme of the stores in dense_x3g
 constexpr int X3_AHEAD = 1, X3_RING = 2;
 #ifndef X3_COUNTED_WAIT
 #define X3_COUNTED_WAIT 1
@@ -104,8 +105,9 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
   const int lane = tid & 63;
   float v[8], vx[8];
   u32x4 bq[2][3];
-  // Stores of the source (saved tensors) are not issued where their values become known but right after the next stage
-  // barrier: the barrier's vmcnt(0) drain (needed for the LDS DMA) would otherwise wait for stores issued moments before it.
+  // Stores of the source (saved tensors) are not issued where their values become known but stashed and flushed once per stage: right behind
+  // the stage's last DMA piece when the source's stores are unconditional instructions (LATE: they are then YOUNGER than the pieces and the
+  // counted wait of the next barrier lets them fly), else right after the next stage barrier (a full stage away from the drain they are part of).
   float sv[2][8], sx[2][8];
   u32x4 d0 = {0u, 0u, 0u, 0u}, d1 = {0u, 0u, 0u, 0u};      // the weights of the sp = 0 group, kept for the deferred W0*h2 pair
   int pk0 = -1, pk1 = -1;               // k-chunks whose stores are pending (compile-time after unrolling)
