@@ -255,7 +255,7 @@ class Workload:
 class _MockEngine:
     """what main() reads off the engine, for --selftest-launch"""
     n_z, parts, use_chain = 98, 0, True
-    sdf_forward_bf16x3 = train_forward_bf16x3 = sdf_backward_bf16x3 = wgrad_bf16x3 = wgrad_bf16x2 = rgb_bf16x3 = False
+    sdf_forward_bf16x3 = train_forward_bf16x3 = sdf_backward_bf16x3 = wgrad_bf16x3 = wgrad_bf16x2 = rgb_bf16x3 = sampler_bf16x2 = False
 
     def start_timing(self):
         pass
@@ -393,12 +393,27 @@ def main():
         extras["dense128"] = sub(d128, B, 128, f"{B} rays/GPU x 128 uniform shaded samples, sampler bypassed (BASELINE.json metric convention), same step otherwise")
         # the fp32-equivalent form of the ONE kernel family that runs narrower by default: the 256x256 weight-gradient blocks with three
         # bf16 planes per operand and six products instead of two and three (I2SDF_OPT_WGRAD_BF16X2 off); everything else unchanged
+        sx2 = bool(getattr(eng, "sampler_bf16x2", False))
         if eng.wgrad_bf16x3 and eng.wgrad_bf16x2:
             eng.set_wgrad_bf16x2(False)
+            if sx2:
+                eng.set_sampler_bf16x2(False)
             x3r = wl.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW)
             eng.set_wgrad_bf16x2(True)
-            extras["wgrad_bf16x3"] = sub(x3r, B, n_shaded, "the headline step with the weight-gradient GEMMs in bf16x3 too (I2SDF_OPT_WGRAD_BF16X2 off: three bf16 terms per "
-                                         "operand, six products): fp32-equivalent arithmetic in EVERY kernel of the step -- the round-3 headline convention")
+            if sx2:
+                eng.set_sampler_bf16x2(True)
+            extras["wgrad_bf16x3"] = sub(x3r, B, n_shaded, "the headline step with the weight-gradient GEMMs AND the sampler's sdf-only passes in bf16x3 too "
+                                         "(I2SDF_OPT_WGRAD_BF16X2 and I2SDF_OPT_SAMPLER_BF16X2 off: three bf16 terms per operand, six products): fp32-equivalent "
+                                         "arithmetic in EVERY kernel of the step -- the round-3 headline convention")
+        if sx2:
+            # the sampler's passes in the fp32-equivalent form, everything else as in the headline: what I2SDF_OPT_SAMPLER_BF16X2 buys (round 6)
+            eng.set_sampler_bf16x2(False)
+            s3 = {"k%d" % args.sampler_iters: sub(wl.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW), B, n_shaded, "headline step, sampler passes with three bf16 planes"),
+                  "natural_k": sub(wl.run(B, 1000 + rank, 0, K, W, windows=SW), B, n_shaded, "data-dependent sampler loop, sampler passes with three bf16 planes")}
+            if world == 1 and not mock:
+                s3["cfg4_image"] = full_image(wl, dev, n_shaded)
+            eng.set_sampler_bf16x2(True)
+            extras["sampler_bf16x3"] = s3
         for kk in (1, 5):
             if kk != args.sampler_iters:
                 extras[f"k{kk}"] = sub(wl.run(B, 1000 + rank, kk, K, W, windows=SW), B, n_shaded,
@@ -474,6 +489,8 @@ def main():
         def peak_of(n):
             if n == "i2sdf_weight_grads" and eng.wgrad_bf16x3 and eng.wgrad_bf16x2:
                 return PEAK_BF16 / 3
+            if n == "i2sdf_sample_rays" and eng.sdf_forward_bf16x3 and getattr(eng, "sampler_bf16x2", False):
+                return PEAK_BF16 / 3      # two planes per operand, three products per block
             return PEAK_X3 if x3.get(n) else PEAK
         roof = None
         if dom:
@@ -518,7 +535,8 @@ def main():
             "timing": f"median of {len(head['dts'])} windows of exactly {K} steps each (barrier + synchronize around every window, max over ranks)",
             "vs_baseline": None,
             "dtype": "f32" if not any_x3 else ("f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate"
-                                                + ("; the 256x256 weight-gradient GEMM blocks: 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
+                                                + ("; the 256x256 weight-gradient GEMM blocks" + (" and the sampler's depth-choosing sdf-only passes" if getattr(eng, "sampler_bf16x2", False) else "")
+                                                   + ": 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
                                                    if eng.wgrad_bf16x2 else ")")),
             "data": "synthetic" if not mock else "mock (launch-logic self-test on the CPU stand-in core: value / ms_per_step carry NO throughput claim)",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",
@@ -645,7 +663,7 @@ def dominant_kernel(live, cfg, fp, eng, B, M_main, M_sdf, iters, PEAK, PEAK_BF16
     sdf = cfg.sdf.dims
     mac_fwd_hidden = sum(o * i for o, i in sdf[:-1])
     per_step = {   # kernel-name fragment -> (algorithmic FLOPs per step, bf16 MFMAs per fp32 product block (0 = fp32-input MFMA))
-        "sdf_fwd3h_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
+        "sdf_fwd3h_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 3 if getattr(eng, "sampler_bf16x2", False) else 6),
         "sdf_fwd3_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
         "sdf_fwd4_kernel": (fp["sdf_forward"] * B * cfg.sampler.N_samples_eval * iters, 6),
         "sdf_train_fwd3h_kernel": (2 * (mac_fwd_hidden + sdf[-1][0] * sdf[-1][1]) * M_sdf, 6),

@@ -76,6 +76,13 @@ class NetConfig:
     # float32_matmul_precision('medium') (main_recon.py:61).  Forward and backward ACTIVATIONS always keep the fp32-equivalent bf16x3
     # form.  `wgrad_bf16x2: false` in the model conf (or I2SDF_WGRAD_BF16X2=0) selects the fp32-equivalent form here too.
     wgrad_bf16x2: bool = True
+    # The sampler's sdf-only passes with TWO bf16 terms per operand (include/i2sdf.h: I2SDF_OPT_SAMPLER_BF16X2).  These passes run under
+    # no_grad and only CHOOSE the depths (ray_sampler.py:83-95); every returned value is computed at the chosen depths by the fp32-equivalent
+    # kernels.  Round 6 ran the WHOLE GPU suite with the option on before making it the default (profiles/r6_sampler_x2.txt: 198 passed --
+    # G7's iteration counts exact, the depth bars of tests/test_gpu_sampler.py, G8/G9/G14/G15 end-to-end at 1e-4): sampler entry point
+    # 1.09 -> 0.67 ms, step 5.42 -> 4.97 ms, a 640x480 eval render 1.18 -> 0.86 s.  `sampler_bf16x2: false` (or I2SDF_SAMPLER_BF16X2=0)
+    # selects the three-plane form here too.
+    sampler_bf16x2: bool = True
 
     @staticmethod
     def from_conf(conf) -> "NetConfig":
@@ -146,7 +153,8 @@ class NetConfig:
                          beta_init=float(_get(_get(dens, "params_init"), "beta")), beta_min=float(_get(dens, "beta_min", 1e-4)),
                          sdf_bias=float(_get(inet, "bias", 1.0)), use_normal=bool(_get(conf, "use_normal", False)),
                          detach_light_feature=bool(_get(conf, "detach_light_feature", True)),
-                         bf16x3=bool(_get(conf, "bf16x3", True)), wgrad_bf16x2=bool(_get(conf, "wgrad_bf16x2", True)))
+                         bf16x3=bool(_get(conf, "bf16x3", True)), wgrad_bf16x2=bool(_get(conf, "wgrad_bf16x2", True)),
+                         sampler_bf16x2=bool(_get(conf, "sampler_bf16x2", True)))
 
 
 def synthetic_conf(light: bool = False) -> dict:

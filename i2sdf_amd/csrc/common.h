@@ -148,8 +148,11 @@ struct WStreamT {
   // implies that the pieces have landed; a smaller `young` than the truth only waits longer).  The source loads issued ahead of their use
   // (x3.h) then fly across the stage barrier instead of being drained at it.  scripts/ubench/mfma_paced.hip (profiles/r5_mfma_paced.txt).
   template <int N> static __device__ __forceinline__ void wait_barrier() {
-    // one asm statement with a memory clobber: no LDS read of the new stage moves above it (__syncthreads() would add its own vmcnt(0))
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+    // one asm statement with a memory clobber: no LDS read of the new stage moves above it (__syncthreads() would add its own vmcnt(0)).
+    // lgkmcnt(0): every wave must have FINISHED reading the other stage buffer before the next DMA overwrites it.  The reads of a stage are
+    // all consumed by MFMAs in front of the barrier, so the compiler has always had the wait there by itself and this one is free -- but
+    // the protocol must not rest on where the compiler puts it (MFMAs may legally sink below an asm statement)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
   }
   __device__ __forceinline__ const float* advance_barrier_young(int young) {
     switch (young < 0 ? 0 : young > 16 ? 16 : young) {

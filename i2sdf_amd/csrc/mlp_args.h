@@ -16,6 +16,7 @@ struct SdfTrainFwdArgs {
   float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
   int kcs = 16;                         // layout of hs / abars for the points of THIS launch: 16 point-major, 512 blocked (mlp_common.h)
   int wg0 = 0;                          // first 128-point workgroup of this launch (point ranges, plan.h: PartRun)
+  int64_t ldf = 0;                      // row stride of `feat` in floats (0 = F: the training workspaces; i2sdf_sdf_forward passes the caller's ld_feat)
 };
 
 struct SdfBwdArgs {

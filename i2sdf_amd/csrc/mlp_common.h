@@ -129,11 +129,11 @@ __host__ __device__ constexpr int sdf_rev3_bwd_stages(int H, int F, int PEC, int
   return c / SC;
 }
 // ---- 16-point-wave family (x3h.h): same ops, 16-row tiles / 32-wide k-chunks -- must mirror plan.cpp
-__host__ __device__ constexpr int sdf_fwd3h_stages(int H, int PED, int L, bool has_skip) {
+__host__ __device__ constexpr int sdf_fwd3h_stages(int H, int PED, int L, bool has_skip, int PL = 3) {
   const int PE32 = cdiv(PED, 32);
-  int c = x3h_op_chunks(H / 16, PE32);
-  for (int l = 1; l < L - 1; ++l) c += x3h_op_chunks(H / 16, H / 32);
-  if (has_skip) c += x3h_op_chunks(H / 16, H / 32 + PE32) - x3h_op_chunks(H / 16, H / 32);
+  int c = x3h_op_chunks(H / 16, PE32, PL);
+  for (int l = 1; l < L - 1; ++l) c += x3h_op_chunks(H / 16, H / 32, PL);
+  if (has_skip) c += x3h_op_chunks(H / 16, H / 32 + PE32, PL) - x3h_op_chunks(H / 16, H / 32, PL);
   c += rowvec_h_chunks(H / 16, 1);
   return c / SCH;
 }

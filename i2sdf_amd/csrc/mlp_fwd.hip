@@ -1,6 +1,7 @@
 // SDF network forward without gradient: ImplicitNetwork.forward / get_sdf_vals
 // (model/network/mlp.py:84-105,145-151).  MFMA-bound: 2*524544 FLOP per point at synthetic.yml shapes.
 #include "epi.h"
+#include "mlp_args.h"
 
 using namespace i2sdf;
 
@@ -10,7 +11,7 @@ void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int 
                            float* sdf_out, unsigned grid, hipStream_t st);
 
 void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M, float* sdf_out,
-                            hipStream_t st);
+                            int planes, hipStream_t st);
 
 namespace {
 
@@ -67,15 +68,16 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const float* __restrict__ 
 
 template <int H, int F, int LF>
 int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, const int* skip_flag, int64_t M, float* sdf_out,
-                   float* feat_out, int64_t ld_feat, hipStream_t st) {
+                   float* feat_out, int64_t ld_feat, hipStream_t st, bool sampler_pass = false) {
   const i2sdf_mlp_desc& d = p->sdf.d;
   const float* stream = packed + p->scale_floats + p->sdf.fwd_chunk0 * CHUNK_FLOATS;
   const bool full = feat_out != nullptr;
   if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && H == 256 && p->sdf.fwd3h_chunks > 0) {
-    // 256-wide nets: 16-point waves, two per SIMD (x3h.h)
-    const float* s3 = packed + p->scale_floats + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;
-    const int ns3 = sdf_fwd3h_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
-    i2sdf_launch_sdf_fwd3h(s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, st);
+    // 256-wide nets: 16-point waves, two per SIMD (x3h.h); the sampler's passes with two split planes under I2SDF_OPT_SAMPLER_BF16X2
+    const int PL = (sampler_pass && p->sampler_bf16x2 && p->sdf.fwd2h_chunks > 0) ? 2 : 3;
+    const float* s3 = packed + p->scale_floats + (PL == 2 ? p->sdf.fwd2h_chunk0 : p->sdf.fwd3h_chunk0) * CHUNK_FLOATS;
+    const int ns3 = sdf_fwd3h_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0, PL);
+    i2sdf_launch_sdf_fwd3h(s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, PL, st);
     return i2sdf_hip_check(hipGetLastError(), "sdf_forward (bf16x3, 16-point waves) launch");
   }
   if (!full && sdf_out != nullptr && p->sdf_fwd_bf16x3 && H == 64 && p->sdf.fwd3_chunks > 0) {
@@ -83,6 +85,17 @@ int launch_sdf_fwd(const i2sdf_plan* p, const float* packed, PointSpec points, c
     const int ns3 = sdf_fwd3_stages(H, PE<LF>::DIM, d.n_lin, d.skip_layer > 0);
     i2sdf_launch_sdf_fwd3(H, s3, ns3, d.n_lin, d.skip_layer, points, skip_flag, M, sdf_out, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st);
     return i2sdf_hip_check(hipGetLastError(), "sdf_forward (bf16x3) launch");
+  }
+  if (full && p->sdf_fwd_bf16x3 && H == 256 && F == 256 && p->sdf.fwd3h_chunks > 0) {
+    // [sdf | feature] rows (ImplicitNetwork.forward: the meshing callers, model/eval/recon.py:51,90, utils/plots.py:52): the 16-point-wave
+    // forward of the training path without its saves -- the same kernel, so the 257 columns are the values a training step computes
+    SdfTrainFwdArgs a{};
+    a.fwd = packed + p->scale_floats + p->sdf.fwd3h_chunk0 * CHUNK_FLOATS;
+    a.n_fwd = sdf_fwd3h_train_stages(256, 256, PE<LF>::DIM, d.n_lin, d.skip_layer > 0, true);
+    a.L = d.n_lin; a.skip = d.skip_layer; a.pts = points; a.M = M; a.Mp = M; a.sdf = sdf_out; a.feat = feat_out; a.ldf = ld_feat;
+    if (skip_flag != nullptr) return I2SDF_EINVAL;      // (the sampler never asks for features)
+    i2sdf_launch_train_fwd3h(a, (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG), st);
+    return i2sdf_hip_check(hipGetLastError(), "sdf_forward (features, bf16x3, 16-point waves) launch");
   }
   const int ns = sdf_fwd_stages(H, F, PE<LF>::PEC, d.n_lin, d.skip_layer > 0, full);
   const unsigned grid = (unsigned)((M + PTS_PER_WG - 1) / PTS_PER_WG);
@@ -115,7 +128,7 @@ int i2sdf_sdf_forward_rays_flagged(const i2sdf_plan* p, const float* packed, con
   const int64_t M = B * n_per_ray;
   const PointSpec ps{nullptr, cam, dirs, z, ldz, M, n_per_ray};
   hipStream_t st = (hipStream_t)stream;
-  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st);
-  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st);
+  if (p->H == 256 && p->F == 256) return launch_sdf_fwd<256, 256, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st, true);
+  if (p->H == 64 && p->F == 64) return launch_sdf_fwd<64, 64, 6>(p, packed, ps, skip_flag, M, sdf_out, nullptr, 0, st, true);
   return I2SDF_EINVAL;
 }

@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 accA[NT], accB[NT];
   {
-    X3Sweep1Src<NT, 0, NGP> src{accB, gpx, nullptr, nullptr, hi, valid};
+    X3Sweep1Src<NT, 0, NGP> src{accB, gpx, nullptr, nullptr, hi};
     dense_x3g<NT, PE16, 2>(ws, src, accA, tid);
   }
   for (int l = 1; l < a.L - 1; ++l) {
     // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l]  (G2(a_{l-1}) is formed by sweep 2 from it, x3.h)
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, valid, kcs};
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
     if (l == a.skip) dense_x3g<NT, KH16 + PE16, 2>(ws, src, accB, tid);
     else dense_x3g<NT, KH16, 2>(ws, src, accB, tid);
 #pragma unroll
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   }
   {
     const int l = a.L - 1;
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, valid, kcs};
+    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
     x3_drain<KH16>(src);
   }
 }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   {
     const int l = a.L - 2;                            // G(a_{L-2}) = (W_feat^T fbar + sbar w_sdf) sigma + G2, then W_{L-2}^T G(a_{L-2})
     X3Sweep2Src<NT, true> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + mcrow, a.abars + l * lstride + mcrow,
-                              a.gas + l * lstride + mrow, hi, valid, sb, a.rev + lane * 4, kcs};
+                              a.gas + l * lstride + mrow, hi, sb, a.rev + lane * 4, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
 #pragma unroll
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   }
   for (int l = a.L - 3; l >= 1; --l) {
     X3Sweep2Src<NT, false> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + mcrow, a.abars + l * lstride + mcrow,
-                               a.gas + l * lstride + mrow, hi, valid, 0.f, nullptr, kcs};
+                               a.gas + l * lstride + mrow, hi, 0.f, nullptr, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) ws.skip(x3_bwd_chunks(PT, KH16) / SC, tid);      // the PE rows of W_skip^T are not needed here
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3Sweep2Src<NT, false> src{accA, a.hs + mcrow, a.gus + lstride + mcrow, a.abars + mcrow, a.gas + mrow, hi, valid, 0.f, nullptr, kcs};     // G(a_0)
+    X3Sweep2Src<NT, false> src{accA, a.hs + mcrow, a.gus + lstride + mcrow, a.abars + mcrow, a.gas + mrow, hi, 0.f, nullptr, kcs};     // G(a_0)
     x3_drain<KH16>(src);
   }
 }

@@ -21,7 +21,8 @@ __device__ __forceinline__ void pe_select_h(float px, float py, float pz, float 
 }
 
 // sdf-only forward (sampler passes, grid queries) of the 256-wide net; 64-wide nets: sdf_fwd3_kernel, mlp_x3.hip
-template <int H, int LF, int NW>
+// PL = 2: the sampler's passes with two split planes per operand (x3h.h: dense_x3h; its own weight stream of two planes)
+template <int H, int LF, int NW, int PL>
 __global__ __launch_bounds__(NW * 64, 2) void sdf_fwd3h_kernel(const float* __restrict__ stream, int n_stages, int L, int skip, PointSpec ps,
                                                                 const int* __restrict__ skip_flag, int64_t M, float* __restrict__ sdf_out) {
   constexpr int NT = H / 16, KH32 = H / 32, PE32 = cdiv(PE<LF>::DIM, 32), NPE = PE32 * 8;
@@ -40,12 +41,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sdf_fwd3h_kernel(const float* __re
   f32x4 accP[NT], accN[NT];
   {
     XhFwdSrc<NT, 0, NPE, false> src{accN, pe, nullptr, kg, valid};
-    dense_x3h<NT, PE32, 1, NW>(ws, src, accP, tid);
+    dense_x3h<NT, PE32, 1, NW, XhFwdSrc<NT, 0, NPE, false>, PL>(ws, src, accP, tid);
   }
   for (int l = 1; l < L - 1; ++l) {
     XhFwdSrc<NT, KH32, NPE, false> src{accP, pe, nullptr, kg, valid};
-    if (l == skip) dense_x3h<NT, KH32 + PE32, 1, NW>(ws, src, accN, tid);
-    else dense_x3h<NT, KH32, 1, NW>(ws, src, accN, tid);
+    if (l == skip) dense_x3h<NT, KH32 + PE32, 1, NW, XhFwdSrc<NT, KH32, NPE, false>, PL>(ws, src, accN, tid);
+    else dense_x3h<NT, KH32, 1, NW, XhFwdSrc<NT, KH32, NPE, false>, PL>(ws, src, accN, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accP[nt] = accN[nt];
   }
@@ -116,12 +117,12 @@ __global__ __launch_bounds__(NW * 64, 2) void sdf_train_fwd3h_kernel(SdfTrainFwd
   {
     float s[1];
     rowvec_h<1, NT, NW>(ws, h, s, tid);
-    if (valid && kg == 0) a.sdf[m] = s[0];
+    if (a.sdf != nullptr && valid && kg == 0) a.sdf[m] = s[0];
   }
   if (a.feat != nullptr) {
     XhRegSrc<NT * 4> src{h};
     dense_x3h<FT, KH32, 1, NW>(ws, src, accB, tid);
-    store_tile_h<FT>(a.feat + mc * F, kg, valid, accB);
+    store_tile_h<FT>(a.feat + mc * (a.ldf ? a.ldf : (int64_t)F), kg, valid, accB);
   }
 }
 
@@ -279,8 +280,10 @@ __global__ __launch_bounds__(NW * 64, 2) void rgb_bwd3h_kernel(RgbBwdArgs a) {
 
 // launches over workgroups of 128 points (eight 16-point waves)
 void i2sdf_launch_sdf_fwd3h(const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M, float* sdf_out,
-                            hipStream_t st) {
-  launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8>, (unsigned)((M + 8 * HP - 1) / (8 * HP)), st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
+                            int planes, hipStream_t st) {
+  const unsigned grid = (unsigned)((M + 8 * HP - 1) / (8 * HP));
+  if (planes == 2) launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8, 2>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
+  else launch_lds_threads(512, sdf_fwd3h_kernel<256, 6, 8, 3>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
 void i2sdf_launch_train_fwd3h(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, sdf_train_fwd3h_kernel<256, 256, 6, 8>, grid, st, a); }
 void i2sdf_launch_rgb_fwd3h(const RgbFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds_threads(512, rgb_fwd3h_kernel<256, 256, 4, 8>, grid, st, a); }

@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256) void pack_kernel(const Seg* __restrict__ segs,
         const int r = 16 * c + 4 * kg + t;
         out[t] = (r < s.nrows) ? params[s.off_bias + s.row_off + r] : 0.f;
       }
-    } else if (s.type == SEG_WFWD3H || s.type == SEG_WBWD3H) {
-      // chunk c -> pair w = c/2 (e = c&1), k-chunk kc = w / (3G), tile pair g, split plane sp; A row = 16*(2g+e) + i16,
+    } else if (s.type == SEG_WFWD3H || s.type == SEG_WBWD3H || s.type == SEG_WFWD2H) {
+      // chunk c -> pair w = c/2 (e = c&1), k-chunk kc = w / (PL G), tile pair g, split plane sp < PL (3; SEG_WFWD2H: 2); A row = 16*(2g+e) + i16,
       // element j <-> reduction index 32*kc + 16*(j>>2) + 4*kg + (j&3)
-      const int G = s.NT / 2, w = c >> 1, e = c & 1;
-      const int kc = w / (3 * G), g = (w / 3) % G, sp = w % 3;
+      const int G = s.NT / 2, w = c >> 1, e = c & 1, PL = s.type == SEG_WFWD2H ? 2 : 3;
+      const int kc = w / (PL * G), g = (w / PL) % G, sp = w % PL;
       const int i16 = lane & 15, kg = lane >> 4;
       const int arow = 16 * (2 * g + e) + i16;
-      const bool fwd = s.type == SEG_WFWD3H;
+      const bool fwd = s.type != SEG_WBWD3H;
       const int acol = fwd ? -1 : map_col(s.cm, arow);            // transposed: the A row is an input column of the layer
       unsigned q[4] = {0u, 0u, 0u, 0u};
       if (fwd ? (arow < s.nrows) : (acol >= 0)) {

@@ -101,6 +101,16 @@ void emit_dense_fwd3h(Builder& b, const NetPlan& np, int l, int NT, int KC32, Co
   sw.row_off = row_off; sw.nrows = nrows;
   b.add(sw);
 }
+// the same op with the two leading split planes only (x3h.h: dense_x3h<..., PL = 2>)
+void emit_dense_fwd2h(Builder& b, const NetPlan& np, int l, int NT, int KC32, ColMap cm, float mult, int row_off, int nrows) {
+  Seg sb = base_seg(np, l, SEG_BIAS_H);
+  sb.NT = NT; sb.KC = 1; sb.nchunks = NT; sb.used = NT; sb.row_off = row_off; sb.nrows = nrows;
+  b.add(sb);
+  Seg sw = base_seg(np, l, SEG_WFWD2H);
+  sw.NT = NT; sw.KC = KC32; sw.used = KC32 * NT * 2; sw.nchunks = x3h_op_chunks(NT, KC32, 2) - NT; sw.cm = cm; sw.mult = mult;
+  sw.row_off = row_off; sw.nrows = nrows;
+  b.add(sw);
+}
 void emit_dense_bwd3h(Builder& b, const NetPlan& np, int l, int KT, int KC32, ColMap cm, int row_off, int nrows, float mult) {
   Seg sw = base_seg(np, l, SEG_WBWD3H);
   sw.NT = KT; sw.KC = KC32; sw.used = KC32 * KT * 3; sw.nchunks = x3h_bwd_chunks(KT, KC32); sw.cm = cm; sw.mult = mult;
@@ -226,6 +236,20 @@ int build_sdf(i2sdf_plan* p, Builder& b) {
   np.fwd3h_chunks = b.chunk - np.fwd3h_chunk0;
   np.rev3h_chunk0 = b.chunk;          // (no reverse stream of this family for the SDF net: its d sdf/dx chain and sweeps run on 32-point waves)
   np.rev3h_chunks = b.chunk - np.rev3h_chunk0;
+  // the sampler's passes with two split planes (I2SDF_OPT_SAMPLER_BF16X2): hidden layers + the fp32 sdf row, 2/3 of the bytes and stages
+  np.fwd2h_chunk0 = b.chunk;
+  if (H == 256 && F == 256) {
+    const int PE32 = cdiv(PED, 32);
+    for (int l = 0; l < L - 1; ++l) {
+      ColMap cm{HUGE_SPLIT, 0, d.in_dim[l], 0, 0};
+      int KC32 = (l == 0) ? PE32 : H / 32;
+      float mult = 1.0f;
+      if (l == d.skip_layer) { cm = ColMap{H, 0, d.in_dim[l] - PED, d.in_dim[l] - PED, PED}; KC32 += PE32; mult = 0.70710678118654752440f; }
+      emit_dense_fwd2h(b, np, l, H / 16, KC32, cm, mult, 0, d.out_dim[l]);
+    }
+    emit_rowvec_h(b, np, L - 1, 1, H / 16, ColMap{HUGE_SPLIT, 0, H, 0, 0});
+  }
+  np.fwd2h_chunks = b.chunk - np.fwd2h_chunk0;
   return I2SDF_OK;
 }
 
@@ -518,6 +542,13 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     const bool runs = (p->H == 256 && p->F == 256 && p->sdf.fwd3h_chunks > 0) || (p->H == 64 && p->F == 64 && p->sdf.fwd3_chunks > 0);
     if (value && !runs) return I2SDF_EINVAL;
     p->sdf_fwd_bf16x3 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
+  if (option == I2SDF_OPT_SAMPLER_BF16X2) {
+    // only the passes inside i2sdf_sample_rays / i2sdf_render_image (they choose depths); i2sdf_sdf_forward and i2sdf_sdf_grid return values
+    // and keep three planes.  Needs the 16-point-wave forward (I2SDF_OPT_SDF_FWD_BF16X3 on a 256-wide net).
+    if (value && (p->sdf.fwd2h_chunks == 0 || p->H != 256 || p->F != 256)) return I2SDF_EINVAL;
+    p->sampler_bf16x2 = value ? 1 : 0;
     return I2SDF_OK;
   }
   if (option == I2SDF_OPT_TRAIN_FWD_BF16X3) {

@@ -13,7 +13,8 @@ enum SegType : int32_t { SEG_ZERO = 0, SEG_BIAS = 1, SEG_WFWD = 2, SEG_WBWD = 3,
                          SEG_WFWD3 = 6 /* bf16x3 split planes, K-outer order (x3.h) */,
                          SEG_WBWD3 = 7 /* transposed weights, bf16x3 split planes, K-outer order */,
                          // the 16-point-wave family (x3h.h): 16-row tiles, 32-wide k-chunks
-                         SEG_BIAS_H = 8, SEG_WFWD3H = 9, SEG_WBWD3H = 10, SEG_ROWVEC_H = 11 };
+                         SEG_BIAS_H = 8, SEG_WFWD3H = 9, SEG_WBWD3H = 10, SEG_ROWVEC_H = 11,
+                         SEG_WFWD2H = 12 /* as SEG_WFWD3H with the two leading split planes only (the sampler's bf16x2 passes) */ };
 
 // Column map from a padded register-space index to a source column of weight_v:
 //   kp <  split : kp < valid0 ? base0 + kp : none
@@ -51,6 +52,7 @@ struct NetPlan {
   int64_t rev3_wsdf_chunk = 0;                 // where the d sdf/dx chain starts inside it
   int64_t fwd3h_chunk0 = 0, fwd3h_chunks = 0;  // bf16x3 streams of the 16-point-wave kernels (x3h.h): sdf net forward [hidden layers, sdf row, feature rows];
   int64_t rev3h_chunk0 = 0, rev3h_chunks = 0;  // radiance net forward and reverse
+  int64_t fwd2h_chunk0 = 0, fwd2h_chunks = 0;  // sdf net, hidden layers + sdf row with TWO split planes (I2SDF_OPT_SAMPLER_BF16X2)
   int64_t wgrad_off[I2SDF_MAX_LAYERS];         // offset (floats) of layer l's [rowsP x colsP] block in the wgrad buffer
   int32_t wg_rows[I2SDF_MAX_LAYERS], wg_cols[I2SDF_MAX_LAYERS];   // padded shape of that block
 };
@@ -74,6 +76,7 @@ struct i2sdf_plan {
   int32_t train_fwd_bf16x3 = 0;      // I2SDF_OPT_TRAIN_FWD_BF16X3: SDF forward + d sdf/dx kernel in bf16x3 split arithmetic
   int32_t wgrad_bf16x3 = 0;          // I2SDF_OPT_WGRAD_BF16X3: full 256x256 weight-gradient blocks in bf16x3 split arithmetic
   int32_t sdf_fwd_bf16x3 = 0;        // i2sdf_plan_set_option(I2SDF_OPT_SDF_FWD_BF16X3): sdf-only forward in bf16x3 split arithmetic
+  int32_t sampler_bf16x2 = 0;        // I2SDF_OPT_SAMPLER_BF16X2: the sampler's sdf-only passes with two split planes / three products
   i2sdf_exchange exchange{nullptr, nullptr};   // i2sdf_plan_set_exchange: small data-parallel exchanges (copied)
   int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
   int32_t wgrad_bf16x2 = 0;          // I2SDF_OPT_WGRAD_BF16X2: 256x256 weight-gradient blocks with two split planes / three products

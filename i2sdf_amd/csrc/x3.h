@@ -152,9 +152,9 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int p0 = first_pair(s), p1 = end_pair(s);
-    // every stage barrier drains vmcnt(0): the DMA pieces must have landed, and hipcc cannot be trusted to wait for them by itself
-    // (common.h: WStream::advance).  Counted waits that let operand loads fly across the barrier and an early barrier that hides the
-    // first LDS reads of a stage were built in round 3 and measured inside the noise; round 4 removed them (git history).
+    // The stage hand-over: the DMA pieces of this stage must have landed (hipcc cannot be trusted to wait for them by itself, common.h:
+    // WStream::advance).  Counted form (round 5): `s_waitcnt vmcnt(vm_young); s_barrier`, vm_young = the vector-memory instructions this
+    // wave has issued since the stage's last piece -- the source loads and saved-tensor stores behind it fly across the barrier.
 #if X3_COUNTED_WAIT
     // the first stage of an op was fetched by the previous op (or begin()): full drain there
     const u32x4* cur = reinterpret_cast<const u32x4*>(s == 0 ? ws.advance_barrier() : ws.advance_barrier_young(vm_young)) + lane;
@@ -207,6 +207,9 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         for (int q = 0; q < 2; ++q)
           if (npiece < WStream::NPIECE) {       // next stage's DMA: 2 pieces per group, from the first group on
             ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
+            // everything counted into vm_young must be emitted BEHIND the stage's last piece: a plain global access does not alias the
+            // LDS DMA, so without a fence the scheduler may hoist one above it and the counted wait would over-count
+            if (npiece == WStream::NPIECE) __builtin_amdgcn_sched_barrier(0);
           }
         if (LATE && !flushed && npiece == WStream::NPIECE) { flush(); flushed = true; }
         {
@@ -218,9 +221,12 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (npiece < WStream::NPIECE) {
 #pragma unroll
-    for (int i = 0; i < WStream::NPIECE; ++i)
-      if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
+      for (int i = 0; i < WStream::NPIECE; ++i)
+        if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
+      __builtin_amdgcn_sched_barrier(0);      // (as above: counted accesses stay behind the last piece)
+    }
     if (LATE && !flushed) flush();
     ws.advance_done();
   }
@@ -340,7 +346,7 @@ struct X3Sweep1Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
-  const float* hrow; float* gurow; int hi; bool valid; int kcs = 16;
+  const float* hrow; float* gurow; int hi; int kcs = 16;
   f32x4 hq[X3_RING][2];
   __device__ __forceinline__ int ahead(int kc) {
     if (kc < KACC) x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs);
@@ -363,7 +369,7 @@ template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
-  const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi; bool valid;
+  const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
   f32x4 hq[X3_RING][2], gq[X3_RING][2], aq[X3_RING][2], wq[X3_RING][2];

@@ -41,7 +41,7 @@ constexpr int SCH = SC;                    // chunks per LDS stage (80 KB stages
 constexpr int LDS_BYTES_H = LDS_BYTES;
 template <int NW> using WStreamH = WStreamT<NW * 64, SCH>;
 
-__host__ __device__ constexpr int x3h_op_chunks(int NT, int KC32) { return round_up(NT + KC32 * NT * 3, SCH); }
+__host__ __device__ constexpr int x3h_op_chunks(int NT, int KC32, int PL = 3) { return round_up(NT + KC32 * NT * PL, SCH); }
 __host__ __device__ constexpr int x3h_bwd_chunks(int KT, int KC32) { return round_up(KC32 * KT * 3, SCH); }
 // row vectors: [NROWS*16 chunks: lane (.,kg) of chunk (row, nt) holds w_row[16 nt + 4 kg + 0..3]][1 scalar chunk]
 __host__ __device__ constexpr int rowvec_h_chunks(int NTK, int nrows) { return round_up(nrows * NTK + 1, SCH); }
@@ -72,7 +72,10 @@ __device__ __forceinline__ void x3h_select(const float (&full)[NC32 * 32], float
 // Per group: one tile pair, one split plane = two A chunks, four MFMAs (the W0*h2 pair of the sp = 0 group rides in the sp = 2
 // group), one twelfth of the next k-chunk's B preparation in every other group, the next stage's DMA pieces in the first groups.
 // ---------------------------------------------------------------------------------------------
-template <int NT, int KC32, int BIAS, int NW, class Src>
+// PL = split planes per operand: 3 = the fp32-equivalent form (six products); 2 = bf16x2 (x = x0 + x1 + O(2^-18 |x|), the three products
+// W0h0 + W0h1 + W1h0; the weight stream then holds two planes per tile pair: SEG_WFWD2H).  Only the sampler's sdf-only passes may run with
+// PL = 2 (I2SDF_OPT_SAMPLER_BF16X2): they choose depths, no returned value is computed from them.
+template <int NT, int KC32, int BIAS, int NW, class Src, int PL = 3>
 __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&acc_io)[NT], int tid) {
   using WS = WStreamH<NW>;
   f32x4 acc[NT];
@@ -84,7 +87,9 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
     for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   static_assert(NT % 2 == 0, "tiles are processed in pairs");
-  constexpr int NB = BIAS != 0 ? NT : 0, G = NT / 2, PPK = G * 3, NPAIR = KC32 * PPK, NWC = NPAIR * 2;
+  static_assert(PL == 2 || PL == 3, "split planes");
+  constexpr int NB = BIAS != 0 ? NT : 0, G = NT / 2, PPK = G * PL, NPAIR = KC32 * PPK, NWC = NPAIR * 2;
+  constexpr int NM = G * (PL == 3 ? 12 : 6);        // MFMAs (= gaps) per k-chunk
   constexpr int TOT = round_up(NB + NWC, SCH), NS = TOT / SCH, PFP = 2;
   static_assert(NB % 2 == 0, "bias chunks come in pairs");
   const int lane = tid & 63;
@@ -126,7 +131,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
       } else {
         const unsigned p1 = pk_bf16(ra[i], rb[i]);
         b[1][i] = p1;
-        b[2][i] = pk_bf16(ra[i] - bf16_lo(p1), rb[i] - bf16_hi(p1));
+        if (PL == 3) b[2][i] = pk_bf16(ra[i] - bf16_lo(p1), rb[i] - bf16_hi(p1));
       }
     }
   };
@@ -160,7 +165,7 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
     for (int jp = 0; jp < SCH / 2; ++jp) {
       if (jp >= p0 && jp < p1) {
         const int w = (s * SCH + 2 * jp - NB) / 2;
-        const int kc = w / PPK, g = (w / 3) % G, sp = w % 3, nt = 2 * g;
+        const int kc = w / PPK, g = (w / PL) % G, sp = w % PL, nt = 2 * g;
         const u32x4 a0 = ring[(jp - p0) % PFP][0], a1 = ring[(jp - p0) % PFP][1];
         const u32x4 (&b)[3] = bq[kc & 1];
         if (jp + PFP < p1) {
@@ -169,36 +174,47 @@ __device__ __forceinline__ void dense_x3h(WStreamH<NW>& ws, Src& src, f32x4 (&ac
         }
         // four units, one MFMA each, fenced: consecutive MFMAs never share an accumulator (a dependent 16x16x32 issued right behind
         // its producer waits out the pipeline latency), and the group's other work is dealt behind them instead of clustering
-        const int pi = w % PPK;
-        auto gap = [&](int q) __attribute__((always_inline)) {        // MFMA gap 4*pi + q of the k-chunk (4*PPK gaps): piece j sits in gap j*4*PPK/NU
-          const int gi = 4 * pi + q;
+        // (PL = 2: the W0 group has four units -- W0h0, W0h1 of both tiles -- the W1 group two)
+        const int gbase = PL == 3 ? 4 * (w % PPK) : 6 * g + 4 * sp;
+        auto gap = [&](int q) __attribute__((always_inline)) {        // MFMA gap gbase + q of the k-chunk (NM gaps): piece j sits in gap j*NM/NU
+          const int gi = gbase + q;
 #pragma unroll
           for (int j = 0; j < NU; ++j)
-            if (j * (4 * PPK) / NU == gi) prep(kc + 1, j, bq[(kc + 1) & 1]);
+            if (j * NM / NU == gi) prep(kc + 1, j, bq[(kc + 1) & 1]);
         };
         acc[nt] = mfma_bf16h(a0, b[0], acc[nt]);
         gap(0);
         __builtin_amdgcn_sched_barrier(0);
         acc[nt + 1] = mfma_bf16h(a1, b[0], acc[nt + 1]);
+        if (PL == 2 && sp == 1 && npiece < WS::NPIECE) {
+          ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
+          if (npiece == WS::NPIECE) __builtin_amdgcn_sched_barrier(0);
+        }
         gap(1);
         __builtin_amdgcn_sched_barrier(0);
-        if (sp == 0) { d0 = a0; d1 = a1; }
-        if (sp < 2) acc[nt] = mfma_bf16h(a0, b[1], acc[nt]);
-        else acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
-        if (npiece < WS::NPIECE) {          // next stage's DMA: one piece per group, from the first group on
-          ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
+        if (PL == 3 || sp == 0) {
+          if (PL == 3 && sp == 0) { d0 = a0; d1 = a1; }
+          if (sp < 2) acc[nt] = mfma_bf16h(a0, b[1], acc[nt]);
+          else acc[nt] = mfma_bf16h(d0, b[2], acc[nt]);
+          if (npiece < WS::NPIECE) {          // next stage's DMA: one piece per group, from the first group on
+            ws.issue_piece(npiece, tid); ++npiece; vm_young = 0;
+            if (npiece == WS::NPIECE) __builtin_amdgcn_sched_barrier(0);      // counted accesses stay behind the stage's last piece (x3.h)
+          }
+          gap(2);
+          __builtin_amdgcn_sched_barrier(0);
+          if (sp < 2) acc[nt + 1] = mfma_bf16h(a1, b[1], acc[nt + 1]);
+          else acc[nt + 1] = mfma_bf16h(d1, b[2], acc[nt + 1]);
+          gap(3);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        gap(2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sp < 2) acc[nt + 1] = mfma_bf16h(a1, b[1], acc[nt + 1]);
-        else acc[nt + 1] = mfma_bf16h(d1, b[2], acc[nt + 1]);
-        gap(3);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (npiece < WS::NPIECE) {
 #pragma unroll
-    for (int i = 0; i < WS::NPIECE; ++i)
-      if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
+      for (int i = 0; i < WS::NPIECE; ++i)
+        if (i >= npiece) { ws.issue_piece(i, tid); vm_young = 0; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     ws.advance_done();
   }
 #pragma unroll

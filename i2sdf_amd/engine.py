@@ -49,6 +49,12 @@ class RenderEngine:
         x2 = os.environ.get("I2SDF_WGRAD_BF16X2", "")
         if cfg.bf16x3 and ((x2 != "0") if x2 != "" else cfg.wgrad_bf16x2):
             self.set_wgrad_bf16x2(True)
+        # the sampler's sdf-only passes with two split planes (include/i2sdf.h: I2SDF_OPT_SAMPLER_BF16X2); conf `sampler_bf16x2`,
+        # I2SDF_SAMPLER_BF16X2=0 / 1 overrides it
+        self.sampler_bf16x2 = False
+        sx2 = os.environ.get("I2SDF_SAMPLER_BF16X2", "")
+        if self.sdf_forward_bf16x3 and cfg.sdf.hidden == 256 and cfg.feature_size == 256 and ((sx2 != "0") if sx2 != "" else getattr(cfg, "sampler_bf16x2", False)):
+            self.set_sampler_bf16x2(True)
         self.blocked_saves = False
         if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
             self.set_blocked_saves(True)
@@ -138,8 +144,8 @@ class RenderEngine:
         side.wait_stream(cur)
         # streams that read `packed` since the previous pack (entry points issued on other streams than the one calling pack()): the
         # new pack must not overwrite the weight streams under them
-        for sid, st in getattr(self, "_pack_readers", {}).items():
-            if sid != cur.cuda_stream:
+        for st in getattr(self, "_pack_readers", {}):
+            if st != cur:
                 side.wait_stream(st)
         with torch.cuda.stream(side):
             L.check(self._lib.i2sdf_pack_weights(self._plan, L.ptr(flat_params), L.ptr(self.packed), L.stream_ptr()), "i2sdf_pack_weights")
@@ -156,10 +162,12 @@ class RenderEngine:
         ev = self._pack_event
         if ev is not None:
             cur = torch.cuda.current_stream(self.packed.device)
+            # keyed on the torch Stream OBJECT (hashable; the dict keeps it alive until the next pack): a raw handle can be reused by a
+            # new stream after its owner was destroyed, and that stream would be mistaken for one that has already waited
             readers = self.__dict__.setdefault("_pack_readers", {})
-            if cur.cuda_stream not in readers:
+            if cur not in readers:
                 cur.wait_event(ev)
-                readers[cur.cuda_stream] = cur
+                readers[cur] = True
         return L.ptr(self.packed)
 
     def set_sdf_forward_bf16x3(self, on: bool):
@@ -194,6 +202,12 @@ class RenderEngine:
         operand -- above the reference's own `float32_matmul_precision('medium')`, below fp32; the gradients stay inside the 1e-4 bar."""
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_WGRAD_BF16X2, int(bool(on))), "i2sdf_plan_set_option")
         self.wgrad_bf16x2 = bool(on)
+
+    def set_sampler_bf16x2(self, on: bool):
+        """The sampler's sdf-only passes (i2sdf_sample_rays, i2sdf_render_image) with two split planes / three products
+        (I2SDF_OPT_SAMPLER_BF16X2): they choose depths; every returned value still comes from the fp32-equivalent kernels."""
+        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SAMPLER_BF16X2, int(bool(on))), "i2sdf_plan_set_option")
+        self.sampler_bf16x2 = bool(on)
 
     def set_blocked_saves(self, on: bool):
         """Saved 256-wide tensors of the bf16x3 full workgroups in the blocked layout (I2SDF_OPT_BLOCKED_SAVES, csrc/mlp_common.h).
@@ -285,6 +299,11 @@ class RenderEngine:
     def pad_rows(M: int) -> int:
         return (M + 127) // 128 * 128
 
+    def _ws(self, *shape, device=None):
+        """A per-point workspace of Mp rows (include/i2sdf.h: the kernels may write its padding rows M..Mp, never a row beyond Mp).
+        One allocation site, so that tests/test_gpu_edge_cases.py can hand out buffers with a canary block behind the last row."""
+        return torch.empty(*shape, dtype=torch.float32, device=device)
+
     def sdf_forward_grad(self, points=None, rays=None, want_grad=True, save=True, want_feat=True):
         """Point batch = [points generated from rays=(cam (B,3), dirs (B,3), z (B,n)) | explicit points (P,3)]; either may be None.
         Returns dict(sdf, feat, grad, hs, abars, pe, Mp, M, n_ray_pts)."""
@@ -304,11 +323,11 @@ class RenderEngine:
         Mp = self.pad_rows(M)
         out = {"Mp": Mp, "M": M, "n_ray_pts": n_ray, "pts": pts, "rays": (cam, dirs, z, npr), "sdf": torch.empty(M, 1, dtype=torch.float32, device=dev),
                "blk": self.blocked_points(0, M, Mp, want_feat)}         # leading points of hs / abars in the blocked layout
-        out["feat"] = torch.empty(Mp, self.F, dtype=torch.float32, device=dev) if want_feat else None
+        out["feat"] = self._ws(Mp, self.F, device=dev) if want_feat else None
         out["grad"] = torch.empty(M, 3, dtype=torch.float32, device=dev) if want_grad else None
-        out["hs"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save or want_grad) else None
-        out["abars"] = torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev) if (save and want_grad) else None
-        out["pe"] = torch.empty(Mp, 40, dtype=torch.float32, device=dev) if save else None
+        out["hs"] = self._ws(NL - 1, Mp, H, device=dev) if (save or want_grad) else None
+        out["abars"] = self._ws(NL - 1, Mp, H, device=dev) if (save and want_grad) else None
+        out["pe"] = self._ws(Mp, 40, device=dev) if save else None
         L.check(self._lib.i2sdf_sdf_forward_grad(self._plan, self._pk(), L.ptr(pts), L.ptr(cam), L.ptr(dirs), L.ptr(z),
                                                   ldz, npr, n_ray, M, Mp, L.ptr(out["sdf"]), L.ptr(out["feat"]), L.ptr(out["grad"]),
                                                   L.ptr(out["hs"]), L.ptr(out["abars"]), L.ptr(out["pe"]), L.stream_ptr()),
@@ -319,8 +338,8 @@ class RenderEngine:
         Mp = feat.shape[0]
         rgb = torch.empty(M, 3, dtype=torch.float32, device=feat.device)
         Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
-        rs = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=feat.device) if save else None
-        pev = torch.empty(Mp, 32, dtype=torch.float32, device=feat.device) if save else None
+        rs = self._ws(Lr - 1, Mp, Hr, device=feat.device) if save else None
+        pev = self._ws(Mp, 32, device=feat.device) if save else None
         L.check(self._lib.i2sdf_rgb_forward(self._plan, self._pk(), L.ptr(dirs.contiguous()), n_per_ray, L.ptr(feat), M, Mp,
                                              L.ptr(rgb), L.ptr(rs), L.ptr(pev), L.stream_ptr()), "i2sdf_rgb_forward")
         return rgb, rs, pev
@@ -328,9 +347,9 @@ class RenderEngine:
     def rgb_backward(self, rgb, rgb_bar, rs, M):
         Mp, dev = rs.shape[1], rs.device
         Lr, Hr = self.cfg.rgb.n_lin, self.cfg.rgb.hidden
-        gar = torch.empty(Lr - 1, Mp, Hr, dtype=torch.float32, device=dev)
-        ga_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
-        fbar = torch.empty(Mp, self.F, dtype=torch.float32, device=dev)
+        gar = self._ws(Lr - 1, Mp, Hr, device=dev)
+        ga_last = self._ws(Mp, 4, device=dev)
+        fbar = self._ws(Mp, self.F, device=dev)
         L.check(self._lib.i2sdf_rgb_backward(self._plan, self._pk(), L.ptr(rgb), L.ptr(rgb_bar.contiguous()), L.ptr(rs), M, Mp,
                                               L.ptr(gar), L.ptr(ga_last), L.ptr(fbar), L.stream_ptr()), "i2sdf_rgb_backward")
         return gar, ga_last, fbar
@@ -341,9 +360,8 @@ class RenderEngine:
         H, NL = cfgs.hidden, cfgs.n_lin
         Mp, M, dev = fw["Mp"], fw["M"], fw["hs"].device
         cam, dirs, z, npr = fw["rays"]
-        o = {"gus": torch.empty(NL, Mp, H, dtype=torch.float32, device=dev), "gpbar": torch.empty(Mp, 40, dtype=torch.float32, device=dev),
-             "gas": torch.empty(NL - 1, Mp, H, dtype=torch.float32, device=dev), "ga_last4": torch.empty(Mp, 4, dtype=torch.float32, device=dev),
-             "ones4": torch.empty(Mp, 4, dtype=torch.float32, device=dev)}
+        o = {"gus": self._ws(NL, Mp, H, device=dev), "gpbar": self._ws(Mp, 40, device=dev), "gas": self._ws(NL - 1, Mp, H, device=dev),
+             "ga_last4": self._ws(Mp, 4, device=dev), "ones4": self._ws(Mp, 4, device=dev)}
         c = lambda t: None if t is None else t.contiguous()
         L.check(self._lib.i2sdf_sdf_backward(self._plan, self._pk(), L.ptr(fw["pts"]), L.ptr(cam), L.ptr(dirs), L.ptr(z),
                                               z.shape[1] if z is not None else 0, npr, fw["n_ray_pts"], M, Mp,
@@ -542,15 +560,15 @@ class RenderEngine:
         Mp, dev = feat.shape[0], feat.device
         HL = self.cfg.light.hidden
         lm = torch.empty(M, dtype=torch.float32, device=dev)
-        hl = torch.empty(Mp, HL, dtype=torch.float32, device=dev) if save else None
+        hl = self._ws(Mp, HL, device=dev) if save else None
         L.check(self._lib.i2sdf_light_forward(self._plan, self._pk(), L.ptr(feat), M, Mp, L.ptr(lm), L.ptr(hl), L.stream_ptr()),
                  "i2sdf_light_forward")
         return lm, hl
 
     def light_backward(self, lm, lm_bar, hl, M):
         Mp, dev = hl.shape[0], hl.device
-        gal0 = torch.empty(Mp, hl.shape[1], dtype=torch.float32, device=dev)
-        gal_last = torch.empty(Mp, 4, dtype=torch.float32, device=dev)
+        gal0 = self._ws(Mp, hl.shape[1], device=dev)
+        gal_last = self._ws(Mp, 4, device=dev)
         L.check(self._lib.i2sdf_light_backward(self._plan, self._pk(), L.ptr(lm), L.ptr(lm_bar.contiguous()), L.ptr(hl), M, Mp,
                                                 L.ptr(gal0), L.ptr(gal_last), L.stream_ptr()), "i2sdf_light_backward")
         return gal0, gal_last

@@ -72,6 +72,7 @@ OPT_TAIL_OVERLAP = 32
 OPT_BLOCKED_SAVES = 128
 OPT_WGRAD_BF16X2 = 256
 OPT_PARTS = 512
+OPT_SAMPLER_BF16X2 = 1024
 MAX_PARTS = 4
 GRID_ORDER_MESHGRID, GRID_ORDER_VOLUME = 0, 1
 

@@ -102,9 +102,13 @@ class I2SDFLoss(nn.Module):
             gtc.pop("light_mask", None)
         import ctypes as C
         dev = out["rgb_values"].device
-        key = (dev, torch.cuda.current_stream(dev).cuda_stream)      # calls in flight on different streams must not share the workspace
+        # calls in flight on different streams must not share the workspace.  Keyed on the Stream OBJECT (a raw handle can be reused by a
+        # later stream -- ADVICE r5) and bounded: a caller that makes a new stream per step does not grow the table
+        key = (dev, torch.cuda.current_stream(dev))
         scratch = self._scratch.get(key)
         if scratch is None:
+            if len(self._scratch) >= 8:
+                self._scratch.pop(next(iter(self._scratch)))
             scratch = self._scratch[key] = torch.empty(int(L.load().i2sdf_loss_scratch_floats()), dtype=torch.float32, device=dev)
         total, vec = _FusedLossFn.apply(C.byref(cfg), 0 if surf is None else surf.shape[0], gtc, scratch, out["rgb_values"], out["depth_values"],
                                  out["weight_sum"].reshape(-1), out.get("normal_values"), out.get("grad_theta"), out.get("diff_norm"),

@@ -125,6 +125,14 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   by another range's next kernel instead of idling -- which replaces the split-K tail workgroups (none in this mode: every point
  *   goes through the full-workgroup kernels and every saved tensor is blocked throughout).  Results do not depend on n.  Default 0. */
 #define I2SDF_OPT_PARTS 512
+/*   I2SDF_OPT_SAMPLER_BF16X2 (256-wide nets with I2SDF_OPT_SDF_FWD_BF16X3): the sdf-only passes INSIDE i2sdf_sample_rays and
+ *   i2sdf_render_image -- the evaluations the error-bounded sampler chooses its depths from (ray_sampler.py:83-95, under no_grad) --
+ *   split every operand into TWO bf16 terms and accumulate the three leading products (per-product error <= 3 * 2^-18): half the MFMAs
+ *   of the bf16x3 form.  No returned value is computed from these passes (sdf, colours, gradients at the chosen depths come from the
+ *   fp32-equivalent kernels); what changes is WHERE the samples sit, by a perturbation of the sdf of ~1e-5 relative -- well inside what
+ *   the reference itself computes them with on its GPU (torch.set_float32_matmul_precision('medium'), main_recon.py:61).
+ *   i2sdf_sdf_forward and i2sdf_sdf_grid (values that are returned) keep three planes.  Default 0. */
+#define I2SDF_OPT_SAMPLER_BF16X2 1024
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset

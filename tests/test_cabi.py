@@ -113,6 +113,33 @@ def test_entry_points_validate_arguments_without_a_gpu(lib):
     h.i2sdf_plan_destroy(plan)
 
 
+def test_per_point_workspaces_need_whole_workgroups_of_rows(lib):
+    """The per-point workspaces (hs, abars, gus, gas, rs, gar, feat ...) have Mp rows, Mp = M rounded up to 128: the kernels run whole
+    128-point workgroups and since round 5 WRITE the padding rows M..Mp of the saved tensors unconditionally (include/i2sdf.h).  A caller
+    that sized a workspace to exactly M rows would be written past its end -- every per-point entry point refuses such an Mp before it
+    launches anything (validation only: no call below reaches a launch)."""
+    from i2sdf_amd.config import synthetic_conf
+    h = lib.load()
+    rc, plan, _, _ = _plan(lib, synthetic_conf(True))
+    assert rc == 0
+    P = C.c_void_p(4096)
+    for M in (1, 127, 129, 51201):
+        good = (M + 127) // 128 * 128
+        for Mp in sorted({M, good - 1, good - 128, good + 64} - {good}):
+            if Mp == M and M % 128 == 0:
+                continue
+            assert h.i2sdf_sdf_forward_grad(plan, P, P, None, None, None, 0, 1, 0, M, Mp, P, P, P, P, P, P, None) == -1, (M, Mp)
+            assert h.i2sdf_sdf_backward(plan, P, P, None, None, None, 0, 1, 0, M, Mp, P, P, P, P, M, P, P, P, P, P, P, None) == -1, (M, Mp)
+            assert h.i2sdf_rgb_forward(plan, P, P, 1, P, M, Mp, P, P, P, None) == -1, (M, Mp)
+            assert h.i2sdf_rgb_backward(plan, P, P, P, P, M, Mp, P, P, P, None) == -1, (M, Mp)
+            assert h.i2sdf_light_forward(plan, P, P, M, Mp, P, P, None) == -1, (M, Mp)
+            assert h.i2sdf_light_backward(plan, P, P, P, P, M, Mp, P, P, None) == -1, (M, Mp)
+            tb = lib.TrainBuffers()
+            tb.M_sdf, tb.M_main, tb.Mp = M, 0, Mp
+            assert h.i2sdf_weight_grads(plan, C.byref(tb), P, P, 1, P, None) == -1, (M, Mp)
+    h.i2sdf_plan_destroy(plan)
+
+
 def test_plan_options(lib):
     """i2sdf_plan_set_option: the bf16x3 twins exist for 256-wide nets only; unknown options are rejected."""
     from i2sdf_amd.config import synthetic_conf, plumbing_conf
@@ -141,7 +168,7 @@ def test_new_plan_options_and_blocked_prefix(lib):
     h = lib.load()
     rc, plan, _, _ = _plan(lib, synthetic_conf())
     assert rc == 0
-    for opt in (lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2):
+    for opt in (lib.OPT_BLOCKED_SAVES, lib.OPT_WGRAD_BF16X2, lib.OPT_SAMPLER_BF16X2):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0 and h.i2sdf_plan_set_option(plan, opt, 0) == 0
     assert h.i2sdf_plan_set_option(plan, 64, 1) != 0           # (the LDS source ring of rounds 2-3 is gone)
     for opt in (lib.OPT_TRAIN_FWD_BF16X3, lib.OPT_SDF_BWD_BF16X3, lib.OPT_RGB_BF16X3, lib.OPT_TAIL_OVERLAP):
@@ -179,6 +206,7 @@ def test_new_plan_options_and_blocked_prefix(lib):
     assert rc == 0
     h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1)
     assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SAMPLER_BF16X2, 1) == -1      # the two-plane sampler stream exists for 256-wide nets only
     h.i2sdf_plan_destroy(plan)
 
 

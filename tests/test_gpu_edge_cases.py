@@ -123,3 +123,97 @@ def test_ray_batcher_rejects_bad_indices():
     t_, i_, sample, gt = rb.batch(torch.tensor([0, 7, n * H * W + 5, -3], device="cuda"))   # device indices: clamped + counted
     assert rb.bad_indices() == 2
     assert torch.isfinite(gt["rgb"]).all() and int(i_.max()) <= n - 1 and int(i_.min()) >= 0
+
+
+# ---- the padding-row contract of the per-point workspaces (include/i2sdf.h; round 5 made the saved-tensor stores of padding lanes unconditional) ----
+CANARY = 0x7FC0BEEF          # a quiet NaN with a payload nobody computes
+
+
+def _canary_engine(conf, sd):
+    """An engine whose per-point workspaces carry a canary block of 128 rows behind their last row (engine._ws is the one allocation site)."""
+    import torch
+    from test_gpu_train_forward import make_engine
+    eng = make_engine(conf, sd)
+    eng._canaries = []
+
+    def ws(*shape, device=None):
+        n = 1
+        for s_ in shape:
+            n *= s_
+        tail = 128 * shape[-1]
+        buf = torch.empty(n + tail, dtype=torch.float32, device=device)
+        buf[n:].view(torch.int32).fill_(CANARY)
+        eng._canaries.append((shape, buf, n))
+        return buf[:n].view(*shape)
+
+    eng._ws = ws
+    return eng
+
+
+def _poison_padding(t, M, blocked):
+    """NaN into rows M..Mp of a saved (layers, Mp, 256) tensor (rows in the blocked layout for the first `blocked` points)."""
+    Lr, Mp, H = t.shape
+    if M >= Mp:
+        return
+    nan = float("nan")
+    if blocked >= Mp:
+        v = t.view(Lr, Mp // 32, 16, 32, 16)
+        b0 = M // 32
+        v[:, b0, :, M % 32:, :] = nan
+        v[:, b0 + 1:] = nan
+    else:
+        assert blocked == 0
+        t[:, M:] = nan
+
+
+@pytest.mark.parametrize("M", [1, 127, 129, 51201])
+def test_padding_rows_may_be_written_but_nothing_beyond_them_and_nobody_reads_them(M, wgrad_mode):
+    """Forward with saves, d sdf/dx chain, radiance forward / backward, both sweeps and the weight gradients at point counts around the
+    128-point workgroup: (1) no kernel writes behind row Mp of any workspace (canary block), (2) the padding rows M..Mp are never READ --
+    poisoned with NaN between the producers and every consumer, all gradients stay finite and bitwise equal to the unpoisoned run."""
+    from i2sdf_amd.config import synthetic_conf
+    ocfg, conf = orc.synthetic_cfg(False), synthetic_conf(False)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=61), 0.05, seed=62)
+    n = 1
+    g = torch.Generator().manual_seed(M)
+    x = ((torch.rand(M, 3, generator=g) * 2 - 1) * 1.2).cuda()
+    dirs = torch.nn.functional.normalize(torch.randn(M, 3, generator=g), dim=1).cuda()
+    cw = torch.randn(M, 3, generator=g).cuda()
+    sw = torch.randn(M, generator=g).cuda()
+    results = []
+    for poison in (False, True):
+        eng = _canary_engine(conf, sd)
+        flat = eng.layout.flat_from_state_dict(sd).cuda()
+        fwd = eng.sdf_forward_grad(points=x)
+        rgb, rs, pev = eng.rgb_forward(dirs, n, fwd["feat"], M)
+        Mp = fwd["Mp"]
+        assert Mp == (M + 127) // 128 * 128
+        blk_s, blk_r = eng.blocked_points(0, M, Mp), eng.blocked_points(1, M, Mp)
+        if poison:
+            for t_ in (fwd["hs"], fwd["abars"]):
+                _poison_padding(t_, M, blk_s)
+            _poison_padding(rs, M, blk_r)
+            fwd["feat"][M:] = float("nan"); fwd["pe"][M:] = float("nan"); pev[M:] = float("nan")
+        gar, ga_last, fbar = eng.rgb_backward(rgb, cw, rs, M)
+        nvec = fwd["grad"]
+        nn_ = nvec.norm(dim=1, keepdim=True)
+        nbar = 2 * (nn_ - 1) * nvec / nn_
+        if poison:
+            _poison_padding(gar, M, blk_r)
+            fbar[M:] = float("nan"); ga_last[M:] = float("nan")
+        bw = eng.sdf_backward(fwd, sbar=sw, fbar=fbar, m_fbar=M, nbar=nbar)
+        if poison:
+            _poison_padding(bw["gus"], M, blk_s); _poison_padding(bw["gas"], M, blk_s)
+            for k in ("gpbar", "ga_last4", "ones4"):
+                bw[k][M:] = float("nan")
+        gflat = torch.zeros_like(flat)
+        eng.weight_grads(flat, gflat, fwd, bw, M_main=M, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
+        torch.cuda.synchronize()
+        assert len(eng._canaries) >= 14
+        for shape, buf, n_used in eng._canaries:
+            tail = buf[n_used:].view(torch.int32)
+            assert bool((tail == CANARY).all()), f"workspace {shape}: {int((tail != CANARY).sum())} words written behind row Mp = {Mp} (M = {M})"
+        assert torch.isfinite(gflat).all(), f"M = {M}, poisoned = {poison}: a consumer read a padding row"
+        assert torch.isfinite(fwd["sdf"]).all() and torch.isfinite(fwd["grad"]).all() and torch.isfinite(rgb).all()
+        results.append(gflat.clone())
+    assert torch.equal(results[0], results[1]), "gradients depend on the contents of the padding rows"

@@ -74,3 +74,33 @@ def test_sdf_forward_bf16x3(which):
     e3 = assert_close(x3[idx], ref, 1e-5, "sdf (bf16x3)")
     print(f"max-norm relative error vs fp64: fp32 MFMA {e32:.2e}, bf16x3 {e3:.2e}")
     assert_close(x3, f32, 1e-5, "bf16x3 vs fp32 kernel, all points")
+
+
+@pytest.mark.parametrize("light", [False, True])
+def test_implicit_network_call_returns_257_columns(light):
+    """`net.implicit_network(x)` -- what the unchanged meshing callers use (model/eval/recon.py:51,90; utils/plots.py:52) -- returns
+    [sdf | feature] rows; since round 6 on the 16-point-wave bf16x3 kernel of the training forward (mlp_fwd.hip: launch_sdf_fwd).  All 257
+    columns against the fp64 oracle at 1e-5, at a size with several workgroups and a ragged tail, both arithmetic forms, and the sdf
+    column against the sdf-only kernel (the sampler's / i2sdf_sdf_grid's)."""
+    from i2sdf_amd import I2SDFNetwork
+    from i2sdf_amd.config import synthetic_conf
+    ocfg = orc.synthetic_cfg(light)
+    sd = orc.perturb_params(orc.init_params(ocfg, seed=3), 0.05, seed=4)
+    net = I2SDFNetwork(synthetic_conf(light))
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    M = 5 * 128 + 77
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(M, 3, generator=g) * 2 - 1) * 2.5
+    ref = orc.sdf_forward({k: v.double() for k, v in sd.items()}, ocfg.sdf, x.double())
+    eng = net._engine_for(torch.device("cuda:0"))
+    outs = {}
+    for x3 in (True, False):
+        eng.set_sdf_forward_bf16x3(x3)
+        out = net.implicit_network(x.cuda())
+        assert out.shape == (M, 257) and out.is_contiguous()
+        assert_close(out.cpu(), ref, 1e-5, f"implicit_network(x), bf16x3={x3}")
+        outs[x3] = out
+    eng.set_sdf_forward_bf16x3(True)
+    assert_close(outs[True][:, :1].cpu(), net.implicit_network.get_sdf_vals(x.cuda()).cpu(), 1e-5, "sdf column vs the sdf-only kernel")
+    assert_close(outs[True].cpu(), outs[False].cpu(), 1e-5, "bf16x3 vs fp32 MFMA")

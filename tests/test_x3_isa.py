@@ -10,7 +10,10 @@ instructions actually emitted ever disagree in the unsafe direction, a stage cou
      only waits longer -- but it drains the pipeline),
   2. the counted barriers are single asm statements `s_waitcnt vmcnt(N); s_barrier` with an immediate N (no jump table),
   3. a good share of them have N > 0 (the optimisation is alive), and
-  4. N never exceeds the vector-memory instructions emitted between the previous stage's barrier and this one that can be young at all."""
+  4. N never exceeds the vector-memory instructions EMITTED BEHIND THE STAGE'S LAST DMA PIECE (`buffer_load ... lds`) -- the invariant the
+     protocol needs (round 6; the round-5 form of this check counted from the previous barrier, which includes the pieces and whatever was
+     issued before them: a plain global access hoisted above the last piece by the scheduler would have gone unnoticed -- ADVICE r5; the
+     sources now fence the last piece with sched_barrier(0)), in the 32-point kernels (mlp_x3.o) AND the 16-point ones (mlp_x3h.o)."""
 import os
 import re
 import shutil
@@ -20,19 +23,23 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "i2sdf_amd", "csrc")
-KERNELS = {"sdf_igrad3_kernel": 6, "sdf_bwd3_sweep1_kernel": 12, "sdf_bwd3_sweep2_kernel": 12}      # name -> minimum number of counted barriers
+KERNELS = {"sdf_igrad3_kernel": 6, "sdf_bwd3_sweep1_kernel": 12, "sdf_bwd3_sweep2_kernel": 12}      # name -> minimum number of barriers with N > 0
+# the 16-point-wave kernels (x3h.h: dense_x3h): the sources that issue global loads ahead (radiance backward: saved activations; radiance forward:
+# feature rows; light head) carry N = 2 waits, the forward kernels' sources issue nothing unconditionally (N = 0 everywhere)
+KERNELS_H = {"rgb_bwd3h_kernel": 6, "rgb_fwd3h_kernel": 1, "light_fwd3h_kernel": 1, "sdf_train_fwd3h_kernel": 0, "sdf_fwd3h_kernel": 0}
 
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 OBJ = os.path.join(ROOT, "i2sdf_amd", "lib", "obj", "mlp_x3.o")
+OBJ_H = os.path.join(ROOT, "i2sdf_amd", "lib", "obj", "mlp_x3h.o")
 
 
-def _disassemble_in_tree(tmp):
+def _disassemble_in_tree(tmp, OBJ=OBJ, src="mlp_x3.hip"):
     """The device code of the in-tree build (seconds); None if there is none or it is older than the sources."""
     if not os.path.exists(OBJ) or not all(os.path.exists(f"{LLVM}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
         return None
     import glob
-    if any(os.path.getmtime(f) > os.path.getmtime(OBJ) for f in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, "mlp_x3.hip")]):
+    if any(os.path.getmtime(f) > os.path.getmtime(OBJ) for f in glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(CSRC, src)]):
         return None
     fat, co = os.path.join(tmp, "x3.fatbin"), os.path.join(tmp, "x3.co")
     if subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", OBJ], capture_output=True).returncode != 0:
@@ -94,18 +101,17 @@ def _insn(ln):
 
 
 VMEM = re.compile(r"^(global_load|global_store|buffer_load|buffer_store|scratch_load|scratch_store|flat_load|flat_store)")
+WAIT = re.compile(r"\s*s_waitcnt\s+vmcnt\((\d+)\)(\s+lgkmcnt\(0\))?\s*$")
 
 
-def test_stage_barriers_carry_counted_waits(isa):
-    text, from_objdump = isa
-    bodies = _bodies(text)
-    for key, min_counted in KERNELS.items():
+def _check_counted_barriers(bodies, kernels, from_objdump, min_barriers=20):
+    for key, min_counted in kernels.items():
         names = [n for n in bodies if key in n]
         assert names, f"{key} not found in the ISA"
         for name in names:
             body = bodies[name]
-            counted, since_barrier, nbar, nasm, in_asm = 0, 0, 0, 0, False
-            last_wait, prev_op_wait = None, None
+            counted, since_piece, nbar, nasm, in_asm, npieces = 0, 0, 0, 0, False, 0
+            last_wait, prev_wait = None, None
             for ln in body:
                 if "#ASMSTART" in ln:
                     in_asm, last_wait = True, None
@@ -116,28 +122,45 @@ def test_stage_barriers_carry_counted_waits(isa):
                 op = _insn(ln)
                 if not op:
                     continue
+                code = ln.split(";")[0].split("//")[0]
                 if VMEM.match(op):
-                    since_barrier += 1
-                m = re.match(r"\s*s_waitcnt\s+vmcnt\((\d+)\)\s*$", ln.split(";")[0])
-                if in_asm and m:
+                    if op.startswith("buffer_load") and re.search(r"\blds\b", code):
+                        since_piece = 0          # a DMA piece of the NEXT stage: what the counted wait of the next barrier must cover
+                        npieces += 1
+                    else:
+                        since_piece += 1
+                m = WAIT.match(code)
+                # the counted form (common.h: wait_barrier<N>) is ONE asm statement `s_waitcnt vmcnt(N) lgkmcnt(0); s_barrier`: in a listing
+                # it sits between the ASM markers, in a disassembly the wait is the instruction directly in front of the barrier
+                if in_asm and m and m.group(2):
                     last_wait = int(m.group(1))
                 if op == "s_barrier":
                     nbar += 1
-                    # the counted form (common.h: wait_barrier<N>) is ONE asm statement: in a listing it sits between the ASM markers, in a
-                    # disassembly the wait (vmcnt only) is the instruction directly in front of the barrier
-                    n = last_wait if in_asm else (prev_op_wait if from_objdump else None)
+                    n = last_wait if in_asm else (prev_wait if from_objdump else None)
                     if n is not None:
                         nasm += 1
-                        # whatever may still be in flight was issued after the previous barrier (everything older was drained or counted there)
-                        assert n <= since_barrier, \
-                            f"{name}: barrier #{nbar} allows {n} instructions in flight, only {since_barrier} were issued since the last barrier"
+                        assert n <= since_piece, \
+                            f"{name}: barrier #{nbar} lets {n} vector-memory instructions fly, only {since_piece} were emitted behind the stage's last DMA piece"
                         counted += n > 0
-                    since_barrier = 0
-                prev_op_wait = int(m.group(1)) if m else None
-            assert nbar >= 20 and nasm >= nbar // 2, (name, nbar, nasm)
-            assert counted >= min_counted, f"{name}: only {counted} of {nbar} stage barriers carry a counted wait"
+                prev_wait = int(m.group(1)) if (m and m.group(2)) else None
+            assert npieces >= 8, (name, npieces)
+            assert nbar >= min_barriers and nasm >= nbar // 2, (name, nbar, nasm)
+            assert counted >= min_counted, f"{name}: only {counted} of {nbar} stage barriers carry a counted wait with N > 0"
             # no jump table left from advance_barrier_young's switch
             assert not any("s_setpc_b64" in ln for ln in body), f"{name}: indirect branch in the kernel body"
+
+
+def test_stage_barriers_carry_counted_waits(isa):
+    text, from_objdump = isa
+    _check_counted_barriers(_bodies(text), KERNELS, from_objdump)
+
+
+def test_stage_barriers_of_the_16_point_kernels(tmp_path):
+    """The same invariant on mlp_x3h.o (in-tree object only: the 32-point fixture above covers the compile-from-source fallback)."""
+    text = _disassemble_in_tree(str(tmp_path), OBJ_H, "mlp_x3h.hip")
+    if text is None:
+        pytest.skip("no fresh in-tree mlp_x3h.o: run __graft_entry__.build()")
+    _check_counted_barriers(_bodies(text), KERNELS_H, True, min_barriers=8)
 
 
 def test_no_scratch_in_the_counted_kernels(isa):
