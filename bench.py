@@ -232,8 +232,12 @@ class Workload:
             self.fence()
             dts.append(time.perf_counter() - t0)
         t = torch.tensor(dts, dtype=torch.float64, device=self.dev)
+        dts_min = None
         if self.world > 1:
+            tmin = t.clone()
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            torch.distributed.all_reduce(tmin, op=torch.distributed.ReduceOp.MIN)      # the fastest rank's view of the same windows: a straggler shows as a spread
+            dts_min = [float(x) for x in tmin.tolist()]
         dts = [float(x) for x in t.tolist()]
         ktimes, prof_steps = None, 0
         if timing and profile_steps > 0:
@@ -248,7 +252,7 @@ class Workload:
             ktimes, prof_steps = eng.stop_timing(), profile_steps
             eng.use_chain = True
         med = sorted(dts)[len(dts) // 2]
-        return {"dt": med, "dts": dts, "loss": float(loss.item()), "iters": int(net.last_sampler_iters.item()) if not dense else 0,
+        return {"dt": med, "dts": dts, "dts_rank_min": dts_min, "loss": float(loss.item()), "iters": int(net.last_sampler_iters.item()) if not dense else 0,
                 "ktimes": ktimes, "prof_steps": prof_steps, "eng": eng}
 
 
@@ -586,6 +590,16 @@ def main():
                                 "ms_per_step": round(strong["dt"] / K * 1e3, 4), "windows_ms_per_step": [round(x / K * 1e3, 4) for x in strong["dts"]],
                                 "us_per_ray": round(strong["dt"] / K / Bs * 1e6, 4), "global_rays": Bs * world, "rays_per_gpu": Bs, "n_gpus": world}
             result["us_per_ray"] = round(dt / K / head_B * 1e6, 4)
+        if world > 1:
+            # one line must show a straggler or a transport fallback: the same windows as seen by the slowest and the fastest
+            # rank, and the rank count the library's RCCL communicator itself reports (None: torch.distributed carried the collective)
+            mins = head.get("dts_rank_min") or head["dts"]
+            comm = getattr(getattr(wl.net, "dp_state", None), "comm", None)
+            result["ranks"] = {"ms_per_step_slowest_rank": round(sorted(head["dts"])[len(head["dts"]) // 2] / K * 1e3, 4),
+                               "ms_per_step_fastest_rank": round(sorted(mins)[len(mins) // 2] / K * 1e3, 4),
+                               "windows_ms_per_step_fastest_rank": [round(x / K * 1e3, 4) for x in mins],
+                               "rccl_nranks": (comm.nranks() if comm is not None and hasattr(comm, "nranks") else None),
+                               "torch_world_size": dist.get_world_size(), "transport": "library RCCL communicator" if comm is not None else "torch.distributed (" + str(args.backend) + ")"}
         result.update(extras)
         if not args.no_extras and world == 1:
             result["eager_rocm_baseline"] = eager_rocm_baseline(dev, iters, n_shaded)

@@ -31,6 +31,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // these ops was the full vmcnt(0) drain at every stage barrier -- of the loads just issued and of the stage's stores -- hence the counted stage
 // wait below and the stash / flush scheme of the stores in dense_x3g
 constexpr int X3_AHEAD = 1, X3_RING = 2;
+// (a source may ask for more: `static constexpr int AHEAD` of the Src, ring of AHEAD + 1 slots -- sweep 2 reads three tensors per k-chunk)
+#ifndef X3_SW2_AHEAD
+#define X3_SW2_AHEAD 1
+#endif
+#ifndef X3_SW2_SHARE_E
+#define X3_SW2_SHARE_E 0
+#endif
 #ifndef X3_COUNTED_WAIT
 #define X3_COUNTED_WAIT 1
 #endif
@@ -117,9 +124,10 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     if (pk0 >= 0) { vm_young += src.done(pk0, sv[0], sx[0]); pk0 = -1; }
     if (pk1 >= 0) { vm_young += src.done(pk1, sv[1], sx[1]); pk1 = -1; }
   };
+  constexpr int AH = Src::AHEAD;
   auto prep = [&](int kc, int u, u32x4 (&b)[3]) __attribute__((always_inline)) {
     if (kc >= KC16) return;
-    if (u == 0 && kc + X3_AHEAD < KC16) vm_young += src.ahead(kc + X3_AHEAD);
+    if (u == 0 && kc + AH < KC16) vm_young += src.ahead(kc + AH);
     if (u < 8) v[u] = src.value(kc, u, vx[u]);
     else {
       if (u == 8 && Src::STORES) {
@@ -141,7 +149,7 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
     }
   };
 #pragma unroll
-  for (int k0 = 0; k0 < X3_AHEAD; ++k0)
+  for (int k0 = 0; k0 < AH; ++k0)
     if (k0 < KC16) (void)src.ahead(k0);
 #pragma unroll
   for (int u = 0; u < 12; ++u) prep(0, u, bq[0]);
@@ -239,12 +247,13 @@ __device__ __forceinline__ void dense_x3g(WStream& ws, Src& src, f32x16 (&acc_io
 template <int KC16, class Src>
 __device__ __forceinline__ void x3_drain(Src& src) {
   float v[8], vx[8];
+  constexpr int AH = Src::AHEAD;
 #pragma unroll
-  for (int k0 = 0; k0 < X3_AHEAD; ++k0)
+  for (int k0 = 0; k0 < AH; ++k0)
     if (k0 < KC16) (void)src.ahead(k0);
 #pragma unroll
   for (int kc = 0; kc < KC16; ++kc) {
-    if (kc + X3_AHEAD < KC16) (void)src.ahead(kc + X3_AHEAD);
+    if (kc + AH < KC16) (void)src.ahead(kc + AH);
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = src.value(kc, u, vx[u]);
     (void)src.done(kc, v, vx);
@@ -258,6 +267,7 @@ template <int NT, int KACC, int NPE, bool ST = true>
 struct X3FwdSrc {
   static constexpr bool STORES = ST;             // ST = false: no saved tensor at all (sampler / sdf-only queries)
   static constexpr bool COUNTED = false;
+  static constexpr int AHEAD = X3_AHEAD;
   const f32x16 (&accP)[NT]; const float (&pe)[NPE]; float* hrow; int hi; bool valid; int kcs = 16;
   __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) {
@@ -277,6 +287,7 @@ template <int NREG>
 struct X3RegSrc {
   static constexpr bool STORES = false;
   static constexpr bool COUNTED = false;
+  static constexpr int AHEAD = X3_AHEAD;
   const float (&r)[NREG];
   __device__ __forceinline__ int ahead(int) { return 0; }
   __device__ __forceinline__ float value(int kc, int u, float&) { return r[8 * kc + u]; }
@@ -288,6 +299,7 @@ template <int NT, bool UNC = false>
 struct X3RevSrc {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = UNC;
+  static constexpr int AHEAD = X3_AHEAD;
   const f32x16 (&accP)[NT]; const float* hrow; float* abrow; int hi; bool valid; int kcs = 16;
   f32x4 hq[X3_RING][2];
   // ahead(): returns the number of vector-memory instructions it issues unconditionally (dense_x3g's counted stage wait)
@@ -345,6 +357,7 @@ template <int NT, int KACC, int NREG>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
+  static constexpr int AHEAD = X3_AHEAD;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; float* gurow; int hi; int kcs = 16;
   f32x4 hq[X3_RING][2];
@@ -369,24 +382,33 @@ template <int NT, bool TOP>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
+  static constexpr int AHEAD = X3_SW2_AHEAD, RING = AHEAD + 1;     // three tensors per k-chunk: the loads of AHEAD k-chunks in flight per wave
   const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
-  f32x4 hq[X3_RING][2], gq[X3_RING][2], aq[X3_RING][2], wq[X3_RING][2];
+  f32x4 hq[RING][2], gq[RING][2], aq[RING][2], wq[RING][2];
   __device__ __forceinline__ int ahead(int kc) {
-    x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs); x3_load8(gurow, kc, hi, gq[kc % X3_RING], kcs); x3_load8(arow, kc, hi, aq[kc % X3_RING], kcs);
+    x3_load8(hrow, kc, hi, hq[kc % RING], kcs); x3_load8(gurow, kc, hi, gq[kc % RING], kcs); x3_load8(arow, kc, hi, aq[kc % RING], kcs);
     if (TOP) {
-      wq[kc % X3_RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
-      wq[kc % X3_RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
+      wq[kc % RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
+      wq[kc % RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
     }
     return TOP ? 8 : 6;
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     float x = accP[kc >> 1][8 * (kc & 1) + u];
-    if (TOP) x = fmaf(sb, wq[kc % X3_RING][u >> 2][u & 3], x);
-    const float sg = sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
-    const float ga = sg > 0.f ? gq[kc % X3_RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
-    const float g2 = ga * aq[kc % X3_RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
+    if (TOP) x = fmaf(sb, wq[kc % RING][u >> 2][u & 3], x);
+#if X3_SW2_SHARE_E
+    // e = exp(-100 h) once: sigma = 1 - e, and (1 - sigma) IS e (exact where the fp32 subtraction 1 - sigma only rounds it again)
+    const float e = __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc % RING][u >> 2][u & 3]);
+    const float sg = 1.0f - e;
+    const float ga = sg > 0.f ? gq[kc % RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
+    const float g2 = ga * aq[kc % RING][u >> 2][u & 3] * (100.f * e);
+#else
+    const float sg = sp_sigma_from_h(hq[kc % RING][u >> 2][u & 3]);
+    const float ga = sg > 0.f ? gq[kc % RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
+    const float g2 = ga * aq[kc % RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
+#endif
     return fmaf(x, sg, g2);
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
@@ -398,6 +420,7 @@ struct X3Sweep2Src {
 struct X3RowSrc {
   static constexpr bool STORES = false;
   static constexpr bool COUNTED = false;
+  static constexpr int AHEAD = X3_AHEAD;
   const float* row; int hi; bool on;
   f32x4 q[X3_RING][2];
   __device__ __forceinline__ int ahead(int kc) {

@@ -90,6 +90,10 @@ class RcclComm:
     def exchange(self) -> L.Exchange:
         return self._ex
 
+    def nranks(self) -> int:
+        """ranks of the RCCL communicator as the LIBRARY reports them (i2sdf_comm_size): what the collectives really span"""
+        return int(self._lib.i2sdf_comm_size(self._h)) if getattr(self, "_h", None) else 0
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.i2sdf_comm_destroy(self._h)

@@ -29,38 +29,26 @@ class RenderEngine:
         self.packed = torch.zeros(self.pack_floats, dtype=torch.float32, device=self.device)
         self._pack_stream, self._pack_event, self._pack_readers = None, None, {}
         self.F = cfg.feature_size
-        self.sdf_forward_bf16x3 = False
-        self.wgrad_bf16x3 = False
-        if cfg.bf16x3 and cfg.sdf.hidden % 64 == 0:
-            self.set_sdf_forward_bf16x3(True)
-        self.train_forward_bf16x3 = False
-        self.sdf_backward_bf16x3 = False
-        self.rgb_bf16x3 = False
-        if cfg.bf16x3:
-            self.set_wgrad_bf16x3(True)
-            if cfg.sdf.hidden == 256 and cfg.feature_size == 256:
-                self.set_train_forward_bf16x3(True)
-                self.set_sdf_backward_bf16x3(True)
-            if cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3:
-                self.set_rgb_bf16x3(True)
+        # every option is SET here, on or off: a fresh plan of a 256-wide net has the bf16x3 twins on by default since round 6 (plan.cpp)
+        wide = cfg.sdf.hidden == 256 and cfg.feature_size == 256
+        self.set_sdf_forward_bf16x3(bool(cfg.bf16x3 and cfg.sdf.hidden % 64 == 0))
+        self.set_wgrad_bf16x3(bool(cfg.bf16x3))
+        self.set_train_forward_bf16x3(bool(cfg.bf16x3 and wide))
+        self.set_sdf_backward_bf16x3(bool(cfg.bf16x3 and wide))
+        self.set_rgb_bf16x3(bool(cfg.bf16x3 and cfg.rgb.hidden == 256 and cfg.feature_size == 256 and cfg.rgb.n_lin >= 3))
         self.wgrad_bf16x2 = False
         # on by default since round 4 (config.py: wgrad_bf16x2; the whole GPU suite runs in both modes, tests/conftest.py);
         # I2SDF_WGRAD_BF16X2=0 / 1 overrides the conf; bench.py reports the fp32-equivalent form as the sub-record `wgrad_bf16x3`
         x2 = os.environ.get("I2SDF_WGRAD_BF16X2", "")
-        if cfg.bf16x3 and ((x2 != "0") if x2 != "" else cfg.wgrad_bf16x2):
-            self.set_wgrad_bf16x2(True)
+        self.set_wgrad_bf16x2(bool(cfg.bf16x3 and ((x2 != "0") if x2 != "" else cfg.wgrad_bf16x2)))
         # the sampler's sdf-only passes with two split planes (include/i2sdf.h: I2SDF_OPT_SAMPLER_BF16X2); conf `sampler_bf16x2`,
         # I2SDF_SAMPLER_BF16X2=0 / 1 overrides it
         self.sampler_bf16x2 = False
         sx2 = os.environ.get("I2SDF_SAMPLER_BF16X2", "")
-        if self.sdf_forward_bf16x3 and cfg.sdf.hidden == 256 and cfg.feature_size == 256 and ((sx2 != "0") if sx2 != "" else getattr(cfg, "sampler_bf16x2", False)):
-            self.set_sampler_bf16x2(True)
-        self.blocked_saves = False
-        if cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0":  # on by default; I2SDF_BLOCKED_SAVES=0 for A/B runs
-            self.set_blocked_saves(True)
-        self.tail_overlap = False
-        if os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0":      # on by default; I2SDF_TAIL_OVERLAP=0 for A/B runs
-            self.set_tail_overlap(True)
+        if wide:
+            self.set_sampler_bf16x2(bool(self.sdf_forward_bf16x3 and ((sx2 != "0") if sx2 != "" else getattr(cfg, "sampler_bf16x2", False))))
+        self.set_blocked_saves(bool(cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0"))      # I2SDF_BLOCKED_SAVES=0 for A/B runs
+        self.set_tail_overlap(os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0")                            # I2SDF_TAIL_OVERLAP=0 for A/B runs
         # point ranges on their own streams instead of split-K tail workgroups (include/i2sdf.h: I2SDF_OPT_PARTS); I2SDF_PARTS=0 for A/B runs
         self.parts = 0
         n_parts = int(os.environ.get("I2SDF_PARTS", "2"))
@@ -206,8 +194,10 @@ class RenderEngine:
     def set_sampler_bf16x2(self, on: bool):
         """The sampler's sdf-only passes (i2sdf_sample_rays, i2sdf_render_image) with two split planes / three products
         (I2SDF_OPT_SAMPLER_BF16X2): they choose depths; every returned value still comes from the fp32-equivalent kernels."""
-        L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SAMPLER_BF16X2, int(bool(on))), "i2sdf_plan_set_option")
-        self.sampler_bf16x2 = bool(on)
+        rc = self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SAMPLER_BF16X2, int(bool(on)))
+        if on or rc == 0:                      # (turning it OFF on a library build that predates the option is not an error: A/B runs)
+            L.check(rc, "i2sdf_plan_set_option")
+        self.sampler_bf16x2 = bool(on) and rc == 0
 
     def set_blocked_saves(self, on: bool):
         """Saved 256-wide tensors of the bf16x3 full workgroups in the blocked layout (I2SDF_OPT_BLOCKED_SAVES, csrc/mlp_common.h).

@@ -79,13 +79,16 @@ const char* i2sdf_last_hip_error(void);    /* thread-local text of the last HIP 
 int i2sdf_plan_create(const i2sdf_net_desc* desc, i2sdf_plan** out);
 void i2sdf_plan_destroy(i2sdf_plan* plan);
 /* Plan options (host side, takes effect on the next launch).
+ * Defaults (round 6): a plan of a 256-wide configuration is created with the five *_BF16X3 options, I2SDF_OPT_BLOCKED_SAVES and
+ * I2SDF_OPT_TAIL_OVERLAP ON (fp32-equivalent results from the kernels the parity tests and profiles cover), I2SDF_OPT_WGRAD_BF16X2,
+ * I2SDF_OPT_SAMPLER_BF16X2 and I2SDF_OPT_PARTS off; a 64-wide plan with everything off.  Value 0 selects the fp32-input MFMA form.
  *   I2SDF_OPT_SDF_FWD_BF16X3: evaluate the sdf-only forward (i2sdf_sdf_forward without features, and the SDF passes inside
  *   i2sdf_sample_rays) in bf16x3 split arithmetic: every fp32 operand is split into three bf16 terms and the six leading
  *   partial products are accumulated in fp32 on the bf16 matrix pipe -- results agree with the fp32 path to fp32 rounding
- *   level (same 1e-4 parity bar) at 3/8 of the matrix-pipe cycles.  Default 0 (plain fp32 MFMA). */
+ *   level (same 1e-4 parity bar) at 3/8 of the matrix-pipe cycles.  (0 = plain fp32 MFMA.) */
 #define I2SDF_OPT_SDF_FWD_BF16X3 1
 /*   I2SDF_OPT_WGRAD_BF16X3: the 256x256 blocks of i2sdf_weight_grads in the same split arithmetic (both operands are split
- *   on the fly); narrower blocks stay on the fp32 MFMA kernel.  Default 0. */
+ *   on the fly); the narrower blocks run the split form with three planes then, the fp32 MFMA kernel otherwise. */
 #define I2SDF_OPT_WGRAD_BF16X3 2
 /*   I2SDF_OPT_TRAIN_FWD_BF16X3: the full workgroups of i2sdf_sdf_forward_grad (256-wide nets) in the same arithmetic. */
 #define I2SDF_OPT_TRAIN_FWD_BF16X3 4
@@ -104,9 +107,7 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   layout [Mp/32][16 k-chunks][32 points][16 floats] for the points handled by the bf16x3 full workgroups (point-major for the
  *   rest): a wave instruction of the K-outer kernels then moves one contiguous 2 KB run instead of touching 32 rows 1 KB apart.
  *   Set it before the first i2sdf_sdf_forward_grad of a step and leave it unchanged through i2sdf_weight_grads; the tensors are
- *   opaque to the caller (i2sdf_blocked_points below gives the address formula for inspecting a copy).  Plan default 0; the Python
- *   engine (i2sdf_amd/engine.py) turns it ON for 256-wide nets, so C callers and Python callers see different layouts unless the C
- *   caller sets the option too. */
+ *   opaque to the caller (i2sdf_blocked_points below gives the address formula for inspecting a copy). */
 #define I2SDF_OPT_BLOCKED_SAVES 128
 /*   I2SDF_OPT_WGRAD_BF16X2 (needs I2SDF_OPT_WGRAD_BF16X3): the 256x256 weight-gradient blocks split every operand into TWO bf16
  *   terms and accumulate the three leading products a0b0 + a0b1 + a1b0 in fp32: per-product error <= 3 * 2^-18 (1.1e-5), i.e.

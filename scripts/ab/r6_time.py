@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Round-6 A/B timing: ONE process per library build (I2SDF_LIB_PATH), step time (k = 2, chained) and the un-chained entry-point times:
+
+  I2SDF_LIB_PATH=... python scripts/ab/r6_time.py [tag]          -> lines `tag step ...` / `tag entries ...`
+  python scripts/ab/r6_time.py implicit                         -> implicit_network(x) on 2^20 points: 257 columns vs sdf-only vs i2sdf_sdf_grid"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+
+from r4_time import make, batch, ev_time, step_fn
+from i2sdf_amd import I2SDFLoss, FusedAdam
+
+
+def main(tag):
+    net, dev = make()
+    net.force_iters = 2
+    loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05)
+    opt = FusedAdam(net, lr=5e-4, eps=1e-15)
+    inp, gt = batch(1024, dev)
+    step = step_fn(net, loss_fn, opt, inp, gt)
+    step()
+    eng = net._engine_for(dev)
+    for rnd in range(3):
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(40):
+            step()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 40
+        print(f"{tag} step round {rnd}: {dt * 1e3:7.3f} ms", flush=True)
+    short = {"i2sdf_weight_grads": "wgrad", "i2sdf_sdf_backward": "sdf_bwd", "i2sdf_sdf_forward_grad": "sdf_fwdg", "i2sdf_sample_rays": "sampler",
+             "i2sdf_rgb_forward": "rgb_f", "i2sdf_rgb_backward": "rgb_b"}
+    for rnd in range(2):
+        eng.use_chain = False
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        eng.start_timing()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        kt = eng.stop_timing()
+        eng.use_chain = True
+        print(f"{tag} entries round {rnd}: " + " ".join(f"{short[k]}={v[0] / 10:.3f}" for k, v in kt.items() if k in short), flush=True)
+
+
+def implicit():
+    net, dev = make()
+    net.eval()
+    M = 1 << 20
+    x = ((torch.rand(M, 3, device=dev) * 2 - 1) * 1.5).contiguous()
+    eng = net._engine_for(dev)
+    with torch.no_grad():
+        for name, fn in (("implicit_network(x) -> (M,257)", lambda: net.implicit_network(x)),
+                         ("engine.sdf_forward(x, want_features=True) (no concatenation)", lambda: eng.sdf_forward(x, want_features=True)),
+                         ("get_sdf_vals(x) (sdf-only kernel)", lambda: net.implicit_network.get_sdf_vals(x)),
+                         ("net.sdf_grid(x) (chunks of 2^20)", lambda: net.sdf_grid(x))):
+            fn()
+            med, best = ev_time(fn, rep=5, rounds=5)
+            print(f"implicit: {name}: {med:7.3f} ms (best {best:7.3f}) per {M} points", flush=True)
+        eng.set_sdf_forward_bf16x3(False)
+        med, best = ev_time(lambda: net.implicit_network(x), rep=3, rounds=3)
+        print(f"implicit: implicit_network(x), fp32-input MFMA kernel (the round-5 path): {med:7.3f} ms (best {best:7.3f})", flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "implicit":
+        implicit()
+    else:
+        main(sys.argv[1] if len(sys.argv) > 1 else "lib")

@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -pragma-unroll-threshold=1000000 scripts/ubench/mfma_paced.hip -o /tmp/mfma_paced && /tmp/mfma_paced
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -232,6 +233,163 @@ __global__ __launch_bounds__(256) void staged_kernel(const float* __restrict__ s
   if (r == 123.456f) sink[threadIdx.x] = r;
 }
 
+// ---- Round 6: the model above + the VALU work of the real sweeps, piece by piece (VERDICT r5 task 1: "instrument, do not guess").
+// staged_kernel<R, W, nt, counted wait, stores behind the DMA pieces> is the best model of round 5 (240 / 350 us for the sweeps' shapes);
+// the real kernels took 314 / 479 us.  Here the B operand of k-chunk kc + 1 is PRODUCED during the MFMAs of k-chunk kc the way x3.h:
+// dense_x3g does it -- twelve pieces, one per MFMA group: eight values (u = 0..7), then four split items (two values -> three bf16
+// planes) -- and the stored values are those eight values.  VM selects how much of a value's arithmetic is there:
+//   1: the three-way split only (value = loaded h * accumulator)           2: + sigma = 1 - exp2(c h)          (sweep 1's value())
+//   3: + G2: v_rcp, compare / select, three multiplies, fma               (sweep 2's value(); needs R = 3)
+//   DEP: the value also reads an accumulator register of the PREVIOUS layer's tiles (a second accumulator set is live: 128 more registers)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_bf16_(float a, float b) {
+  const f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+template <int R, int W, int VM, bool DEP>
+__global__ __launch_bounds__(256) void valu_kernel(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ wts, long tensor_floats,
+                                                   long layer_floats, float* sink) {
+  constexpr int SGR = 16;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long blk = (long)blockIdx.x * 4 + wave;
+  const int off = (lane & 31) * 16 + 4 * (lane >> 5);
+  f32x16 acc[8], accP[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[i][j] = 0.f; accP[i][j] = 1.0f + 0.001f * (float)(i + j + lane); }
+  f32x4 q[2][R > 0 ? R : 1][2];
+  const float* sbase = src + blk * 8192 + off;
+  float* dbase = dst + blk * 8192 + off;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wts), 0, 0x7ffffff0, 0x00020000);
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  auto dma = [&](int buf, int stage, int piece) {
+    float* d = lds + buf * (SGR * 512) + piece * 1024 + wv * 256;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16, tid * 16, (stage * (SGR * 2048)) % 393216 + piece * 4096, 0, 0);
+  };
+  auto loads = [&](int slot, const float* lbase, int kc) {
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const float* p = lbase + t * tensor_floats + kc * 512;
+      q[slot][t][0] = ld16<0>(p);
+      q[slot][t][1] = ld16<0>(p + 8);
+    }
+  };
+  if (R) loads(0, sbase, 0);
+#pragma unroll
+  for (int pc = 0; pc < SGR / 2; ++pc) dma(0, 0, pc);
+  float sv[2][8];      // stash of the values whose stores wait for their slot
+  u32x4 bq[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) bq[i][p] = u32x4{0x3f803f80u + lane, 0x3f803f80u, 0x3f003f00u, 0x3e803e80u};
+  for (int l = 0; l < 8; ++l) {
+    const float* lb = sbase + (long)l * layer_floats;
+    float* db = dbase + (long)l * layer_floats;
+    int vm_young = 0, pend0 = -1, pend1 = -1;
+    float v[8];
+    auto store_kc = [&](int kc, const float (&x)[8]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < W; ++t) {
+        float* p = db + t * tensor_floats + kc * 512;
+        st16<1>(p, f32x4{x[0], x[1], x[2], x[3]}); st16<1>(p + 8, f32x4{x[4], x[5], x[6], x[7]});
+      }
+      vm_young += 2 * W;
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+      if (pend0 >= 0) { store_kc(pend0, sv[0]); pend0 = -1; }
+      if (pend1 >= 0) { store_kc(pend1, sv[1]); pend1 = -1; }
+    };
+    // piece u of the B preparation of k-chunk kc (values from the loads of kc, planes into bq[kc & 1])
+    auto piece = [&](int kc, int u) __attribute__((always_inline)) {
+      if (kc >= 16) return;
+      if (R && u == 0 && kc + 1 < 16) { loads((kc + 1) & 1, lb, kc + 1); vm_young += 2 * R; }      // X3_AHEAD = 1: the next k-chunk's sources
+      if (u < 8) {
+        const float h = q[kc & 1][0][u >> 2][u & 3];
+        float x = DEP ? accP[kc >> 1][8 * (kc & 1) + u] : 1.25f;
+        if (VM == 1) v[u] = x * h;
+        else {
+          const float sg = 1.0f - __builtin_amdgcn_exp2f(-144.269504f * h);
+          if (VM == 2) v[u] = x * sg;
+          else {
+            const float gu = q[kc & 1][R > 1 ? 1 : 0][u >> 2][u & 3], ab = q[kc & 1][R > 2 ? 2 : 0][u >> 2][u & 3];
+            const float ga = sg > 0.f ? gu * __builtin_amdgcn_rcpf(sg) : 0.f;
+            const float g2 = ga * ab * (100.f * (1.0f - sg));
+            v[u] = fmaf(x, sg, g2);
+          }
+        }
+      } else {
+        if (u == 8 && W) {
+          if (pend0 >= 0 && pend1 >= 0) flush();
+          if (pend0 < 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[0][i] = v[i];
+            pend0 = kc;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sv[1][i] = v[i];
+            pend1 = kc;
+          }
+        }
+        const int i = u - 8;
+        const unsigned p0 = pk_bf16_(v[2 * i], v[2 * i + 1]);
+        float ra = v[2 * i] - bf_lo(p0), rb = v[2 * i + 1] - bf_hi(p0);
+        const unsigned p1 = pk_bf16_(ra, rb);
+        ra -= bf_lo(p1); rb -= bf_hi(p1);
+        bq[kc & 1][0][i] = p0; bq[kc & 1][1][i] = p1; bq[kc & 1][2][i] = pk_bf16_(ra, rb);
+      }
+    };
+    if (R && l > 0) loads(0, lb, 0);               // (the un-hidden prologue of an op, as in dense_x3g: its first sources, then their B preparation)
+#pragma unroll
+    for (int u = 0; u < 12; ++u) piece(0, u);
+    bool flushed = false;
+#pragma unroll
+    for (int gg = 0; gg < 192; ++gg) {
+      const int st = gg / SGR, gs = gg % SGR, kc = gg / 12, g = gg % 12;
+      const u32x4* cur = reinterpret_cast<const u32x4*>(lds + (st & 1) * (SGR * 512)) + lane;
+      u32x4 ring[2][2];
+      if (gs == 0) {
+        if (st == 0) wait_vm<0>(); else wait_vm_n(vm_young);
+        __builtin_amdgcn_s_barrier();
+        flushed = false;
+        ring[0][0] = cur[0]; ring[0][1] = cur[64]; ring[1][0] = cur[128]; ring[1][1] = cur[192];
+      }
+      const u32x4 a0 = ring[gs & 1][0], a1 = ring[gs & 1][1];
+      if (gs + 2 < SGR) { ring[gs & 1][0] = cur[(2 * (gs + 2)) * 64]; ring[gs & 1][1] = cur[(2 * (gs + 2) + 1) * 64]; }
+      const int sp = g % 3;      // the products of a group as in dense_x3g: W_sp with planes 0 (,1) of the activations
+      acc[(4 * g) % 8] = mfma_bf16(a0, bq[kc & 1][0], acc[(4 * g) % 8]);
+      acc[(4 * g + 1) % 8] = mfma_bf16(a1, bq[kc & 1][0], acc[(4 * g + 1) % 8]);
+      acc[(4 * g + 2) % 8] = mfma_bf16(a0, bq[kc & 1][sp < 2 ? 1 : 2], acc[(4 * g + 2) % 8]);
+      acc[(4 * g + 3) % 8] = mfma_bf16(a1, bq[kc & 1][sp < 2 ? 1 : 2], acc[(4 * g + 3) % 8]);
+      if (gs < SGR / 4) {
+        dma((st + 1) & 1, st + 1, 2 * gs); dma((st + 1) & 1, st + 1, 2 * gs + 1);
+        if (gs == SGR / 4 - 1) { vm_young = 0; __builtin_amdgcn_sched_barrier(0); }
+      }
+      if (gs >= SGR / 4 - 1 && !flushed) { flush(); flushed = true; }
+      piece(kc + 1, g);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    flush();
+    if (DEP) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) accP[i] = acc[i];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    }
+  }
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r += acc[i][0] + acc[i][15] + accP[i][3];
+  if (r == 123.456f) sink[threadIdx.x] = r;
+}
+
 // ---- latency probes: MODE 0: 2 loads; 1: 2 stores; 2: 2 stores then 2 loads; 3: 2 loads then 2 stores.  PACE: s_sleep units between probes
 template <int MODE, int FL>
 __global__ __launch_bounds__(256) void probe_kernel(const float* __restrict__ src, float* __restrict__ dst, long layer_floats, int pace, unsigned long long* out) {
@@ -326,6 +484,32 @@ void run_staged(const char* what) {
   fflush(stdout);
 }
 
+template <int R, int W, int VM, bool DEP>
+void run_valu(const char* what) {
+  auto k = valu_kernel<R, W, VM, DEP>;
+  const int lds_bytes = 96 * 1024;
+  hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best[2] = {1e30f, 1e30f};
+  for (int which = 0; which < 2; ++which) {
+    const int grid = which ? 256 : (int)(PTS / 128);
+    k<<<grid, 256, lds_bytes>>>(g_src, g_dst, g_wts, TENSOR, LAYER, g_sink);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < 5; ++rep) {
+      hipEventRecord(e0);
+      k<<<grid, 256, lds_bytes>>>(g_src, g_dst, g_wts, TENSOR, LAYER, g_sink);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (ms < best[which]) best[which] = ms;
+    }
+  }
+  hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)k);
+  printf("%-10s R=%d W=%d  VALU mix %d (%s)%s: %7.1f us per range (400 wg);  one round (256 wg) %7.1f us   [%d VGPRs, %zu B scratch]\n", what, R, W, VM,
+         VM == 1 ? "three-way split" : VM == 2 ? "+ sigma = 1 - exp2" : "+ rcp, select, G2", DEP ? " + previous layer's accumulators live" : "", best[0] * 1e3, best[1] * 1e3,
+         fa.numRegs, (size_t)fa.localSizeBytes);
+  fflush(stdout);
+}
+
 template <int MODE, int FL>
 void probe(const char* what, int pace) {
   auto k = probe_kernel<MODE, FL>;
@@ -347,6 +531,9 @@ void probe(const char* what, int pace) {
 int main() {
   hipMalloc(&g_src, (size_t)3 * TENSOR * 4); hipMalloc(&g_dst, (size_t)2 * TENSOR * 4); hipMalloc(&g_sink, 4096); hipMalloc(&g_out, 2 * 1024 * 8);
   hipMemset(g_src, 0, (size_t)3 * TENSOR * 4); hipMemset(g_dst, 0, (size_t)2 * TENSOR * 4);
+  hipMalloc(&g_wts, 12 * 32768 + 65536); hipMemset(g_wts, 0, 12 * 32768 + 65536);
+  const bool r6_only = getenv("PACED_R6_ONLY") != nullptr;
+  if (!r6_only) {
   printf("== the two sides alone\n");
   run<0, 0, 1, 1, 0, 11, 0>("MFMA only");
   run<1, 1, 1, 1, 0, 11, F_NOMFMA>("memory only");
@@ -376,7 +563,6 @@ int main() {
   run<3, 1, 1, 3, 0, 11, 0>("sweep 2");
   run<3, 1, 1, 4, 0, 11, 0>("sweep 2");
   run<3, 1, 1, 2, 0, 1, 0>("sweep 2");
-  hipMalloc(&g_wts, 12 * 32768 + 65536); hipMemset(g_wts, 0, 12 * 32768 + 65536);
   printf("== with the weight stream (LDS DMA from L2, ds_reads, a barrier per 16 groups)\n");
   run_staged<0, 0, 1, 0, 0, 16>("MFMA only");
   run_staged<1, 0, 1, 0, 0, 16>("loads");
@@ -403,6 +589,18 @@ int main() {
   run_staged<3, 1, 1, 0, 0, 32>("sweep 2");
   run_staged<3, 1, 1, 0, 2, 32>("sweep 2");
   run_staged<3, 1, 1, 1, 1, 32>("sweep 2");
+  }
+  printf("== round 6: the best model (counted waits, stores behind the DMA pieces, 32 KB stages) + the VALU work of the real B preparation, piece by piece\n");
+  run_staged<1, 1, 1, 1, 1, 16>("sweep 1");
+  run_valu<1, 1, 1, false>("sweep 1");
+  run_valu<1, 1, 2, false>("sweep 1");
+  run_valu<1, 1, 2, true>("sweep 1");
+  run_staged<3, 1, 1, 1, 1, 16>("sweep 2");
+  run_valu<3, 1, 1, false>("sweep 2");
+  run_valu<3, 1, 2, false>("sweep 2");
+  run_valu<3, 1, 3, false>("sweep 2");
+  run_valu<3, 1, 3, true>("sweep 2");
+  if (r6_only) return 0;
   printf("== latency probes (one wave per SIMD, 256 workgroups)\n");
   probe<0, 1>("2 loads", 0); probe<1, 1>("2 stores", 0); probe<1, 0>("2 stores", 0); probe<2, 1>("2 stores, 2 loads", 0); probe<3, 1>("2 loads, 2 stores", 0);
   probe<0, 1>("2 loads", 2); probe<1, 1>("2 stores", 2); probe<1, 0>("2 stores", 2); probe<2, 1>("2 stores, 2 loads", 2); probe<3, 1>("2 loads, 2 stores", 2);

@@ -161,6 +161,25 @@ def test_plan_options(lib):
     h.i2sdf_plan_destroy(plan)
 
 
+def test_fresh_plan_defaults(lib):
+    """Round 6: a fresh plan of a 256-wide configuration runs the tested bf16x3 twins with blocked saved tensors (what a C caller gets without
+    setting anything), the narrower-than-fp32 options and the point ranges stay opt-in; 64-wide plans have nothing on."""
+    from i2sdf_amd.config import synthetic_conf, plumbing_conf
+    h = lib.load()
+    M = 1024 * 100
+    Mp = (M + 127) // 128 * 128
+    bulk = (Mp // 128 // 256) * 256 * 128
+    rc, plan, _, _ = _plan(lib, synthetic_conf())
+    assert rc == 0
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == bulk and h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == bulk      # blocked + bf16x3 sweeps on, parts off
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SDF_BWD_BF16X3, 0) == 0
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0 and h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == bulk         # (blocked needs the bf16x3 family)
+    h.i2sdf_plan_destroy(plan)
+    rc, plan, _, _ = _plan(lib, plumbing_conf())
+    assert rc == 0 and h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0 and h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == 0
+    h.i2sdf_plan_destroy(plan)
+
+
 def test_new_plan_options_and_blocked_prefix(lib):
     """Round-2 options toggle on 256-wide nets; i2sdf_blocked_points follows the split of a launch into full rounds of 128-point
     workgroups (one per CU, 256 without a device) and the split-K tail (csrc/mlp_common.h: split_bulk_points)."""
@@ -175,11 +194,12 @@ def test_new_plan_options_and_blocked_prefix(lib):
         assert h.i2sdf_plan_set_option(plan, opt, 1) == 0
     M = 1024 * 98 + 1024 * 2                                   # the training batch: 98 shaded + 2 eikonal points per ray
     Mp = (M + 127) // 128 * 128
-    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0      # option off: point-major rows everywhere
-    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1) == 0
     n_wg = Mp // 128
     bulk = (n_wg // 256) * 256 * 128                           # 3 full rounds of 256 workgroups, 32 workgroups of tail
     assert 0 < bulk < M and (n_wg - bulk // 128) * 4 <= 256
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 0) == 0
+    assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0      # option off: point-major rows everywhere
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1) == 0
     assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == bulk
     assert h.i2sdf_blocked_points(plan, 1, M, Mp, 1) == bulk
     assert h.i2sdf_blocked_points(plan, 0, M, Mp, 0) == Mp     # eikonal-only launches (no feature output) are never split

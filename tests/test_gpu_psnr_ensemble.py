@@ -36,7 +36,9 @@ import torch
 from oracle import i2sdf_oracle as orc
 
 pytestmark = pytest.mark.gpu
-N_RUNS = int(os.environ.get("I2SDF_ENS_RUNS", "16"))
+# I2SDF_ENS_FAST=1: 8 members per arm for local runs (half the 145 s of the eager arm; SE grows by sqrt(2) and must STILL meet its bar);
+# the driver's run uses 16.  Whatever the overrides, the power check below is asserted, never skipped.
+N_RUNS = int(os.environ.get("I2SDF_ENS_RUNS", "8" if os.environ.get("I2SDF_ENS_FAST", "0") == "1" else "16"))
 STEPS = int(os.environ.get("I2SDF_ENS_STEPS", "300"))
 B, LR, TAIL = 256, 5.0e-4, 50
 LR_DECAY = 0.01           # total decay of the exponential schedule over the run
@@ -201,7 +203,9 @@ def test_ensemble_tail_psnr_production_vs_restatement():
           f"restatement {sum(held_r) / N_RUNS:.3f} dB, difference {m_h:+.4f} dB, SE {se_h:.4f} dB")
     assert max(abs(a - b) for a, b in zip(first_p, first_r)) < 1e-2, "step 0 renders the same weights with the same draws"
     assert mr - sum(first_r) / N_RUNS > 5.0, "the runs must actually train"
-    if N_RUNS >= 16 and STEPS >= 300:
-        assert se_t <= 0.1 and se_h <= 0.1, (se_t, se_h)           # the power of the test: it resolves what it claims
+    # the power of the test: it must resolve what it claims -- with ANY member / step count the environment selected (a reduced run that
+    # cannot resolve 0.1 dB fails here instead of passing on a looser effective bar)
+    assert se_t <= 0.1 and se_h <= 0.1, (se_t, se_h, N_RUNS, STEPS)
+    # effective tolerance: |difference| <= 0.1 dB + 2 SE <= 0.3 dB in the worst admissible case; measured SE 0.05 dB -> 0.2 dB (README)
     assert abs(m_t) <= 0.1 + 2.0 * se_t, (m_t, se_t)
     assert abs(m_h) <= 0.1 + 2.0 * se_h, (m_h, se_h)
