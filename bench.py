@@ -688,6 +688,8 @@ def dominant_kernel(live, cfg, fp, eng, B, M_main, M_sdf, iters, PEAK, PEAK_BF16
         "rgb_bwd3h_kernel": (fp["rgb_backward"] * M_main, 6),
         # the 256x256 blocks: 7 SDF layers x 2 products over all points, the feature block + 4 radiance blocks over the ray samples
         "wgrad3p_kernel": (2 * 65536 * (14 * M_sdf + 5 * M_main), 3 if eng.wgrad_bf16x2 else 6),
+        # round 6: blocks + narrow tasks of a range in one grid (the narrow tasks' products, ~3 % of the blocks', are not counted)
+        "wgrad_all_kernel": (2 * 65536 * (14 * M_sdf + 5 * M_main), 3 if eng.wgrad_bf16x2 else 6),
     }
     best = None
     for k, v in live.items():

@@ -2,7 +2,7 @@
 // model/network/__init__.py:289-406 with its quirks (angular term = the same L1 normal term, :368-369).
 // Replaces ~100 element-wise torch kernels (forward and autograd backward) per training step.
 #include <algorithm>
-#include "plan.h"
+#include "loss_dev.h"
 
 using namespace i2sdf;
 
@@ -10,63 +10,14 @@ int i2sdf_hip_check(hipError_t e, const char* what);
 
 namespace {
 
-enum { S_RGB = 0, S_EIK, S_SMOOTH, S_MASK, S_DEPTH, S_DEPTH_CNT, S_NORMAL, S_NORMAL_CNT, S_BUBBLE, S_LIGHT, S_N };
-// denominators of the means: local values, or (data parallel, i2sdf_loss_cfg.exchange) their mean over the ranks
-enum { C_B = 0, C_NPC, C_DEPTH, C_NORMAL, C_N };
-constexpr int LOSS_BLOCKS = 64;
-
-struct LossArgs {
-  i2sdf_loss_cfg c;
-  int64_t B, n_pc;
-  const float *rgb, *depth, *wsum, *normal, *grad_theta, *diff_norm, *surface, *lmask;
-  const float *gt_rgb, *gt_depth, *gt_normal, *gt_mask, *gt_lmask;
-  const uint8_t *depth_mask, *normal_mask;
-  float* partial;      // (LOSS_BLOCKS, S_N)
-  float* sums;         // (S_N)   only written / read on the data-parallel path (reduced = 1)
-  float* cnt;          // (C_N)   likewise: the denominators the exchange hook averages over the ranks
-  int nb;              // workgroups of the reduction launch = rows of `partial`
-  int reduced;         // 1: sums / cnt are in memory (loss_reduce_kernel + exchange ran); 0: every workgroup of the gradient launch adds the
-                       //    block partials up itself, in block order -- no counter, no state in the scratch, nothing to initialise
-  float* losses;       // (10): loss, rgb, eikonal, smooth, mask, depth, normal, angular, bubble, light_mask
-  float* loss_value;   // (1) | NULL: the total once more, as a tensor of its own
-  float *g_rgb, *g_depth, *g_wsum, *g_normal, *g_grad_theta, *g_diff_norm, *g_surface, *g_lmask;
-};
-
-__device__ __forceinline__ float bce(float p_raw, float y, float& dp) {
-  const float p = fminf(fmaxf(p_raw, 1e-3f), 1.0f - 1e-3f);
-  const bool inside = p_raw >= 1e-3f && p_raw <= 1.0f - 1e-3f;
-  const float l = -(y * fmaxf(logf(p), -100.f) + (1.0f - y) * fmaxf(logf(1.0f - p), -100.f));   // F.binary_cross_entropy clamps log at -100
-  dp = inside ? (-(y / p) + (1.0f - y) / (1.0f - p)) : 0.f;
-  return l;
-}
-
 __global__ __launch_bounds__(256) void loss_partial_kernel(LossArgs a) {
   float s[S_N];
 #pragma unroll
   for (int i = 0; i < S_N; ++i) s[i] = 0.f;
   const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.B; i += stride) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) s[S_RGB] += fabsf(a.rgb[i * 3 + k] - a.gt_rgb[i * 3 + k]);
-    if (a.diff_norm) s[S_SMOOTH] += a.diff_norm[i];
-    if (a.gt_mask) { float d; s[S_MASK] += bce(a.wsum[i], a.gt_mask[i], d); }
-    if (a.gt_depth) {
-      const float m = a.depth_mask[i] ? 1.f : 0.f, d = a.depth[i] - a.gt_depth[i];
-      s[S_DEPTH] += m * d * d; s[S_DEPTH_CNT] += m;
-    }
-    if (a.gt_normal && a.normal) {
-      const float m = a.normal_mask[i] ? 1.f : 0.f;
-      const float dot = a.normal[i * 3] * a.gt_normal[i * 3] + a.normal[i * 3 + 1] * a.gt_normal[i * 3 + 1] + a.normal[i * 3 + 2] * a.gt_normal[i * 3 + 2];
-      s[S_NORMAL] += m * fabsf(1.0f - dot); s[S_NORMAL_CNT] += m;
-    }
-    if (a.lmask && a.gt_lmask) { float d; s[S_LIGHT] += bce(a.lmask[i], a.gt_lmask[i], d); }
-  }
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.B; i += stride) loss_ray_terms(a, i, s);
   if (a.grad_theta)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * a.B; i += stride) {
-      const float x = a.grad_theta[i * 3], y = a.grad_theta[i * 3 + 1], z = a.grad_theta[i * 3 + 2];
-      const float d = sqrtf(x * x + y * y + z * z) - 1.0f;
-      s[S_EIK] += d * d;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < 2 * a.B; i += stride) s[S_EIK] += loss_eik_term(a.grad_theta + i * 3);
   if (a.surface)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < a.n_pc; i += stride) s[S_BUBBLE] += fabsf(a.surface[i]);
   __shared__ float sm[4][S_N];
@@ -105,27 +56,7 @@ __global__ __launch_bounds__(64) void loss_reduce_kernel(LossArgs a) {
   if (threadIdx.x < C_N) a.cnt[threadIdx.x] = cnt[threadIdx.x];
 }
 
-// the reported values (workgroup 0 of the gradient launch)
-__device__ __forceinline__ void loss_finalize(const LossArgs& a, const float (&tot)[S_N], const float (&cnt)[C_N]) {
-  if (threadIdx.x == 0) {
-    const float B = cnt[C_B];
-    const float rgb = tot[S_RGB] / (3.0f * B);
-    const float eik = a.grad_theta ? tot[S_EIK] / (2.0f * B) : 0.f;
-    const float smooth = (a.diff_norm && a.c.smooth_on && a.c.smooth_w > 0.f) ? tot[S_SMOOTH] / B : 0.f;
-    const float mask = (a.gt_mask && a.c.mask_w > 0.f) ? tot[S_MASK] / B : 0.f;
-    const float depth = (a.gt_depth && a.c.depth_w > 0.f) ? tot[S_DEPTH] / cnt[C_DEPTH] : 0.f;
-    const float nl1 = (a.gt_normal && a.normal) ? tot[S_NORMAL] / cnt[C_NORMAL] : 0.f;
-    const float normal = a.c.normal_w > 0.f ? nl1 : 0.f, angular = a.c.angular_w > 0.f ? nl1 : 0.f;
-    const float bubble = (a.surface && a.c.bubble_w > 0.f) ? tot[S_BUBBLE] / cnt[C_NPC] : 0.f;
-    const float light = (a.lmask && a.gt_lmask && a.c.light_w > 0.f) ? tot[S_LIGHT] / B : 0.f;
-    a.losses[0] = rgb + a.c.eikonal_w * eik + a.c.smooth_w * smooth + a.c.mask_w * mask + a.c.depth_w * depth + a.c.normal_w * normal +
-                  a.c.angular_w * angular + a.c.bubble_w * bubble + a.c.light_w * light;
-    a.losses[1] = rgb; a.losses[2] = eik; a.losses[3] = smooth; a.losses[4] = mask; a.losses[5] = depth;
-    a.losses[6] = normal; a.losses[7] = angular; a.losses[8] = bubble; a.losses[9] = light;
-    if (a.loss_value) a.loss_value[0] = a.losses[0];
-  }
-}
-
+// the reported values (workgroup 0 of the gradient launch): loss_dev.h: loss_values
 __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
   __shared__ float tot[S_N], cnt[C_N];
   if (a.reduced) {
@@ -135,49 +66,26 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
     loss_reduce(a, tot, cnt);
   }
   __syncthreads();
-  if (blockIdx.x == 0) loss_finalize(a, tot, cnt);
+  if (blockIdx.x == 0 && threadIdx.x == 0) loss_values(a, tot, cnt);
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const float B = cnt[C_B];
   if (i < a.B) {
+    LossSeeds g;
+    loss_ray_grads(a, i, cnt, g);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float d = a.rgb[i * 3 + k] - a.gt_rgb[i * 3 + k];
-      a.g_rgb[i * 3 + k] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / (3.0f * B);
-    }
-    float gd = 0.f;
-    if (a.gt_depth && a.c.depth_w > 0.f && a.depth_mask[i]) gd = a.c.depth_w * 2.0f * (a.depth[i] - a.gt_depth[i]) / cnt[C_DEPTH];
-    a.g_depth[i] = gd;
-    float gw = 0.f;
-    if (a.gt_mask && a.c.mask_w > 0.f) { float d; (void)bce(a.wsum[i], a.gt_mask[i], d); gw = a.c.mask_w * d / B; }
-    a.g_wsum[i] = gw;
-    if (a.g_normal) {
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-      if (a.gt_normal && a.normal && a.normal_mask[i]) {
-        const float w = ((a.c.normal_w > 0.f ? a.c.normal_w : 0.f) + (a.c.angular_w > 0.f ? a.c.angular_w : 0.f)) / cnt[C_NORMAL];
-        const float n0 = a.gt_normal[i * 3], n1 = a.gt_normal[i * 3 + 1], n2 = a.gt_normal[i * 3 + 2];
-        const float u = 1.0f - (a.normal[i * 3] * n0 + a.normal[i * 3 + 1] * n1 + a.normal[i * 3 + 2] * n2);
-        const float sg = u > 0.f ? -1.f : (u < 0.f ? 1.f : 0.f);          // d|1-dot| / d dot
-        g0 = w * sg * n0; g1 = w * sg * n1; g2 = w * sg * n2;
-      }
-      a.g_normal[i * 3] = g0; a.g_normal[i * 3 + 1] = g1; a.g_normal[i * 3 + 2] = g2;
-    }
-    if (a.g_diff_norm) a.g_diff_norm[i] = (a.c.smooth_on && a.c.smooth_w > 0.f) ? a.c.smooth_w / B : 0.f;
-    if (a.g_lmask) {
-      float gl = 0.f;
-      if (a.lmask && a.gt_lmask && a.c.light_w > 0.f) { float d; (void)bce(a.lmask[i], a.gt_lmask[i], d); gl = a.c.light_w * d / B; }
-      a.g_lmask[i] = gl;
-    }
+    for (int k = 0; k < 3; ++k) a.g_rgb[i * 3 + k] = g.rgb[k];
+    a.g_depth[i] = g.depth;
+    a.g_wsum[i] = g.wsum;
+    if (a.g_normal) { a.g_normal[i * 3] = g.normal[0]; a.g_normal[i * 3 + 1] = g.normal[1]; a.g_normal[i * 3 + 2] = g.normal[2]; }
+    if (a.g_diff_norm) a.g_diff_norm[i] = g.diff_norm;
+    if (a.g_lmask) a.g_lmask[i] = g.lmask;
   }
   if (a.g_grad_theta && i < 2 * a.B) {
-    const float x = a.grad_theta[i * 3], y = a.grad_theta[i * 3 + 1], z = a.grad_theta[i * 3 + 2];
-    const float nrm = sqrtf(x * x + y * y + z * z);
-    const float f = nrm > 0.f ? a.c.eikonal_w * 2.0f * (nrm - 1.0f) / (nrm * 2.0f * B) : 0.f;
-    a.g_grad_theta[i * 3] = f * x; a.g_grad_theta[i * 3 + 1] = f * y; a.g_grad_theta[i * 3 + 2] = f * z;
+    float o[3];
+    loss_eik_grad(a, a.grad_theta + i * 3, B, o);
+    a.g_grad_theta[i * 3] = o[0]; a.g_grad_theta[i * 3 + 1] = o[1]; a.g_grad_theta[i * 3 + 2] = o[2];
   }
-  if (a.g_surface && i < a.n_pc) {
-    const float sv = a.surface[i];
-    a.g_surface[i] = a.c.bubble_w > 0.f ? a.c.bubble_w * (sv > 0.f ? 1.f : (sv < 0.f ? -1.f : 0.f)) / cnt[C_NPC] : 0.f;
-  }
+  if (a.g_surface && i < a.n_pc) a.g_surface[i] = loss_surface_grad(a, a.surface[i], cnt[C_NPC]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -187,17 +95,8 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(LossArgs a) {
 // and the backward of both in one launch.  In torch these are ~8 forward and ~25 autograd-backward kernels on (2B,3) tensors.
 // Conventions of the torch backward formulas are kept: d||x||/dx = 0 at x = 0; no gradient through ||v|| where ||v|| < eps.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr float NRM_EPS = 1e-6f;
-// No FMA contraction from here on: n1 - n2 must subtract the ROUNDED unit vectors, so that identical normals give exactly 0
-// (as they do in torch); contracted, the difference is the rounding error of n2 and the gradient an O(1) noise vector.
+// (unit3 / unit3_bwd / eik_out_bwd_point with FMA contraction off: loss_dev.h)
 #pragma clang fp contract(off)
-
-__device__ __forceinline__ void unit3(const float* __restrict__ g, float (&v)[3], float (&n)[3], float& r) {
-  v[0] = g[0]; v[1] = g[1]; v[2] = g[2];
-  r = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  const float inv = 1.0f / fmaxf(r, NRM_EPS);
-  n[0] = v[0] * inv; n[1] = v[1] * inv; n[2] = v[2] * inv;
-}
 
 __global__ __launch_bounds__(256) void eik_out_fwd_kernel(const float* __restrict__ g, int64_t B, float* __restrict__ theta,
                                                            float* __restrict__ diff) {
@@ -214,41 +113,16 @@ __global__ __launch_bounds__(256) void eik_out_fwd_kernel(const float* __restric
   }
 }
 
-__device__ __forceinline__ void unit3_bwd(const float (&n)[3], float r, const float (&gn)[3], float (&gv)[3]) {
-  if (r >= NRM_EPS) {       // clamp_min passes the gradient of ||v||: gv = (gn - n (gn.n)) / r
-    const float dot = gn[0] * n[0] + gn[1] * n[1] + gn[2] * n[2];
-    const float inv = 1.0f / r;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gv[c] = (gn[c] - n[c] * dot) * inv;
-  } else {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) gv[c] = gn[c] * (1.0f / NRM_EPS);
-  }
-}
-
 __global__ __launch_bounds__(256) void eik_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ theta_bar,
                                                            const float* __restrict__ diff_bar, int64_t B, float* __restrict__ g_bar) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
-  float o0[3] = {0.f, 0.f, 0.f}, o1[3] = {0.f, 0.f, 0.f}, o2[3] = {0.f, 0.f, 0.f};
+  float th0[3] = {0.f, 0.f, 0.f}, th1[3] = {0.f, 0.f, 0.f}, o0[3], o1[3], o2[3];
   if (theta_bar) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { o0[c] = theta_bar[i * 3 + c]; o1[c] = theta_bar[(B + i) * 3 + c]; }
+    for (int c = 0; c < 3; ++c) { th0[c] = theta_bar[i * 3 + c]; th1[c] = theta_bar[(B + i) * 3 + c]; }
   }
-  if (diff_bar) {
-    float v1[3], n1[3], r1, v2[3], n2[3], r2;
-    unit3(g + (B + i) * 3, v1, n1, r1);
-    unit3(g + (2 * B + i) * 3, v2, n2, r2);
-    const float d[3] = {n1[0] - n2[0], n1[1] - n2[1], n1[2] - n2[2]};
-    const float nd = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    const float f = nd > 0.f ? diff_bar[i] / nd : 0.f;
-    const float gn1[3] = {f * d[0], f * d[1], f * d[2]}, gn2[3] = {-f * d[0], -f * d[1], -f * d[2]};
-    float a[3], b[3];
-    unit3_bwd(n1, r1, gn1, a);
-    unit3_bwd(n2, r2, gn2, b);
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { o1[c] += a[c]; o2[c] += b[c]; }
-  }
+  eik_out_bwd_point(g, B, i, th0, th1, diff_bar != nullptr, diff_bar ? diff_bar[i] : 0.f, o0, o1, o2);
 #pragma unroll
   for (int c = 0; c < 3; ++c) { g_bar[i * 3 + c] = o0[c]; g_bar[(B + i) * 3 + c] = o1[c]; g_bar[(2 * B + i) * 3 + c] = o2[c]; }
 }

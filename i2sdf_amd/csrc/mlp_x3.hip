@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   }
   {
     const int l = a.L - 1;
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
+    X3Sweep1Src<NT, KH16, NGP, X3_DRAIN_AHEAD> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
     x3_drain<KH16>(src);
   }
 }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3Sweep2Src<NT, false> src{accA, a.hs + mcrow, a.gus + lstride + mcrow, a.abars + mcrow, a.gas + mrow, hi, 0.f, nullptr, kcs};     // G(a_0)
+    X3Sweep2Src<NT, false, X3_DRAIN_AHEAD> src{accA, a.hs + mcrow, a.gus + lstride + mcrow, a.abars + mcrow, a.gas + mrow, hi, 0.f, nullptr, kcs};     // G(a_0)
     x3_drain<KH16>(src);
   }
 }

@@ -4,6 +4,7 @@
 // the _weight_norm backward.  X, Y are point-major ([Mp][ld]); a wave owns a 128x128 output tile and streams
 // point pairs straight from HBM into MFMA operands (fp32 32x32x2: the reduction index of the MFMA is the point).
 #include <algorithm>
+#include <stdlib.h>
 #include "mlp_common.h"
 
 using namespace i2sdf;
@@ -803,6 +804,46 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
   }
 }
 
+// ---- ONE launch for every split-arithmetic task of a point range (round 6): the 256x256 blocks (wgrad3p_body) and the narrow / 128x128
+// tasks (wgrad_narrow_body / wgrad_wide_body) as workgroups of the same grid, dispatched on the task's variant.  Two launches per range
+// on one stream ran back to back -- the 250 narrow workgroups alone on their range's stream, not even one round of the chip, then the
+// 475 block workgroups behind a kernel boundary; as one grid of 725 the short narrow workgroups fill the rounds of the long ones.  Both
+// bodies are one workgroup per CU by their registers (460-512) and LDS either way.  Task order: narrow tasks FIRST (they are dispatched
+// first and finish first; the blocks' last round is then the only partly filled one).
+template <int NPL>
+__global__ __launch_bounds__(256) void wgrad_all_kernel(WgLaunch L) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WgTask& t = L.t[blockIdx.y];
+  if (t.variant == 4) {
+    const int64_t m_lo = (int64_t)(blockIdx.x + L.chunk0) * WG_CH;
+    const bool ba = m_lo < t.j[0].a_blk, bb = m_lo < t.j[0].b_blk;       // workgroup-uniform
+    bool plain = t.relu_b == 0;
+    for (int jb = 0; jb < t.njobs; ++jb) {
+      const int64_t left = t.j[jb].m_count - m_lo;
+      plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
+    }
+    if (plain) {
+      if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
+      else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
+      else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
+      else wgrad3p_body<false, false, NPL, true>(L, lds);
+    } else {
+      if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
+      else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
+      else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
+      else wgrad3p_body<false, false, NPL, false>(L, lds);
+    }
+    return;
+  }
+  // (the narrow blocks always with three planes, as in wgrad_narrow_kernel<3>: bound by their operand reads)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t chunk = blockIdx.x + L.chunk0;
+  if (t.variant == 0) wgrad_wide_body<3>(L, t, chunk, wave, lane, lds);
+  else if (t.variant == 1) wgrad_narrow_body<1, 0, 3>(L, t, chunk, wave, lane, lds);
+  else if (t.variant == 2) wgrad_narrow_body<0, 1, 3>(L, t, chunk, wave, lane, lds);
+  else wgrad_narrow_body<0, 2, 3>(L, t, chunk, wave, lane, lds);
+}
+
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
 struct WnLayer {
   int64_t off_v, off_g, off_bias, blk_off, bias_blk_off;
@@ -1044,7 +1085,16 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       L.chunk_stride = p->wgrad_floats; L.partials = partials;
       L.chunk0 = c_lo;
       dim3 grid((unsigned)(c_hi - c_lo), (unsigned)L.n);
-      if (var == 4) {
+      if (var == 5) {          // split arithmetic: every task of the range in one grid (wgrad_all_kernel)
+        constexpr int LB = W3P_LDS_BYTES > WGN_LDS_BYTES ? W3P_LDS_BYTES : WGN_LDS_BYTES;
+        if (p->wgrad_bf16x2) {
+          (void)hipFuncSetAttribute((const void*)wgrad_all_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
+          wgrad_all_kernel<2><<<grid, 256, LB, st>>>(L);
+        } else {
+          (void)hipFuncSetAttribute((const void*)wgrad_all_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LB);
+          wgrad_all_kernel<3><<<grid, 256, LB, st>>>(L);
+        }
+      } else if (var == 4) {
         if (p->wgrad_bf16x2) {
           (void)hipFuncSetAttribute((const void*)wgrad3p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, W3P_LDS_BYTES);
           wgrad3p_kernel<2><<<grid, 256, W3P_LDS_BYTES, st>>>(L);
@@ -1082,6 +1132,11 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     for (const WgTask& x : tl.tasks) if (x.variant == (v == 0 ? 4 : 0) && !(v == 1 && wide_in_narrow)) sel_blocks[v].push_back(x);
     std::stable_sort(sel_blocks[v].begin(), sel_blocks[v].end(), [](const WgTask& x, const WgTask& y) { return x.njobs > y.njobs; });
   }
+  // split arithmetic: narrow tasks + 256x256 blocks as ONE grid per range (I2SDF_WGRAD_MERGED=0: the two launches of rounds 4-5, for A/B runs)
+  static const bool merged_env = [] { const char* e = getenv("I2SDF_WGRAD_MERGED"); return !(e && e[0] == '0'); }();
+  const bool merged = merged_env && p->wgrad_bf16x3 != 0 && sel_narrow.size() + sel_blocks[0].size() <= (size_t)MAX_TASKS && !sel_blocks[0].empty();
+  std::vector<WgTask> sel_all;
+  if (merged) { sel_all = sel_narrow; sel_all.insert(sel_all.end(), sel_blocks[0].begin(), sel_blocks[0].end()); }
   PartRun pr;
   if (i2sdf_parts_on(p) && i2sdf_parts_begin(p, st_main, Ms, &pr)) {
     // point ranges (plan.h: PartRun): the GEMMs of a range's chunks on the range's stream, behind that range's backward sweeps
@@ -1089,8 +1144,11 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       if (pr.hi[q] <= pr.lo[q]) continue;
       c_lo = (int)(pr.lo[q] / WG_CH); c_hi = (int)((pr.hi[q] + WG_CH - 1) / WG_CH);
       st = pr.st[q];
-      launch(sel_narrow, 1);               // (the narrow blocks behind the 256x256 ones instead: +0.02 ms, measured)
-      launch(sel_blocks[0], 4);
+      if (merged) launch(sel_all, 5);
+      else {
+        launch(sel_narrow, 1);               // (the narrow blocks behind the 256x256 ones instead: +0.02 ms, measured)
+        launch(sel_blocks[0], 4);
+      }
       launch(sel_blocks[1], 0);
     }
     st = st_main; c_lo = 0; c_hi = n_chunks;

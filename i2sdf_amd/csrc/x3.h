@@ -35,6 +35,10 @@ constexpr int X3_AHEAD = 1, X3_RING = 2;
 #ifndef X3_SW2_AHEAD
 #define X3_SW2_AHEAD 1
 #endif
+// the final drain of a sweep (x3_drain: loads -> values -> stores of the last layer's sixteen k-chunks, no MFMAs in between): k-chunks of load-ahead
+#ifndef X3_DRAIN_AHEAD
+#define X3_DRAIN_AHEAD 1
+#endif
 #ifndef X3_SW2_SHARE_E
 #define X3_SW2_SHARE_E 0
 #endif
@@ -353,22 +357,23 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
 // RECOVERS G(abar_l) = G(hbar_{l+1}) / sigma_l from the tensor stored above -- the same sigma bits from the same h, so the quotient is
 // G(abar_l) to one rounding -- and forms G2 itself.  One store pass of this sweep and its read of abar become one more read pass of
 // sweep 2; the knock-outs of profiles/r5_step0_knockouts.txt price a store pass of the sweeps at ~4x a load pass.
-template <int NT, int KACC, int NREG>
+// AH: k-chunks of load-ahead (the final drain of a sweep has no MFMAs to hide a load behind: it asks for X3_DRAIN_AHEAD)
+template <int NT, int KACC, int NREG, int AH = X3_AHEAD>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
-  static constexpr int AHEAD = X3_AHEAD;
+  static constexpr int AHEAD = AH, RING = AH + 1;
   const f32x16 (&accP)[NT]; const float (&tailreg)[NREG];     // k-chunks >= KACC: registers in the fp32 kernels' B layout
   const float* hrow; float* gurow; int hi; int kcs = 16;
-  f32x4 hq[X3_RING][2];
+  f32x4 hq[RING][2];
   __device__ __forceinline__ int ahead(int kc) {
-    if (kc < KACC) x3_load8(hrow, kc, hi, hq[kc % X3_RING], kcs);
+    if (kc < KACC) x3_load8(hrow, kc, hi, hq[kc % RING], kcs);
     return kc < KACC ? 2 : 0;
   }
   __device__ __forceinline__ float value(int kc, int u, float&) {
     if (kc >= KACC) return tailreg[8 * (kc - KACC < 0 ? 0 : kc - KACC) + u];
     const float ga = accP[(kc >> 1) < NT ? (kc >> 1) : 0][8 * (kc & 1) + u];
-    return ga * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
+    return ga * sp_sigma_from_h(hq[kc % RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
     if (kc < KACC) x3_store8(gurow, kc, hi, v, kcs);
@@ -378,11 +383,11 @@ struct X3Sweep1Src {
 // sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored to grow]
 //          G2(a_l) = (G(hbar_{l+1}) / sigma_l) abar_l 100 (1 - sigma_l)   from sweep 1's stored G(hbar_{l+1}) (gurow) and the forward's abar_l (arow);
 //          sigma_l = 0 (h_{l+1} underflowed to 0: abar_l = 0 and G(hbar_{l+1}) = 0 as well) -> G2 = 0
-template <int NT, bool TOP>
+template <int NT, bool TOP, int AH = X3_SW2_AHEAD>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
-  static constexpr int AHEAD = X3_SW2_AHEAD, RING = AHEAD + 1;     // three tensors per k-chunk: the loads of AHEAD k-chunks in flight per wave
+  static constexpr int AHEAD = AH, RING = AHEAD + 1;     // three tensors per k-chunk: the loads of AHEAD k-chunks in flight per wave
   const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;

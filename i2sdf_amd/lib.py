@@ -147,6 +147,12 @@ SIGNATURES = {
     "i2sdf_loss_forward_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I64] + [_P] * 27),
     "i2sdf_eikonal_outputs_forward": (C.c_int, [_P, _I64, _P, _P, _P]),
     "i2sdf_extra_points": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P, _P]),
+    "i2sdf_render_loss_scratch_floats": (_I64, [_I64]),
+    # cfg, B, n, n_pc, M_main, M_sdf, n_eik | beta_param, beta_min, z, ldz, sdf, rgb_pts, grad_pts, dnorm, nsum_save | 8 outputs | 7 ground truth |
+    # scratch, losses, loss_value | 8 seeds | sdf_bar, rgb_bar, grad_bar, normal_term, lmask_bar, beta_grad, stream
+    "i2sdf_render_loss_backward": (C.c_int, [C.POINTER(LossCfg), _I64, _I32, _I64, _I64, _I64, _I64, _P, C.c_float, _P, _I64] + [_P] * 5 + [_P] * 8 + [_P] * 7 +
+                                   [_P] * 3 + [_P] * 8 + [_P, _P, _P, _I32, _P, _P, _P]),
+    "i2sdf_scale_seeds": (C.c_int, [_P, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P]),
     "i2sdf_backward_seeds": (C.c_int, [_P, _I64, _P, _P, _I64, _I64, _P, _I64, _P, _I64, C.c_int32, _P]),
     "i2sdf_eikonal_outputs_backward": (C.c_int, [_P, _P, _P, _I64, _P, _P]),
     "i2sdf_ray_setup": (C.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P]),

@@ -114,6 +114,10 @@ class _RenderFn(torch.autograd.Function):
         comp = eng.composite_forward(beta_param, st["z_all"], fw["sdf"], rgb, fw["grad"], lm, st["dnorm"], want_normal=st["want_normal"])
         ctx.net, ctx.st, ctx.fw, ctx.rgb, ctx.rs, ctx.pev, ctx.lm, ctx.hl, ctx.comp = net, st, fw, rgb, rs, pev, lm, hl, comp
         ctx.M_main = M_main
+        # for I2SDFLoss's fused path (loss.py: _FusedRenderLossFn -> i2sdf_render_loss_backward): the compositing inputs of this render.
+        # Cleared in backward together with ctx; no entry refers to an output tensor (the handle is an attribute of one: no cycle)
+        st["fused"] = {"fw": fw, "rgb_pts": rgb, "lm_pts": lm, "nsum": comp["nsum"], "beta_param": beta_param, "n": n, "M_main": M_main,
+                       "use_light": net.use_light, "beta_min": eng.cfg.beta_min}
         # outputs the loss does not use (weight_sum without a mask term, ...) arrive in backward as None instead of as zero tensors that
         # autograd would fill with one launch each; the kernels take NULL for them (include/i2sdf.h)
         ctx.set_materialize_grads(False)
@@ -141,9 +145,32 @@ class _RenderFn(torch.autograd.Function):
         # extra points are set here (eikonal points carry d loss / d grad, the bubble point cloud d loss / d sdf).
         # One launch (i2sdf_backward_seeds) instead of three fills and two copies.
         gflat = torch.empty_like(flat)
+        from . import lib as L_
+        pre = st.get("pre")
+        same = lambda a, b: a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.numel() == b.numel()
+        if pre is not None and pre["g"] is not None:
+            tk = pre["tok"]
+            fast = (same(g_rgb, tk["rgb"]) and same(g_depth, tk["depth"]) and (g_wsum is None or same(g_wsum, tk["wsum"]))
+                    and ((not st["want_normal"]) or tk["normal"] is None or same(g_normal, tk["normal"]))
+                    and ((not net.use_light) or same(g_lmask, tk["lmask"]))
+                    and ((not n_eik) or same(g_eik, pre["tok_eik"]))
+                    and ((not n_pc) or tk["surface"] is None or same(g_surf, tk["surface"])))
+            if fast:
+                # I2SDFLoss already ran the loss AND the backward down to the per-sample gradients, for an upstream gradient of 1
+                # (i2sdf_render_loss_backward); what autograd delivered are the loss's own untouched seeds: scale by its gradient, done
+                return _RenderFn._backward_from_seeds(ctx, pre, gflat)
+            # the loss's seeds were mixed with other gradients of the same outputs (another loss term on them): they were handed to
+            # autograd UNSCALED -- correct what arrived to  g * seed + the rest,  then take the general path
+            gs_ = pre["g"].reshape(()).to(torch.float32) - 1.0
+            fix = lambda gx, t: gx if (gx is None or t is None) else gx + gs_ * t.reshape(gx.shape)
+            g_rgb, g_depth, g_wsum = fix(g_rgb, tk["rgb"]), fix(g_depth, tk["depth"]), fix(g_wsum, tk["wsum"])
+            g_normal, g_lmask, g_surf = fix(g_normal, tk["normal"]), fix(g_lmask, tk["lmask"]), fix(g_surf, tk["surface"])
+            if n_eik and g_eik is not None and not same(g_eik, pre["tok_eik"]):
+                pass      # (_EikonalOutputsFn.backward applied the same correction to grad_theta / diff_norm before its own backward)
+            elif n_eik and same(g_eik, pre["tok_eik"]):
+                g_eik = pre["eik_true"]()          # the placeholder reached us: recompute the extra points' gradient the general way
         sbar = torch.empty(M_sdf, device=dev)
         nbar = torch.empty(M_sdf, 3, device=dev)
-        from . import lib as L_
         if g_rgb is None:                      # a loss without a colour term: the compositing backward wants the pointer
             g_rgb = torch.zeros_like(comp["rgb"])
         if net.use_light and g_lmask is None:
@@ -168,6 +195,12 @@ class _RenderFn(torch.autograd.Function):
             bw = eng.sdf_backward(fw, sbar=sbar, fbar=fbar, m_fbar=M_main, nbar=nbar)
             eng.weight_grads(flat, gflat, fw, bw, M_main=M_main, fbar=fbar, rgb_fw={"pev": ctx.pev, "rs": ctx.rs},
                              rgb_bw={"gar": gar, "ga_last": ga_last}, light=light)
+        return _RenderFn._finish(ctx, gflat)
+
+    @staticmethod
+    def _finish(ctx, gflat):
+        net, st = ctx.net, ctx.st
+        eng = st["eng"]
         if net.grad_sync is not None:
             net.grad_sync(gflat)
         grads = []
@@ -176,8 +209,36 @@ class _RenderFn(torch.autograd.Function):
             for s in shape:
                 cnt *= s
             grads.append(gflat[off:off + cnt].view(shape))
+        st.pop("fused", None)
+        st.pop("pre", None)
         ctx.net = ctx.st = ctx.fw = ctx.comp = None
         return (None, None) + tuple(grads)
+
+    @staticmethod
+    def _backward_from_seeds(ctx, pre, gflat):
+        """backward when I2SDFLoss's fused path has already produced the per-sample gradients (for an upstream gradient of 1): one launch
+        scales them by the gradient autograd delivered, then radiance backward -> SDF sweeps -> weight gradients as in the general path"""
+        from . import lib as L_
+        net, st, fw, M_main = ctx.net, ctx.st, ctx.fw, ctx.M_main
+        eng: RenderEngine = st["eng"]
+        flat = net._flat
+        off_beta = eng.layout.offset("density.beta")
+        sbar, nbar, rgb_bar, lmask_bar = pre["sbar"], pre["nbar"], pre["rgb_bar"], pre["lmask_bar"]
+        g = pre["g"].reshape(1).to(torch.float32).contiguous()
+        with torch.cuda.device(flat.device):
+            L_.check(L_.load().i2sdf_scale_seeds(L_.ptr(g), L_.ptr(sbar), sbar.numel(), L_.ptr(nbar), nbar.numel(), L_.ptr(rgb_bar), rgb_bar.numel(),
+                                                 L_.ptr(lmask_bar), 0 if lmask_bar is None else lmask_bar.numel(), L_.ptr(pre["beta_g"]),
+                                                 L_.ptr(gflat[off_beta:]), L_.stream_ptr()), "i2sdf_scale_seeds")
+        light = None
+        if net.use_light:
+            gal0, gal_last = eng.light_backward(ctx.lm, lmask_bar, ctx.hl, M_main)
+            light = {"hl": ctx.hl, "gal0": gal0, "gal_last": gal_last}
+        with eng.chain(fw["M"]):
+            gar, ga_last, fbar = eng.rgb_backward(ctx.rgb, rgb_bar, ctx.rs, M_main)
+            bw = eng.sdf_backward(fw, sbar=sbar, fbar=fbar, m_fbar=M_main, nbar=nbar)
+            eng.weight_grads(flat, gflat, fw, bw, M_main=M_main, fbar=fbar, rgb_fw={"pev": ctx.pev, "rs": ctx.rs},
+                             rgb_bw={"gar": gar, "ga_last": ga_last}, light=light)
+        return _RenderFn._finish(ctx, gflat)
 
 
 class _EikonalOutputsFn(torch.autograd.Function):
@@ -185,9 +246,10 @@ class _EikonalOutputsFn(torch.autograd.Function):
     (i2sdf_eikonal_outputs_*), instead of ~8 + ~25 element-wise torch kernels on (2B,3) tensors."""
 
     @staticmethod
-    def forward(ctx, g_all, B):
+    def forward(ctx, g_all, B, st=None):
         from . import lib as L_
         g_all = g_all.contiguous()
+        ctx.st = st
         theta = torch.empty(2 * B, 3, device=g_all.device)
         diff = torch.empty(B, device=g_all.device)
         with torch.cuda.device(g_all.device):
@@ -203,14 +265,36 @@ class _EikonalOutputsFn(torch.autograd.Function):
         from . import lib as L_
         (g_all,) = ctx.saved_tensors
         if g_theta is None and g_diff is None:
-            return None, None
+            return None, None, None
+        pre = ctx.st.get("pre") if ctx.st is not None else None
+        ctx.st = None
+        if pre is not None and pre["g"] is not None:
+            tk = pre["tok"]
+            same = lambda a, b: a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.numel() == b.numel()
+            if same(g_theta, tk["grad_theta"]) and (g_diff is None or same(g_diff, tk["diff_norm"])):
+                # the fused loss's own seeds, untouched: the extra points' gradient rows were already written by i2sdf_render_loss_backward;
+                # hand the placeholder on, so that _RenderFn.backward can tell that nobody else contributed.  `eik_true` computes the real
+                # thing if the placeholder should meet other gradients further down after all.
+                g_th, g_df, ga = g_theta, g_diff, g_all
+                pre["eik_true"] = lambda: _EikonalOutputsFn._bwd(ga, g_th * pre["g"].reshape(()), None if g_df is None else g_df * pre["g"].reshape(()), ctx.B)
+                return pre["tok_eik"], None, None
+            gs_ = pre["g"].reshape(()).to(torch.float32) - 1.0          # unscaled seeds mixed with other gradients: g * seed + the rest
+            if g_theta is not None and tk["grad_theta"] is not None:
+                g_theta = g_theta + gs_ * tk["grad_theta"]
+            if g_diff is not None and tk["diff_norm"] is not None:
+                g_diff = g_diff + gs_ * tk["diff_norm"]
+        return _EikonalOutputsFn._bwd(g_all, g_theta, g_diff, ctx.B), None, None
+
+    @staticmethod
+    def _bwd(g_all, g_theta, g_diff, B):
+        from . import lib as L_
         c = lambda t: None if t is None else t.contiguous()
         g_theta, g_diff = c(g_theta), c(g_diff)
         out = torch.empty_like(g_all)
         with torch.cuda.device(g_all.device):
-            L_.check(L_.load().i2sdf_eikonal_outputs_backward(L_.ptr(g_all), L_.ptr(g_theta), L_.ptr(g_diff), ctx.B, L_.ptr(out),
+            L_.check(L_.load().i2sdf_eikonal_outputs_backward(L_.ptr(g_all), L_.ptr(g_theta), L_.ptr(g_diff), B, L_.ptr(out),
                                                               L_.stream_ptr()), "i2sdf_eikonal_outputs_backward")
-        return out, None
+        return out
 
 
 class I2SDFNetwork(nn.Module):
@@ -407,9 +491,13 @@ class I2SDFNetwork(nn.Module):
             if predict_only:
                 return out
             if training:
-                self._eikonal_outputs(out, g_eik, surf, N, n_pc)
+                self._eikonal_outputs(out, g_eik, surf, N, n_pc, st)
                 if self.use_normal:
                     out["normal_values"] = normal
+                # I2SDFLoss looks for this handle: with it, loss + render backward run as one fused library call (loss.py).  The pointers
+                # identify the outputs (a clone / detach / slice of one is a different tensor: the loss then takes its general path)
+                st["out_ptrs"] = {k: v.data_ptr() for k, v in out.items()}
+                rgb._i2sdf_render = st
             else:
                 out["normal_map"] = normal.detach()
             return out
@@ -513,8 +601,8 @@ class I2SDFNetwork(nn.Module):
             return pts, 3 * N, n_pc
 
     @staticmethod
-    def _eikonal_outputs(out, g_all, surf, N, n_pc):
-        out["grad_theta"], out["diff_norm"] = _EikonalOutputsFn.apply(g_all, N)
+    def _eikonal_outputs(out, g_all, surf, N, n_pc, st=None):
+        out["grad_theta"], out["diff_norm"] = _EikonalOutputsFn.apply(g_all, N, st)
         if n_pc:
             out["surface_sdf"] = surf
 

@@ -502,6 +502,40 @@ int i2sdf_backward_seeds(float* beta_grad, int64_t n_beta, float* sdf_bar, float
                          const float* g_eik, int64_t n_eik, const float* g_surf, int64_t n_pc, int32_t zero_main_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Loss + render backward fused (round 6): I2SDFLoss -- model/network/__init__.py:289-406 -- evaluated on the outputs of a TRAINING render,
+ * together with the backward of everything between those outputs and the per-sample gradients the MLP backward starts from: the
+ * compositing backward (:223-240,:120-125,:169,:204-219), the backward of the eikonal / smoothness outputs (:188-193) and the seeds of the
+ * extra points.  Replaces i2sdf_loss_forward_backward + i2sdf_eikonal_outputs_backward + i2sdf_backward_seeds + i2sdf_composite_backward
+ * (seven launches and, in between, two of autograd's own) by two launches, for an upstream gradient of 1; i2sdf_scale_seeds multiplies the
+ * results by the gradient autograd delivers.  No data-parallel exchange hook here (cfg->exchange must be NULL: use the separate entry points).
+ *   batch layout as in i2sdf_backward_seeds: M_main = B n ray samples, then n_eik (= 3 B or 0) extra points [uniform | near | neighbour],
+ *     then n_pc bubble points (iff surface), M_sdf rows in all
+ *   compositing inputs as in i2sdf_composite_backward: beta_param, z (B, ldz), sdf (M_sdf), rgb_pts (M_main,3), grad_pts (M_sdf,3)|NULL
+ *     (d sdf / d x of every point: needed iff normal_term or n_eik), dnorm (B), nsum_save (B,3)|NULL (iff normal_term)
+ *   render outputs / ground truth as in i2sdf_loss_forward_backward (grad_theta (2B,3) and diff_norm (B) iff n_eik; surface (n_pc)|NULL)
+ *   -> losses (10), loss_value (1)|NULL, the output seeds g_* (as i2sdf_loss_forward_backward writes them),
+ *      sdf_bar (M_sdf), rgb_bar (M_main,3), grad_bar (M_sdf,3) -- every row written; normal_term = 0: the ray samples' rows are zeros --,
+ *      lmask_bar (M_main)|NULL, beta_grad (1) = d loss / d beta_param;  scratch: i2sdf_render_loss_scratch_floats(B) floats
+ * ---------------------------------------------------------------------------------------------- */
+int64_t i2sdf_render_loss_scratch_floats(int64_t B);
+int i2sdf_render_loss_backward(const i2sdf_loss_cfg* cfg, int64_t B, int32_t n, int64_t n_pc, int64_t M_main, int64_t M_sdf, int64_t n_eik,
+                               const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf, const float* rgb_pts,
+                               const float* grad_pts, const float* dnorm, const float* nsum_save,
+                               const float* rgb, const float* depth, const float* wsum, const float* normal, const float* grad_theta,
+                               const float* diff_norm, const float* surface, const float* lmask,
+                               const float* gt_rgb, const float* gt_depth, const uint8_t* depth_mask, const float* gt_normal,
+                               const uint8_t* normal_mask, const float* gt_mask, const float* gt_lmask,
+                               float* scratch, float* losses, float* loss_value,
+                               float* g_rgb, float* g_depth, float* g_wsum, float* g_normal, float* g_grad_theta, float* g_diff_norm,
+                               float* g_surface, float* g_lmask,
+                               float* sdf_bar, float* rgb_bar, float* grad_bar, int32_t normal_term, float* lmask_bar, float* beta_grad,
+                               void* stream);
+/* x *= g[0] for the four per-sample gradient tensors (n_* = their float counts; a pointer may be NULL with a count of 0) and
+ * beta_out[0] = beta_in[0] * g[0] (beta_out may be NULL); g = a device scalar (the gradient of the loss value autograd delivers). */
+int i2sdf_scale_seeds(const float* g, float* sdf_bar, int64_t n_sdf, float* grad_bar, int64_t n_grad, float* rgb_bar, int64_t n_rgb,
+                      float* lmask_bar, int64_t n_lmask, const float* beta_in, float* beta_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Full-image inference in one call -- the chunk loop of utils.split_input / model(chunk) /
  * utils.merge_output (utils/__init__.py:35-84) as used by model/eval/recon.py:161-182 and the plotting callbacks: eval mode,
  * `chunk` = split_n_pixels rays at a time, every chunk rendered exactly as the reference renders it (the sampler's convergence

@@ -528,10 +528,26 @@ void probe(const char* what, int pace) {
   fflush(stdout);
 }
 
+// PACED_RANDOM=1: the tensors and the weight stream hold pseudo-random values instead of zeros (real kernels multiply real data: the matrix
+// pipe's and the memory system's power draw depend on it -- profiles/r6_sweeps_vs_model.txt)
+__global__ void fill_random(float* p, long n, unsigned seed, float lo, float hi) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    p[i] = lo + (hi - lo) * (float)(x >> 8) * (1.0f / 16777216.0f);
+  }
+}
+
 int main() {
   hipMalloc(&g_src, (size_t)3 * TENSOR * 4); hipMalloc(&g_dst, (size_t)2 * TENSOR * 4); hipMalloc(&g_sink, 4096); hipMalloc(&g_out, 2 * 1024 * 8);
   hipMemset(g_src, 0, (size_t)3 * TENSOR * 4); hipMemset(g_dst, 0, (size_t)2 * TENSOR * 4);
   hipMalloc(&g_wts, 12 * 32768 + 65536); hipMemset(g_wts, 0, 12 * 32768 + 65536);
+  if (getenv("PACED_RANDOM")) {
+    fill_random<<<4096, 256>>>(g_src, 3 * TENSOR, 1u, 0.0f, 0.05f);          // h-like: small positive activations (sigma = 1 - exp(-100 h) spans (0, 1))
+    fill_random<<<4096, 256>>>(g_wts, (12 * 32768 + 65536) / 4, 7u, -1.0f, 1.0f);
+    hipDeviceSynchronize();
+    printf("(tensors and weights: pseudo-random values)\n");
+  }
   const bool r6_only = getenv("PACED_R6_ONLY") != nullptr;
   if (!r6_only) {
   printf("== the two sides alone\n");

@@ -28,6 +28,12 @@ def _check(stdout, n, equivalent=False):
     assert f"dp{n}" in d["config"]["parallelism"]
     if n > 1:
         assert "torch.distributed all_reduce" in d["config"]["parallelism"] and d["config"]["backend"] == "gloo"
+        # round 6: one line shows a straggler or a transport fall-back -- the windows as the fastest and the slowest rank saw them, the rank
+        # count the library's RCCL communicator reports (None here: gloo carries the collective)
+        rk = d["ranks"]
+        assert 0 < rk["ms_per_step_fastest_rank"] <= rk["ms_per_step_slowest_rank"] == d["ms_per_step"]
+        assert len(rk["windows_ms_per_step_fastest_rank"]) == len(d["windows_ms_per_step"])
+        assert rk["rccl_nranks"] is None and rk["torch_world_size"] == n and "torch.distributed" in rk["transport"]
         ar = d["allreduce_us"]                      # the collective of a step timed alone: the record the first N-GPU run will carry
         assert ar["unit"] == "us" and ar["value"] > 0 and ar["bytes"] > 3_000_000 and "torch.distributed" in ar["transport"]
         # round 5: what the collective costs THE STEP -- the same step under no_sync() and the difference, next to the collective alone
@@ -37,7 +43,7 @@ def _check(stdout, n, equivalent=False):
         else:
             assert "step_ms_without_allreduce" not in d      # the sampler's flag exchange keeps running under no_sync(): the pair would not isolate the all-reduce
     else:
-        assert "step_ms_without_allreduce" not in d and "exposed_allreduce_ms" not in d
+        assert "step_ms_without_allreduce" not in d and "exposed_allreduce_ms" not in d and "ranks" not in d
     assert len(d["strong"]["windows_ms_per_step"]) >= 1 and d["strong"]["us_per_ray"] > 0 and d["us_per_ray"] > 0
     return d
 

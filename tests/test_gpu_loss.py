@@ -109,3 +109,85 @@ def test_extra_points_and_backward_seeds_match_the_torch_glue_bitwise():
     # argument checks
     assert lib.i2sdf_backward_seeds(None, 1, None, None, 0, 0, None, 0, None, 0, 0, L.stream_ptr()) != 0
     assert lib.i2sdf_backward_seeds(L.ptr(beta), 1, L.ptr(sbar), L.ptr(nbar), 10, 12, None, 3, None, 0, 0, L.stream_ptr()) != 0      # n_eik > extra rows
+
+
+# ---- round 6: loss + render backward fused (i2sdf_render_loss_backward) against the separate path, same process, same draws -------------
+def _step(net, loss_fn, inp, gt, draws, step, fused, scale=1.0, extra=None):
+    """one forward + loss + backward; returns (loss dict, flat gradient copy).  fused=False forces the separate path."""
+    import os
+    os.environ["I2SDF_FUSED_RENDER_LOSS"] = "1" if fused else "0"
+    try:
+        for p in net.parameters():
+            p.grad = None
+        out = net(inp, draws=draws)
+        res = loss_fn(out, gt, step)
+        tot = res["loss"] * scale
+        if extra is not None:
+            tot = tot + extra(out)
+        tot.backward()
+        g = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone()
+        return {k: v.detach().clone() for k, v in res.items()}, g, out
+    finally:
+        os.environ.pop("I2SDF_FUSED_RENDER_LOSS", None)
+
+
+@pytest.mark.parametrize("light,n_pc,step,scale", [(False, 0, 10, 1.0), (True, 0, 10, 0.37), (False, 37, 60000, 1.0), (False, 0, 200000, 2.5)])
+def test_fused_render_loss_equals_the_separate_path(light, n_pc, step, scale, wgrad_mode):
+    """The module's default path -- I2SDFLoss recognises the outputs of a training render and runs loss + render backward as one fused library
+    call -- against the separate entry points (I2SDF_FUSED_RENDER_LOSS=0): same reported values, same parameter gradients (the per-sample
+    gradients are computed by the same device functions; sums are taken in a different but fixed order -> 1e-6), with a light head, with a
+    bubble point cloud (step inside the bubble window), with the smoothness term active (step behind smooth_iter) and with an upstream
+    gradient that is not 1."""
+    from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
+    from helpers import camera_inputs, make_gt
+    conf = synthetic_conf(light)
+    conf["use_normal"] = True
+    torch.manual_seed(5)
+    net = I2SDFNetwork(conf).cuda().train()
+    with torch.no_grad():
+        net.density.beta.fill_(0.05)
+    B = 203
+    inp = {k: v.cuda() for k, v in camera_inputs(B, (0.0, 0.0, -2.0), seed=11).items()}
+    if n_pc:
+        inp["pointcloud"] = (torch.rand(n_pc, 3, device="cuda") * 2 - 1) * 0.7
+    gt = {k: v.cuda() for k, v in make_gt(B).items()}
+    gt["depth_mask"][::3] = False
+    gt["normal_mask"][1::4] = False
+    if light:
+        gt["light_mask"] = (torch.rand(B, 1, device="cuda") > 0.5).float()
+    loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=150000, depth_weight=0.1, normal_weight=0.05, bubble_weight=0.5 if n_pc else 0.0,
+                        min_bubble_iter=50000, max_bubble_iter=150000, light_mask_weight=0.5 if light else 0.0)
+    eng = net._engine_for(torch.device("cuda:0"))
+    draws = {k: v for k, v in eng.training_draws(B, 1234, "cuda", net.scene_bounding_sphere).items() if v is not None}
+    net.force_iters = 2
+    r_sep, g_sep, _ = _step(net, loss_fn, inp, gt, draws, step, fused=False, scale=scale)
+    r_fus, g_fus, out = _step(net, loss_fn, inp, gt, draws, step, fused=True, scale=scale)
+    assert getattr(out["rgb_values"], "_i2sdf_render", None) is not None
+    for k in r_sep:
+        assert_close(r_fus[k], r_sep[k], 2e-6, f"loss term {k}", floor=1e-6)
+    assert torch.isfinite(g_fus).all()
+    assert_close(g_fus, g_sep, 2e-6, "parameter gradients, fused vs separate")
+
+
+def test_fused_render_loss_with_other_consumers_of_the_outputs(wgrad_mode):
+    """Another differentiable term on the same outputs: the loss's seeds reach _RenderFn.backward summed with foreign gradients -- the fused
+    path must notice (its placeholders do not arrive untouched), correct for the upstream scale and give what the separate path gives."""
+    from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
+    from helpers import camera_inputs, make_gt
+    conf = synthetic_conf(False)
+    conf["use_normal"] = True
+    torch.manual_seed(6)
+    net = I2SDFNetwork(conf).cuda().train()
+    B = 64
+    inp = {k: v.cuda() for k, v in camera_inputs(B, (0.0, 0.0, -2.0), seed=12).items()}
+    gt = {k: v.cuda() for k, v in make_gt(B).items()}
+    loss_fn = I2SDFLoss(eikonal_weight=0.1, smooth_weight=0.01, smooth_iter=None, depth_weight=0.1, normal_weight=0.05)
+    eng = net._engine_for(torch.device("cuda:0"))
+    draws = {k: v for k, v in eng.training_draws(B, 99, "cuda", net.scene_bounding_sphere).items() if v is not None}
+    net.force_iters = 1
+    for extra in (lambda o: 0.1 * o["rgb_values"].sum() + 0.05 * o["depth_values"].mean(),
+                  lambda o: 0.02 * o["grad_theta"].pow(2).sum(),
+                  lambda o: 0.3 * o["diff_norm"].sum() + 0.1 * o["normal_values"][:, 0].sum()):
+        _, g_sep, _ = _step(net, loss_fn, inp, gt, draws, 10, fused=False, scale=0.7, extra=extra)
+        _, g_fus, _ = _step(net, loss_fn, inp, gt, draws, 10, fused=True, scale=0.7, extra=extra)
+        assert_close(g_fus, g_sep, 5e-6, "parameter gradients with a foreign term, fused vs separate")

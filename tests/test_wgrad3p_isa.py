@@ -164,3 +164,80 @@ def test_wgrad_narrow_bf16_has_no_spills_in_its_loops(isa):
                 bad.append(ln.strip())
     assert n_loop_blocks > 10
     assert not bad, bad[:5]
+
+
+# ---- round 6: wgrad_all_kernel = the 256x256 blocks AND the narrow / 128x128 tasks of a point range in ONE grid (the kernel the default
+# path launches); the same three contracts on the merged kernel, where one body's register needs could leak into another's code
+def _bodies_named(lines, pat):
+    out, cur = {}, None
+    for ln in lines:
+        m = re.match(r"^(_Z\w*" + pat + r"\w*):", ln)
+        if m:
+            cur = m.group(1); out[cur] = []
+        elif cur is not None:
+            if ln.startswith(".Lfunc_end"):
+                cur = None
+            else:
+                out[cur].append(ln)
+    return out
+
+
+def test_wgrad_all_kernel_keeps_the_accumulator_windows(isa):
+    lines, remarks = isa
+    ks = _bodies_named(lines, "wgrad_all_kernel")
+    assert len(ks) == 2, list(ks)                       # two / three planes for the 256x256 blocks
+    for name, body in ks.items():
+        in_asm, events = False, []
+        for ln in body:
+            if "#ASMSTART" in ln:
+                in_asm = True; continue
+            if "#ASMEND" in ln:
+                in_asm = False; continue
+            code = ln.split(";")[0].strip()
+            if not code or code.startswith("."):
+                continue
+            if in_asm:
+                if code.startswith("v_mfma"):
+                    events.append("M")
+                elif code.startswith("v_accvgpr_read"):
+                    events.append("R")
+                elif code.startswith("v_accvgpr_write") or code.startswith(".rept"):
+                    events.append("Z")
+            else:
+                assert "v_mfma" not in code, f"{name}: an MFMA outside the inline asm: {code}"
+                if re.search(r"[ ,]a(\[\d+|\d+)", " " + code):
+                    events.append("C")
+        runs = re.sub(r"(.)\1+", r"\1", "".join(events))
+        # every body: zero fill -> asm MFMAs -> read-out [-> ordinary code that may use AGPRs: only the narrow bodies' cross-wave sums]
+        assert re.fullmatch(r"(ZMRC?)+", runs), f"{name}: unexpected order of zero fill / MFMAs / read-out / compiler AGPR uses: {runs}"
+        assert events.count("M") >= 8 * 48 + 3 * 12, (name, events.count("M"))
+    for m in re.finditer(r"Function Name: (\S*wgrad_all_kernel\S*)(.*?)Occupancy", remarks, re.S):
+        sz = int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", m.group(2)).group(1))
+        assert sz <= 8, (m.group(1), sz)
+
+
+def test_wgrad_all_kernel_loops_are_clean(isa):
+    """the stage loops of the 256x256 bodies inside the merged kernel: no scratch, no row copies, no low vmcnt waits (as for wgrad3p_kernel
+    above), and no scratch access inside ANY loop of the kernel"""
+    lines, _ = isa
+    for name, body in _bodies_named(lines, "wgrad_all_kernel").items():
+        blocks, cur, loop_blocks, bad = {}, None, 0, []
+        in_loop = False
+        for ln in body:
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                cur = m.group(1); blocks[cur] = []
+                in_loop = "Loop" in ln
+                loop_blocks += in_loop
+            elif cur is not None:
+                blocks[cur].append(ln.split(";")[0])
+                if in_loop and "scratch_" in ln.split(";")[0]:
+                    bad.append(ln.strip())
+        assert loop_blocks > 10 and not bad, (name, bad[:5])
+        loops = {k: v for k, v in blocks.items() if sum("v_mfma" in x for x in v) >= 96 and any(re.search(r"s_cbranch\w+ " + re.escape(k) + r"\b", x) for x in v)}
+        assert loops, name
+        for k, v in loops.items():
+            assert not any(re.search(r"\bv_mov_b(32|64)", x) for x in v), (name, k, [x.strip() for x in v if "v_mov_b" in x][:4])
+            assert not any(re.search(r"v_accvgpr", x) for x in v), (name, k)
+            low = [x.strip() for x in v if re.search(r"s_waitcnt vmcnt\([0-3]\)", x)]
+            assert not low, (name, k, low)
