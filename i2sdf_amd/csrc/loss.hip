@@ -102,15 +102,7 @@ __global__ __launch_bounds__(256) void eik_out_fwd_kernel(const float* __restric
                                                            float* __restrict__ diff) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= B) return;
-  float v1[3], n1[3], r1, v2[3], n2[3], r2;
-  unit3(g + (B + i) * 3, v1, n1, r1);
-  unit3(g + (2 * B + i) * 3, v2, n2, r2);
-  const float dx = n1[0] - n2[0], dy = n1[1] - n2[1], dz = n1[2] - n2[2];
-  diff[i] = sqrtf(dx * dx + dy * dy + dz * dz);
-  if (theta) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { theta[i * 3 + c] = g[i * 3 + c]; theta[(B + i) * 3 + c] = v1[c]; }
-  }
+  eik_out_fwd_point(g, B, i, theta, diff);
 }
 
 __global__ __launch_bounds__(256) void eik_out_bwd_kernel(const float* __restrict__ g, const float* __restrict__ theta_bar,

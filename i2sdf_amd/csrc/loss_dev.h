@@ -137,6 +137,19 @@ __device__ __forceinline__ void unit3_bwd(const float (&n)[3], float r, const fl
     for (int c = 0; c < 3; ++c) gv[c] = gn[c] * (1.0f / NRM_EPS);
   }
 }
+// forward of point index i: theta rows i, B + i (the raw gradients), diff_norm[i] = || normalize(g[B+i]) - normalize(g[2B+i]) ||
+__device__ __forceinline__ void eik_out_fwd_point(const float* __restrict__ g, int64_t B, int64_t i, float* __restrict__ theta, float* __restrict__ diff) {
+#pragma clang fp contract(off)
+  float v1[3], n1[3], r1, v2[3], n2[3], r2;
+  unit3(g + (B + i) * 3, v1, n1, r1);
+  unit3(g + (2 * B + i) * 3, v2, n2, r2);
+  const float dx = n1[0] - n2[0], dy = n1[1] - n2[1], dz = n1[2] - n2[2];
+  diff[i] = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (theta) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { theta[i * 3 + c] = g[i * 3 + c]; theta[(B + i) * 3 + c] = v1[c]; }
+  }
+}
 // backward of (grad_theta rows i, B+i; diff_norm[i]) w.r.t. the gradients g of the extra points i, B+i, 2B+i: o0 / o1 / o2
 // th0 / th1: d loss / d grad_theta rows i and B+i (zeros if there is none); db: d loss / d diff_norm[i] (has_diff: is there one)
 __device__ __forceinline__ void eik_out_bwd_point(const float* __restrict__ g, int64_t B, int64_t i, const float (&th0)[3], const float (&th1)[3],

@@ -155,6 +155,9 @@ struct CompArgs {
   // backward
   const float* g_rgb; const float* g_depth; const float* g_wsum; const float* g_normal; const float* g_lmask;
   float* sdf_bar; float* rgb_bar; float* grad_bar; float* lmask_bar; float* beta_bar_partial;   // (B)
+  // composite forward + the eikonal / smoothness outputs of the extra points in one launch (i2sdf_composite_forward_eik): eik_g (3B,3) =
+  // d sdf / d x of the extra points -> eik_theta (2B,3), eik_diff (B); the wave of ray i does point index i
+  const float* eik_g = nullptr; float* eik_theta = nullptr; float* eik_diff = nullptr;
   float* grad_bar_all = nullptr;          // fused loss + backward only: the whole (M_sdf,3) d loss / d grad tensor (grad_bar = its ray-sample rows when there is a normal term, else NULL)
 };
 
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompArgs a) {
       if (a.nsum_save) { a.nsum_save[ray * 3 + 0] = acc_n[0]; a.nsum_save[ray * 3 + 1] = acc_n[1]; a.nsum_save[ray * 3 + 2] = acc_n[2]; }
     }
     if (a.o_lmask) a.o_lmask[ray] = acc_l;
+    if (a.eik_g) eik_out_fwd_point(a.eik_g, a.B, ray, a.eik_theta, a.eik_diff);
   }
 }
 
@@ -626,4 +630,24 @@ extern "C" int i2sdf_scale_seeds(const float* g, float* sdf_bar, int64_t n_sdf, 
   const unsigned grid = (unsigned)std::min<int64_t>(std::max<int64_t>((most + 255) / 256, 1), 2048);
   scale_seeds_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(g, sdf_bar, n_sdf, grad_bar, n_grad, rgb_bar, n_rgb, lmask_bar, n_lmask, beta_in, beta_out);
   return i2sdf_hip_check(hipGetLastError(), "scale_seeds launch");
+}
+
+// i2sdf_composite_forward + i2sdf_eikonal_outputs_forward in ONE launch (round 6: the training forward's two per-ray launches between the
+// radiance net and the loss): grad_all (3B,3) = d sdf / d x of the extra points [uniform | near | neighbour] -> grad_theta (2B,3), diff_norm (B)
+extern "C" int i2sdf_composite_forward_eik(const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf,
+                                           const float* rgb, const float* grad, const float* lmask, const float* dnorm, int64_t B, int32_t n,
+                                           float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* w_save,
+                                           float* nsum_save, const float* grad_all, float* grad_theta, float* diff_norm, void* stream) {
+  if (B == 0) return I2SDF_OK;
+  if (!beta_param || !z || !sdf || !rgb || !dnorm || !o_rgb || !o_depth || !o_wsum || B < 0 || n <= 0 || n > 64 * MAX_SEG) return I2SDF_EINVAL;
+  if (o_normal && !grad) return I2SDF_EINVAL;
+  if (o_lmask && !lmask) return I2SDF_EINVAL;
+  if (!grad_all || !grad_theta || !diff_norm) return I2SDF_EINVAL;
+  CompArgs a{};
+  a.beta_param = beta_param; a.beta_min = beta_min; a.z = z; a.ldz = ldz; a.sdf = sdf; a.rgb = rgb; a.grad = o_normal ? grad : nullptr;
+  a.lmask = o_lmask ? lmask : nullptr; a.dnorm = dnorm; a.B = B; a.n = n;
+  a.o_rgb = o_rgb; a.o_depth = o_depth; a.o_wsum = o_wsum; a.o_normal = o_normal; a.o_lmask = o_lmask; a.w_save = w_save; a.nsum_save = nsum_save;
+  a.eik_g = grad_all; a.eik_theta = grad_theta; a.eik_diff = diff_norm;
+  composite_fwd_kernel<<<(unsigned)((B + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  return i2sdf_hip_check(hipGetLastError(), "composite_forward_eik launch");
 }

@@ -409,7 +409,9 @@ class RenderEngine:
             raise ValueError(f"BOUNDING SPHERE PROBLEM: {int(miss.item())} rays do not intersect the sphere of radius {radius}")
         return out
 
-    def composite_forward(self, beta_param, z_all, sdf, rgb, grad, lmask, dnorm, want_normal, save=True):
+    def composite_forward(self, beta_param, z_all, sdf, rgb, grad, lmask, dnorm, want_normal, save=True, eik_grad=None):
+        """eik_grad (3B,3): d sdf / d x of the extra points -> also o["grad_theta"] (2B,3), o["diff_norm"] (B) from the same launch
+        (i2sdf_composite_forward_eik)"""
         B, n = z_all.shape[0], z_all.shape[1] - 1
         dev = z_all.device
         o = {"rgb": torch.empty(B, 3, device=dev), "depth": torch.empty(B, device=dev), "wsum": torch.empty(B, 1, device=dev)}
@@ -417,6 +419,14 @@ class RenderEngine:
         o["lmask"] = torch.empty(B, 1, device=dev) if lmask is not None else None
         o["w"] = torch.empty(B, n, device=dev) if save else None
         o["nsum"] = torch.empty(B, 3, device=dev) if (save and want_normal) else None
+        if eik_grad is not None and eik_grad.shape[0] == 3 * B and B > 0:
+            o["grad_theta"], o["diff_norm"] = torch.empty(2 * B, 3, device=dev), torch.empty(B, device=dev)
+            L.check(self._lib.i2sdf_composite_forward_eik(L.ptr(beta_param), self.cfg.beta_min, L.ptr(z_all), z_all.shape[1], L.ptr(sdf),
+                                                           L.ptr(rgb), L.ptr(grad) if want_normal else None, L.ptr(lmask), L.ptr(dnorm), B, n,
+                                                           L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["wsum"]), L.ptr(o["normal"]),
+                                                           L.ptr(o["lmask"]), L.ptr(o["w"]), L.ptr(o["nsum"]), L.ptr(eik_grad.contiguous()),
+                                                           L.ptr(o["grad_theta"]), L.ptr(o["diff_norm"]), L.stream_ptr()), "i2sdf_composite_forward_eik")
+            return o
         L.check(self._lib.i2sdf_composite_forward(L.ptr(beta_param), self.cfg.beta_min, L.ptr(z_all), z_all.shape[1], L.ptr(sdf),
                                                    L.ptr(rgb), L.ptr(grad) if want_normal else None, L.ptr(lmask), L.ptr(dnorm), B, n,
                                                    L.ptr(o["rgb"]), L.ptr(o["depth"]), L.ptr(o["wsum"]), L.ptr(o["normal"]),

@@ -160,6 +160,7 @@ SIGNATURES = {
     "i2sdf_ray_batch": (C.c_int, [C.POINTER(RayTables), _P, _I64, C.POINTER(RayBatch), _P]),
     "i2sdf_sphere_intersections": (C.c_int, [_P, _P, _I64, _F, _P, _P, _P]),
     "i2sdf_composite_forward": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 8),
+    "i2sdf_composite_forward_eik": (C.c_int, [_P, _F, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32] + [_P] * 11),
     "i2sdf_composite_backward": (C.c_int, [_P, _F, _P, _I64] + [_P] * 5 + [_I64, _I32] + [_P] * 12),
 }
 

@@ -111,7 +111,11 @@ class _RenderFn(torch.autograd.Function):
         if net.use_light:
             lm, hl = eng.light_forward(fw["feat"], M_main, save=True)
         beta_param = flat[eng.layout.offset("density.beta"):]
-        comp = eng.composite_forward(beta_param, st["z_all"], fw["sdf"], rgb, fw["grad"], lm, st["dnorm"], want_normal=st["want_normal"])
+        n_eik0 = st["n_eik"]
+        comp = eng.composite_forward(beta_param, st["z_all"], fw["sdf"], rgb, fw["grad"], lm, st["dnorm"], want_normal=st["want_normal"],
+                                     eik_grad=fw["grad"][M_main:M_main + n_eik0] if n_eik0 == 3 * B else None)
+        # (the eikonal / smoothness outputs came out of the same launch: _EikonalOutputsFn.forward returns them instead of launching)
+        st["eik_out"] = (comp.pop("grad_theta"), comp.pop("diff_norm")) if "grad_theta" in comp else None
         ctx.net, ctx.st, ctx.fw, ctx.rgb, ctx.rs, ctx.pev, ctx.lm, ctx.hl, ctx.comp = net, st, fw, rgb, rs, pev, lm, hl, comp
         ctx.M_main = M_main
         # for I2SDFLoss's fused path (loss.py: _FusedRenderLossFn -> i2sdf_render_loss_backward): the compositing inputs of this render.
@@ -250,11 +254,15 @@ class _EikonalOutputsFn(torch.autograd.Function):
         from . import lib as L_
         g_all = g_all.contiguous()
         ctx.st = st
-        theta = torch.empty(2 * B, 3, device=g_all.device)
-        diff = torch.empty(B, device=g_all.device)
-        with torch.cuda.device(g_all.device):
-            L_.check(L_.load().i2sdf_eikonal_outputs_forward(L_.ptr(g_all), B, L_.ptr(theta), L_.ptr(diff), L_.stream_ptr()),
-                     "i2sdf_eikonal_outputs_forward")
+        pre_out = st.pop("eik_out", None) if st is not None else None
+        if pre_out is not None:
+            theta, diff = pre_out            # computed by the compositing launch of _RenderFn.forward (i2sdf_composite_forward_eik)
+        else:
+            theta = torch.empty(2 * B, 3, device=g_all.device)
+            diff = torch.empty(B, device=g_all.device)
+            with torch.cuda.device(g_all.device):
+                L_.check(L_.load().i2sdf_eikonal_outputs_forward(L_.ptr(g_all), B, L_.ptr(theta), L_.ptr(diff), L_.stream_ptr()),
+                         "i2sdf_eikonal_outputs_forward")
         ctx.save_for_backward(g_all)
         ctx.B = B
         ctx.set_materialize_grads(False)

@@ -303,6 +303,13 @@ int i2sdf_composite_forward(const float* beta_param, float beta_min, const float
                             float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* w_save,
                             float* nsum_save, void* stream);
 
+/* The same and i2sdf_eikonal_outputs_forward (below) in ONE launch -- the two per-ray launches of a training forward between the radiance
+ * net and the loss: grad_all (3B,3) = d sdf / d x of the extra points [uniform | near | neighbour] -> grad_theta (2B,3), diff_norm (B). */
+int i2sdf_composite_forward_eik(const float* beta_param, float beta_min, const float* z, int64_t ldz, const float* sdf,
+                                const float* rgb, const float* grad, const float* lmask, const float* dnorm, int64_t B, int32_t n,
+                                float* o_rgb, float* o_depth, float* o_wsum, float* o_normal, float* o_lmask, float* w_save,
+                                float* nsum_save, const float* grad_all, float* grad_theta, float* diff_norm, void* stream);
+
 /* Backward of the above (what loss.backward() does through :118-125,:169,:204-209).
  * Upstream: g_rgb (B,3), g_depth (B)|NULL, g_wsum (B)|NULL, g_normal (B,3)|NULL (w.r.t. normal_values),
  * g_lmask (B)|NULL.  The normal / light composites use w.detach() as the reference does in training.
