@@ -108,7 +108,7 @@ class _FusedRenderLossFn(torch.autograd.Function):
             toks[5] = None      # smoothness term inactive: no gradient for diff_norm (as in _FusedLossFn)
             pre["tok"]["diff_norm"] = None
         h["pre"] = pre
-        ctx.pre, ctx.toks = pre, toks
+        ctx.pre, ctx.toks, ctx.h = pre, toks, h
         ctx.mark_non_differentiable(losses)
         ctx.set_materialize_grads(False)
         return total, losses
@@ -117,10 +117,16 @@ class _FusedRenderLossFn(torch.autograd.Function):
     def backward(ctx, g, _g_items):
         if g is None:
             return (None,) * (4 + len(ctx.toks))
-        ctx.pre["g"] = g
-        out = (None, None, None, None) + tuple(ctx.toks)
-        ctx.pre = ctx.toks = None
-        return out
+        pre, toks, h = ctx.pre, ctx.toks, ctx.h
+        ctx.pre = ctx.toks = ctx.h = None
+        if h.get("pre") is not pre:
+            # a later loss call on the same outputs replaced this call's prepared gradients (or the render's backward already ran): the
+            # placeholders mean nothing to _RenderFn.backward any more -- hand autograd the real thing, seeds times the upstream gradient
+            live = [t for t in toks if t is not None]
+            scaled = iter(torch._foreach_mul(live, g))
+            return (None, None, None, None) + tuple((next(scaled) if t is not None else None) for t in toks)
+        pre["g"] = g
+        return (None, None, None, None) + tuple(toks)
 
 
 class I2SDFLoss(nn.Module):

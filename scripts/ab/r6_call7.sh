@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU call 7 of round 6: smoke(), the loss tests after the superseded-call fix, the N > 1 bench line of two ranks on one GPU (gloo)
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+python -c "import __graft_entry__ as g; g.smoke(); print('SMOKE_OK')" > $O/r6_c7_smoke.log 2>&1; tail -3 $O/r6_c7_smoke.log
+python -m pytest tests/test_gpu_loss.py tests/test_gpu_rccl.py tests/test_gpu_dp_equivalence.py tests/test_gpu_training_parity.py -q > $O/r6_c7_tests.log 2>&1; tail -3 $O/r6_c7_tests.log
+timeout 600 python bench.py --gpus 2 --backend gloo --share-gpu --steps 5 --warmup 2 --windows 3 --no-cpu-baseline > $O/r6_two_ranks_one_gpu.log 2>&1
+python - <<'PY'
+import json
+ls=[l for l in open("gpurun_out/r6_two_ranks_one_gpu.log") if l.startswith("{")]
+if ls:
+    d=json.loads(ls[-1]); print({k:d.get(k) for k in ("n_gpus","ms_per_step","ranks","allreduce_us","exposed_allreduce_ms","step_ms_without_allreduce")})
+else:
+    print(open("gpurun_out/r6_two_ranks_one_gpu.log").read()[-1500:])
+PY

@@ -191,3 +191,38 @@ def test_fused_render_loss_with_other_consumers_of_the_outputs(wgrad_mode):
         _, g_sep, _ = _step(net, loss_fn, inp, gt, draws, 10, fused=False, scale=0.7, extra=extra)
         _, g_fus, _ = _step(net, loss_fn, inp, gt, draws, 10, fused=True, scale=0.7, extra=extra)
         assert_close(g_fus, g_sep, 5e-6, "parameter gradients with a foreign term, fused vs separate")
+
+
+def test_fused_render_loss_called_twice_on_the_same_outputs(wgrad_mode):
+    """Two loss calls on one render's outputs (e.g. a logging call and the training call with other weights), backward through a weighted
+    sum of both: the first call's prepared gradients are superseded by the second's -- its node must then give autograd real, scaled
+    gradients -- and the result must equal the separate path's."""
+    from i2sdf_amd import I2SDFNetwork, I2SDFLoss, synthetic_conf
+    from helpers import camera_inputs, make_gt
+    import os
+    conf = synthetic_conf(False)
+    conf["use_normal"] = True
+    torch.manual_seed(8)
+    net = I2SDFNetwork(conf).cuda().train()
+    B = 48
+    inp = {k: v.cuda() for k, v in camera_inputs(B, (0.0, 0.0, -2.0), seed=13).items()}
+    gt = {k: v.cuda() for k, v in make_gt(B).items()}
+    l1 = I2SDFLoss(eikonal_weight=0.1, depth_weight=0.1, normal_weight=0.05)
+    l2 = I2SDFLoss(eikonal_weight=0.3, depth_weight=0.0, normal_weight=0.2, smooth_weight=0.05, smooth_iter=None)
+    eng = net._engine_for(torch.device("cuda:0"))
+    draws = {k: v for k, v in eng.training_draws(B, 5, "cuda", net.scene_bounding_sphere).items() if v is not None}
+    net.force_iters = 1
+    res = []
+    for fused in (False, True):
+        os.environ["I2SDF_FUSED_RENDER_LOSS"] = "1" if fused else "0"
+        try:
+            for p in net.parameters():
+                p.grad = None
+            out = net(inp, draws=draws)
+            a, b = l1(out, gt, 10)["loss"], l2(out, gt, 10)["loss"]
+            (0.6 * a + 1.7 * b).backward()
+            res.append((torch.cat([p.grad.reshape(-1) for p in net.parameters()]).clone(), a.detach().clone(), b.detach().clone()))
+        finally:
+            os.environ.pop("I2SDF_FUSED_RENDER_LOSS", None)
+    assert_close(res[1][1], res[0][1], 2e-6, "first loss value"); assert_close(res[1][2], res[0][2], 2e-6, "second loss value")
+    assert_close(res[1][0], res[0][0], 5e-6, "parameter gradients of a weighted sum of two loss calls, fused vs separate")

@@ -21,7 +21,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 BUDGET = {
     "sdf_fwd3h_kernel": (0, 256), "sdf_train_fwd3h_kernel": (0, 256), "rgb_fwd3h_kernel": (0, 256), "rgb_bwd3h_kernel": (0, 256),
     "sdf_igrad3_kernel": (0, 512), "sdf_bwd3_sweep1_kernel": (0, 512), "sdf_bwd3_sweep2_kernel": (0, 512),
-    "wgrad3p_kernel": (0, 512), "wgrad_narrow_kernelILi3E": (8, 512), "wgrad_all_kernel": (8, 512),      # (<0>, the fp32-input form of the non-default path, spills: known)
+    "wgrad3p_kernel": (0, 512), "wgrad_narrow_kernelILi3E": (8, 512), "wgrad_all_kernel": (8, 512),
+    # the fp32-input form of the narrow blocks (what I2SDF_OPT_WGRAD_BF16X3 = 0 selects; off by default for 256-wide plans since round 6)
+    # spills 104 B per lane: known, held where it is
+    "wgrad_narrow_kernelILi0E": (104, 512),
 }
 
 
