@@ -57,8 +57,9 @@ def test_sampler_eval_vs_reference_golden(golden, tag):
     robust_z_check(zo, z[f"{tag}.z_vals"], what=f"z_vals[{tag}]")
 
 
+# (the last case: the BASELINE batch width -- 1024 rays, five iterations -- against the oracle's own sampler in fp64)
 @pytest.mark.parametrize("which,tvec,beta,B", [("synthetic", (0.1, -0.2, 0.3), 0.1, 256), ("synthetic", (0.0, 0.0, -2.0), 0.02, 256),
-                                               ("light", (0.0, 0.0, -2.0), 0.02, 200)])
+                                               ("light", (0.0, 0.0, -2.0), 0.02, 200), ("synthetic", (0.0, 0.0, -2.0), 0.02, 1024)])
 @pytest.mark.parametrize("planes", [2, 3])
 def test_sampler_eval_full_size(which, tvec, beta, B, planes):
     """planes: split planes per operand of the sampler's sdf-only passes -- 2 = I2SDF_OPT_SAMPLER_BF16X2 (the default since round 6),
