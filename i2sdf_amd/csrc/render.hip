@@ -12,18 +12,24 @@ namespace {
 
 constexpr int MAX_SEG = 4;      // up to 256 samples per ray
 
+// wave-wide inclusive scan / sum by DPP (row_shr:1/2/4/8 inside the 16-lane rows, row_bcast:15 / :31 across them) instead of six dependent
+// ds_bpermute_b32 round trips through the LDS crossbar each (round 6; sampler.hip has the same pair with its measurements)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov0(float v) {      // lanes without a source lane (or outside ROW_MASK) get 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const float t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
+  (void)lane;
+  v += dpp_mov0<0x111, 0xf>(v);
+  v += dpp_mov0<0x112, 0xf>(v);
+  v += dpp_mov0<0x114, 0xf>(v);
+  v += dpp_mov0<0x118, 0xf>(v);
+  v += dpp_mov0<0x142, 0xa>(v);      // row_bcast:15 -> rows 1 and 3
+  v += dpp_mov0<0x143, 0xc>(v);      // row_bcast:31 -> rows 2 and 3
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_incl_scan(v, 0)), 63));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -30,23 +30,61 @@ constexpr int EMAX = NMAX / 64;
 // state words
 enum { ST_DONE = 0, ST_ITERS = 1, ST_FLAG0 = 2 /* +it */, ST_CNT0 = 16 /* +it: workgroups that finished step B of iteration it */, ST_WORDS = 32 };
 
-__device__ __forceinline__ float wsum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+// Wave-wide sum / max / inclusive scan by DPP (round 6).  The __shfl_* forms compile to ds_bpermute_b32 -- a trip through the LDS crossbar,
+// ~100 cycles of latency each -- and the bisection of beta_step runs eighteen of them, strictly dependent, in every one of its eleven error-bound
+// evaluations: at 1024 rays (one workgroup per CU) that latency chain WAS the kernel.  DPP moves data inside the VALU: row_shr:1/2/4/8 scan the
+// four 16-lane rows, row_bcast:15 / :31 carry the row totals on (gfx9 has both), lane 63 then holds the total.  SAMPLER_DPP=0: the shuffle forms.
+#ifndef SAMPLER_DPP
+#define SAMPLER_DPP 1
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float v) {      // lanes without a source lane (or outside ROW_MASK) get `old`
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-__device__ __forceinline__ float wmax(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 __device__ __forceinline__ float wscan_incl(float v, int lane) {
+#if SAMPLER_DPP
+  (void)lane;
+  v += dpp_mov<DPP_ROW_SHR1, 0xf>(0.f, v);
+  v += dpp_mov<DPP_ROW_SHR2, 0xf>(0.f, v);
+  v += dpp_mov<DPP_ROW_SHR4, 0xf>(0.f, v);
+  v += dpp_mov<DPP_ROW_SHR8, 0xf>(0.f, v);
+  v += dpp_mov<DPP_ROW_BCAST15, 0xa>(0.f, v);     // rows 1 and 3 += the total of the row below
+  v += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.f, v);     // rows 2 and 3 += the total of lanes 0..31
+  return v;
+#else
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const float t = __shfl_up(v, o);
     if (lane >= o) v += t;
   }
   return v;
+#endif
+}
+__device__ __forceinline__ float wsum(float v) {
+#if SAMPLER_DPP
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wscan_incl(v, 0)), 63));
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+#endif
+}
+__device__ __forceinline__ float wmax(float v) {
+#if SAMPLER_DPP
+  const float lo = -3.4028234663852886e38f;
+  v = fmaxf(v, dpp_mov<DPP_ROW_SHR1, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_SHR2, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_SHR4, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_SHR8, 0xf>(lo, v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_BCAST15, 0xa>(lo, v));
+  v = fmaxf(v, dpp_mov<DPP_ROW_BCAST31, 0xc>(lo, v));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+#endif
 }
 // inclusive scan of a blocked row (lane owns E consecutive entries), in place
 template <int E>
