@@ -808,8 +808,7 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
 // tasks (wgrad_narrow_body / wgrad_wide_body) as workgroups of the same grid, dispatched on the task's variant.  Two launches per range
 // on one stream ran back to back -- the 250 narrow workgroups alone on their range's stream, not even one round of the chip, then the
 // 475 block workgroups behind a kernel boundary; as one grid of 725 the short narrow workgroups fill the rounds of the long ones.  Both
-// bodies are one workgroup per CU by their registers (460-512) and LDS either way.  Task order: narrow tasks FIRST (they are dispatched
-// first and finish first; the blocks' last round is then the only partly filled one).
+// bodies are one workgroup per CU by their registers (460-512) and LDS either way.  Task order: longest first (see the launch site).
 template <int NPL>
 __global__ __launch_bounds__(256) void wgrad_all_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1136,7 +1135,14 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
   static const bool merged_env = [] { const char* e = getenv("I2SDF_WGRAD_MERGED"); return !(e && e[0] == '0'); }();
   const bool merged = merged_env && p->wgrad_bf16x3 != 0 && sel_narrow.size() + sel_blocks[0].size() <= (size_t)MAX_TASKS && !sel_blocks[0].empty();
   std::vector<WgTask> sel_all;
-  if (merged) { sel_all = sel_narrow; sel_all.insert(sel_all.end(), sel_blocks[0].begin(), sel_blocks[0].end()); }
+  // order inside the grid: workgroups are dispatched task by task.  LONGEST FIRST -- the two-job 256x256 tasks, the one-job ones, then the short
+  // narrow tasks, which fill the last round: i2sdf_weight_grads 0.95-0.96 -> 0.91-0.92 ms against narrow-first (three interleaved repetitions in
+  // one GPU call, profiles/r6_launch_chain_ab.txt); I2SDF_WGRAD_BLOCKS_FIRST=0 restores narrow-first for A/B runs
+  static const bool blocks_first = [] { const char* e = getenv("I2SDF_WGRAD_BLOCKS_FIRST"); return !(e && e[0] == '0'); }();
+  if (merged) {
+    if (blocks_first) { sel_all = sel_blocks[0]; sel_all.insert(sel_all.end(), sel_narrow.begin(), sel_narrow.end()); }
+    else { sel_all = sel_narrow; sel_all.insert(sel_all.end(), sel_blocks[0].begin(), sel_blocks[0].end()); }
+  }
   PartRun pr;
   if (i2sdf_parts_on(p) && i2sdf_parts_begin(p, st_main, Ms, &pr)) {
     // point ranges (plan.h: PartRun): the GEMMs of a range's chunks on the range's stream, behind that range's backward sweeps
