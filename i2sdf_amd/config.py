@@ -83,6 +83,11 @@ class NetConfig:
     # 1.09 -> 0.67 ms, step 5.42 -> 4.97 ms, a 640x480 eval render 1.18 -> 0.86 s.  `sampler_bf16x2: false` (or I2SDF_SAMPLER_BF16X2=0)
     # selects the three-plane form here too.
     sampler_bf16x2: bool = True
+    # abars, G(hbar), G(a) of the SDF net -- the saved tensors whose consumers keep 16 significant bits of them anyway (the two-plane
+    # weight-gradient GEMMs) or use them in the second-order injection only -- stored with 16 significant bits in 3 bytes per value
+    # (include/i2sdf.h: I2SDF_OPT_SAVES24; csrc/x3.h P24).  Effective only together with `wgrad_bf16x2` and the point ranges; with
+    # `wgrad_bf16x2: false` (the fp32-equivalent mode) these tensors keep fp32 storage.  `saves24: false` (or I2SDF_SAVES24=0) keeps fp32 storage here too.
+    saves24: bool = True
 
     @staticmethod
     def from_conf(conf) -> "NetConfig":
@@ -154,7 +159,7 @@ class NetConfig:
                          sdf_bias=float(_get(inet, "bias", 1.0)), use_normal=bool(_get(conf, "use_normal", False)),
                          detach_light_feature=bool(_get(conf, "detach_light_feature", True)),
                          bf16x3=bool(_get(conf, "bf16x3", True)), wgrad_bf16x2=bool(_get(conf, "wgrad_bf16x2", True)),
-                         sampler_bf16x2=bool(_get(conf, "sampler_bf16x2", True)))
+                         sampler_bf16x2=bool(_get(conf, "sampler_bf16x2", True)), saves24=bool(_get(conf, "saves24", True)))
 
 
 def synthetic_conf(light: bool = False) -> dict:

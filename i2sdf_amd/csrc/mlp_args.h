@@ -15,6 +15,7 @@ struct SdfTrainFwdArgs {
   float* abars;                         // (L-1, Mp, H)  abar_0..abar_{L-2} or nullptr
   float* pe_save;                       // (Mp, PEC*8) PE(x) for the weight-gradient GEMMs, or nullptr
   int kcs = 16;                         // layout of hs / abars for the points of THIS launch: 16 point-major, 512 blocked (mlp_common.h)
+  int p24 = 0;                          // abars as packed 24-bit records (mlp_common.h: sdf_saves24; kcs is then 512 and applies to hs)
   int wg0 = 0;                          // first 128-point workgroup of this launch (point ranges, plan.h: PartRun)
   int64_t ldf = 0;                      // row stride of `feat` in floats (0 = F: the training workspaces; i2sdf_sdf_forward passes the caller's ld_feat)
 };
@@ -35,6 +36,7 @@ struct SdfBwdArgs {
   float* ga_last4;                      // (Mp,4) {sbar,0,0,0}: A operand of the last layer's sdf-row weight gradient
   float* ones4;                         // (Mp,4) {1,0,0,0}
   int kcs = 16;                         // layout of hs / abars / gus / gas for the points of this launch
+  int p24 = 0;                          // abars / gus / gas as packed 24-bit records (kcs is then 512 and applies to hs)
   int wg0 = 0;                          // first 128-point workgroup of this launch
 };
 

@@ -412,6 +412,7 @@ extern "C" int i2sdf_sdf_backward(const i2sdf_plan* p, const float* packed, cons
       a3.n_fwd = sdf_fwd3_hidden_stages(256, PE<6>::DIM, d.n_lin, has_skip);
       a3.n_rev = sdf_rev3_bwd_stages(256, 256, PE<6>::PEC, d.n_lin, has_skip);
       a3.kcs = sdf_blocked_points(p, M, Mp) > 0 ? KCS_BLK : KCS_PM;
+      a3.p24 = (sdf_saves24(p) && a3.kcs == KCS_BLK) ? 1 : 0;
       i2sdf_launch_sdf_bwd3(a3, g, st);
     };
     if (x3 && i2sdf_parts_on(p)) {      // point ranges (plan.h: PartRun): both sweeps of a range on the range's stream

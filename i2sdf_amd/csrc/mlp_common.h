@@ -62,6 +62,10 @@ inline int64_t split_bulk_points(int64_t M, int n_cu) {
 // Both ranges are tile aligned, so one tensor holds both; every producer / consumer derives the blocked prefix from (plan, M).
 constexpr int KCS_PM = 16, KCS_BLK = 512;
 __host__ __device__ inline int64_t save_row_off(int64_t m, int kcs) { return kcs == KCS_PM ? m * 256 : (m >> 5) * 8192 + (m & 31) * 16; }
+// packed 24-bit records (I2SDF_OPT_SAVES24; x3.h: p24_load8 / p24_store8, wgrad.hip: the p24 loaders): abars, gus, gas of the points that go through the
+// bf16x3 kernels when EVERY point does (point ranges on).  A 32-point block of a layer is 16 k-chunks of 1536 B: [32 points][2 lanes][16 B] upper halves,
+// then [32 points][2 lanes][8 B] mid bytes -- 6144 floats, dense; the layer stride stays Mp * 256 floats (the tensors keep their fp32 allocation).
+// (constants and p24_row_off: x3.h)
 
 inline bool sdf_x3_path(const i2sdf_plan* p) {
   const i2sdf_mlp_desc& d = p->sdf.d;
@@ -73,6 +77,11 @@ inline int64_t sdf_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp, bo
   if (i2sdf_parts_on(p)) return Mp;                           // point ranges: no split-K tail, everything blocked
   const int64_t bulk = split_bulk_points(M, p->n_cu);
   return (bulk > 0 && has_feat) ? bulk : Mp;
+}
+// abars / gus / gas as packed 24-bit records?  Needs every producer and consumer on the blocked bf16x3 path for EVERY point (point ranges: no split-K
+// tail) and the two-plane weight-gradient GEMMs (which keep 16 significant bits per operand anyway); the fp32-equivalent mode keeps fp32 storage.
+inline bool sdf_saves24(const i2sdf_plan* p) {
+  return p->saves24 != 0 && p->wgrad_bf16x3 != 0 && p->wgrad_bf16x2 != 0 && p->blocked_saves != 0 && sdf_x3_path(p) && i2sdf_parts_on(p);
 }
 inline int64_t rgb_blocked_points(const i2sdf_plan* p, int64_t M, int64_t Mp) {
   if (!p->blocked_saves || !p->rgb_bf16x3 || p->rgb.d.hidden != 256 || p->F != 256) return 0;

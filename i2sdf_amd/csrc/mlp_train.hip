@@ -347,9 +347,11 @@ __global__ __launch_bounds__(256) void rgb_fwd_split_kernel(RgbFwdArgs a, int64_
 }  // namespace
 
 // leading points of a batch whose saved 256-wide tensors are in the blocked layout (I2SDF_OPT_BLOCKED_SAVES): which = 0 the SDF
-// tensors (hs, abars, gus, gas) of a batch of M points, 1 the radiance tensors (rs, gar)
+// tensors (hs, abars, gus, gas) of a batch of M points, 1 the radiance tensors (rs, gar); which = 2: the leading points whose abars / gus / gas
+// are packed 24-bit records (I2SDF_OPT_SAVES24: all of them, Mp, or none)
 extern "C" int64_t i2sdf_blocked_points(const i2sdf_plan* p, int32_t which, int64_t M, int64_t Mp, int32_t has_feat) {
   if (!p || M <= 0) return 0;
+  if (which == 2) return (sdf_saves24(p) && sdf_blocked_points(p, M, Mp, has_feat != 0) == Mp) ? Mp : 0;
   return which == 0 ? sdf_blocked_points(p, M, Mp, has_feat != 0) : rgb_blocked_points(p, M, Mp);
 }
 
@@ -394,6 +396,7 @@ extern "C" int i2sdf_sdf_forward_grad(const i2sdf_plan* p, const float* packed, 
     a3.n_fwd = sdf_fwd3h_train_stages(256, 256, PE<6>::DIM, d.n_lin, has_skip, feat != nullptr);     \
     a3.n_rev = sdf_rev3_stages(256, PE<6>::PEC, d.n_lin, has_skip);                                  \
     a3.kcs = sdf_blocked_points(p, M, Mp, feat != nullptr) > 0 ? KCS_BLK : KCS_PM;                   \
+    a3.p24 = (sdf_saves24(p) && a3.kcs == KCS_BLK && abars != nullptr) ? 1 : 0;                      \
     i2sdf_launch_train_fwd3h(a3, G_, st);                                                            \
     if (grad) i2sdf_launch_igrad3(a3, G_, st);                                                       \
   } while (0)

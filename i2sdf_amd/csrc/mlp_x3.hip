@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void sdf_fwd3_kernel(const float* __restrict__
 // d sdf/dx chain of the bf16x3 path as its own launch (appendix A.2): the forward kernel above and this one each fit the
 // register file without spills; h_{L-1} is re-read from the tensor the forward saved.
 // SV: a.abars is given (a backward will follow) -> its stores are unconditional instructions, counted by the stage waits (x3.h)
-template <int H, int LF, bool SV>
+// P24: abars as packed 24-bit records (x3.h; only with SV)
+template <int H, int LF, bool SV, bool P24 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void sdf_igrad3_kernel(SdfTrainFwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int64_t lstride = a.Mp * H;
   const int kcs = a.kcs;
   const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
+  const int64_t arow_ = P24 ? p24_row_off(m) : mrow;                             // ... and in abars
   float px, py, pz;
   fetch_point(a.pts, mc, px, py, pz);
   f32x16 accA[NT], accB[NT];
@@ -85,7 +87,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < KC * 4; ++i) h[i] = wv[i] * sp_sigma_from_h(h[i]);       // abar_{L-2} = w_sdf (.) sigma_{L-2}
   }
-  if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + mrow, hi, valid, h, kcs);
+  if (P24) {
+#pragma unroll
+    for (int kc = 0; kc < KH16; ++kc) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = h[8 * kc + u];
+      p24_store8(a.abars + (a.L - 2) * lstride + arow_, kc, hi, v8);
+    }
+  } else if (a.abars) store_regs<KC>(a.abars + (a.L - 2) * lstride + mrow, hi, valid, h, kcs);
   f32x16 pt[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i)
@@ -107,7 +117,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
   for (int l = a.L - 3; l >= 1; --l) {
     const float* hrow = a.hs + l * lstride + mcrow;
-    X3RevSrc<NT, SV> src{accA, hrow, (SV || a.abars) ? a.abars + l * lstride + mrow : nullptr, hi, valid, kcs};
+    X3RevSrc<NT, SV, P24> src{accA, hrow, (SV || a.abars) ? a.abars + l * lstride + arow_ : nullptr, hi, valid, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) {
@@ -118,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3RevSrc<NT, SV> src{accA, a.hs + mcrow, (SV || a.abars) ? a.abars + mrow : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
+    X3RevSrc<NT, SV, P24> src{accA, a.hs + mcrow, (SV || a.abars) ? a.abars + arow_ : nullptr, hi, valid, kcs};     // abar_0 = (.) * sigma(h_1)
     dense_x3g<PT, KH16, 0>(ws, src, pt, tid);       // pbar += W_0^T abar_0
   }
   {
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // per-element epilogue of an op (loads of the saved tensors, sigma products, stores) is the B preparation of the next op;
 // the last op of a sweep is followed by a drain that only runs the epilogue.
 // ---------------------------------------------------------------------------------------------------------------
-template <int H, int LF>
+template <int H, int LF, bool P24 = false>
 __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   constexpr int NT = H / 32, KH16 = H / 16, PEC = PE<LF>::PEC, PED = PE<LF>::DIM, PE16 = cdiv(PED, 16), NGP = PE16 * 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -163,12 +173,12 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   ws.begin(a.fwd, lds, a.n_fwd, tid);
   f32x16 accA[NT], accB[NT];
   {
-    X3Sweep1Src<NT, 0, NGP> src{accB, gpx, nullptr, nullptr, hi};
+    X3Sweep1Src<NT, 0, NGP, X3_AHEAD, P24> src{accB, gpx, nullptr, nullptr, hi};
     dense_x3g<NT, PE16, 2>(ws, src, accA, tid);
   }
   for (int l = 1; l < a.L - 1; ++l) {
     // the B preparation of layer l is the epilogue of layer l-1: G(hbar_l) -> gus[l]  (G2(a_{l-1}) is formed by sweep 2 from it, x3.h)
-    X3Sweep1Src<NT, KH16, NGP> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
+    X3Sweep1Src<NT, KH16, NGP, X3_AHEAD, P24> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + (P24 ? p24_row_off(m) : mrow), hi, kcs};
     if (l == a.skip) dense_x3g<NT, KH16 + PE16, 2>(ws, src, accB, tid);
     else dense_x3g<NT, KH16, 2>(ws, src, accB, tid);
 #pragma unroll
@@ -176,12 +186,13 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep1_kernel(SdfBwdArgs a) {
   }
   {
     const int l = a.L - 1;
-    X3Sweep1Src<NT, KH16, NGP, X3_DRAIN_AHEAD> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
+    // (G(hbar_{L-1}) stays fp32 also with packed records: x3.h X3Sweep2Src)
+    X3Sweep1Src<NT, KH16, NGP, X3_DRAIN_AHEAD, false> src{accA, gpx, a.hs + (l - 1) * lstride + mcrow, a.gus + l * lstride + mrow, hi, kcs};
     x3_drain<KH16>(src);
   }
 }
 
-template <int H, int F, int LF>
+template <int H, int F, int LF, bool P24 = false>
 __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   constexpr int NT = H / 32, KC = H / 8, KH16 = H / 16, PEC = PE<LF>::PEC, PT = cdiv(PEC * 8, 32);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -192,6 +203,8 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   const int64_t lstride = a.Mp * H;
   const int kcs = a.kcs;
   const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
+  // rows of gus / abars (read: the clamped point) and gas (written: this point, padding rows included) -- fp32 blocked or packed 24-bit records
+  const int64_t srow = P24 ? p24_row_off(mc) : mcrow, wrow = P24 ? p24_row_off(m) : mrow;
   const float sb = a.sbar ? a.sbar[mc] : 0.f;
   if (valid && hi == 0) {
     *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
@@ -215,16 +228,16 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   ws.skip(rowvec_chunks(KC, 1) / SC, tid);            // the d sdf/dx chain's copy of w_sdf
   {
     const int l = a.L - 2;                            // G(a_{L-2}) = (W_feat^T fbar + sbar w_sdf) sigma + G2, then W_{L-2}^T G(a_{L-2})
-    X3Sweep2Src<NT, true> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + mcrow, a.abars + l * lstride + mcrow,
-                              a.gas + l * lstride + mrow, hi, sb, a.rev + lane * 4, kcs};
+    X3Sweep2Src<NT, true, X3_SW2_AHEAD, P24, false> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + mcrow, a.abars + l * lstride + srow,
+                                                 a.gas + l * lstride + wrow, hi, sb, a.rev + lane * 4, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   for (int l = a.L - 3; l >= 1; --l) {
-    X3Sweep2Src<NT, false> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + mcrow, a.abars + l * lstride + mcrow,
-                               a.gas + l * lstride + mrow, hi, 0.f, nullptr, kcs};
+    X3Sweep2Src<NT, false, X3_SW2_AHEAD, P24> src{accA, a.hs + l * lstride + mcrow, a.gus + (l + 1) * lstride + srow, a.abars + l * lstride + srow,
+                                                  a.gas + l * lstride + wrow, hi, 0.f, nullptr, kcs};
     zero(accB);
     dense_x3g<NT, KH16, 0>(ws, src, accB, tid);
     if (l == a.skip) ws.skip(x3_bwd_chunks(PT, KH16) / SC, tid);      // the PE rows of W_skip^T are not needed here
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
     for (int nt = 0; nt < NT; ++nt) accA[nt] = accB[nt];
   }
   {
-    X3Sweep2Src<NT, false, X3_DRAIN_AHEAD> src{accA, a.hs + mcrow, a.gus + lstride + mcrow, a.abars + mcrow, a.gas + mrow, hi, 0.f, nullptr, kcs};     // G(a_0)
+    X3Sweep2Src<NT, false, X3_DRAIN_AHEAD, P24> src{accA, a.hs + mcrow, a.gus + lstride + srow, a.abars + srow, a.gas + wrow, hi, 0.f, nullptr, kcs};     // G(a_0)
     x3_drain<KH16>(src);
   }
 }
@@ -246,10 +259,16 @@ void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int 
   launch_lds(sdf_fwd3_kernel<64, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
 void i2sdf_launch_igrad3(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) {
-  if (a.abars) launch_lds(sdf_igrad3_kernel<256, 6, true>, grid, st, a);
+  if (a.abars && a.p24) launch_lds(sdf_igrad3_kernel<256, 6, true, true>, grid, st, a);
+  else if (a.abars) launch_lds(sdf_igrad3_kernel<256, 6, true>, grid, st, a);
   else launch_lds(sdf_igrad3_kernel<256, 6, false>, grid, st, a);
 }
 void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
+  if (a.p24) {
+    launch_lds(sdf_bwd3_sweep1_kernel<256, 6, true>, grid, st, a);
+    launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6, true>, grid, st, a);
+    return;
+  }
   launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
   launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);
 }

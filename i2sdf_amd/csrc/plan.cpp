@@ -587,6 +587,12 @@ extern "C" int i2sdf_plan_set_option(i2sdf_plan* p, int32_t option, int32_t valu
     p->blocked_saves = value ? 1 : 0;
     return I2SDF_OK;
   }
+  if (option == I2SDF_OPT_SAVES24) {
+    if (value && (p->H != 256 || p->F != 256 || p->sdf.rev3_chunks == 0)) return I2SDF_EINVAL;
+    if (p->chain_active) return I2SDF_EINVAL;          // the layout of tensors in flight
+    p->saves24 = value ? 1 : 0;
+    return I2SDF_OK;
+  }
   if (option == I2SDF_OPT_TAIL_OVERLAP) {
     p->tail_overlap = value ? 1 : 0;
     return I2SDF_OK;

@@ -81,6 +81,7 @@ struct i2sdf_plan {
   int32_t dp_flags = 0;              // I2SDF_DP_GLOBAL_SAMPLER
   int32_t wgrad_bf16x2 = 0;          // I2SDF_OPT_WGRAD_BF16X2: 256x256 weight-gradient blocks with two split planes / three products
   int32_t blocked_saves = 0;         // I2SDF_OPT_BLOCKED_SAVES: saved tensors of the bf16x3 full workgroups in the blocked layout (mlp_common.h)
+  int32_t saves24 = 0;               // I2SDF_OPT_SAVES24: abars / gus / gas as packed 24-bit records (mlp_common.h: sdf_saves24 says when it takes effect)
   int32_t tail_overlap = 0;          // I2SDF_OPT_TAIL_OVERLAP: split-K tail workgroups on a side stream, concurrent with the full ones
   // side stream + fork/join events of the tail overlap, created on first use (entry points take a const plan)
   mutable hipStream_t side = nullptr;

@@ -28,7 +28,9 @@ constexpr int MAX_TASKS = 30;
 
 // A / B point at column a_c0 / b_c0 of the operand's first row in the POINT-MAJOR sense; a_blk / b_blk = leading points of the
 // operand tensor stored in the blocked layout (mlp_common.h; only 256-wide tensors, accessed as 128-column tiles, are ever blocked)
-struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; int64_t a_blk, b_blk; int32_t a_c0, b_c0; };
+// a_p24 / b_p24: the operand's blocked points are packed 24-bit records (x3.h P24: abars, gus, gas under I2SDF_OPT_SAVES24; only 256-wide tensors,
+// read by the split-arithmetic kernels)
+struct WgJob { const float* A; const float* B; int32_t lda, ldb, a_w, b_w; int64_t m_count; int64_t a_blk, b_blk; int32_t a_c0, b_c0; int32_t a_p24, b_p24; };
 struct WgTask {
   WgJob j[2];
   int32_t njobs, relu_b, has_bias, rows_store, cols_store, ldo;
@@ -178,7 +180,8 @@ __device__ __forceinline__ void w3_mfma_valu(int k, u32x4 a, u32x4 b) {
 // byte offset per k-slot computed once per job (an out-of-range value for a masked column: the buffer load returns 0) plus ONE scalar
 // offset per stage; no selects or branches in the stage loop; the rows of a ragged last stage are zeroed after the load.
 // (core: leaves the tiles in a[16 k : 16 k + 15], k = ta + 4 tb, drained; wgrad_accumulate_x below reads them out)
-template <int AM, int BM, int NPL>
+// A24 (AM = 0 only): the A operand -- a 128-column tile of gas / abars, in both jobs of the task -- is packed 24-bit records (x3.h P24) in its blocked points
+template <int AM, int BM, int NPL, bool A24 = false>
 __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t lo, int64_t hi_cap, int lane, float (&bsum)[AM ? 1 : 4]) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NBV = BM ? BM : 1;
   const int i32 = lane & 31, hi = lane >> 5;
@@ -197,12 +200,22 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
     const int nst = (rows + 15) / 16;
     const unsigned OOB = 0x7fffffffu;
     const bool ablk = !AM && m_lo < job.a_blk, bblk = !BM && m_lo < job.b_blk;
+    // packed 24-bit records (x3.h P24; wave-uniform): the 128-column operand is read as 8 B of upper halves + 4 mid bytes per point and column quad,
+    // into the first three slots of the raw row, and unpacked in front of the split (compute_stage)
+    constexpr bool a24 = A24 && !AM;          // (host: a packed operand is blocked throughout, mlp_common.h sdf_saves24; B is never packed here)
     // descriptors over "everything behind the first row of this wave's range" (the column offset a_c0 / b_c0 of a 128-column tile is
     // folded into the per-lane offset for the blocked layout, where columns are not contiguous)
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A - (AM ? 0 : job.a_c0) + m_lo * job.lda), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.A - (AM ? 0 : job.a_c0) + m_lo * (a24 ? P24_BLOCK / 32 : job.lda)), 0, 0x7ffffff0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.B - (BM ? 0 : job.b_c0) + m_lo * job.ldb), 0, 0x7ffffff0, 0x00020000);
+    const char* pa24 = reinterpret_cast<const char*>(job.A - (AM ? 0 : job.a_c0) + m_lo * (P24_BLOCK / 32));      // (a24 only)
     // per-lane byte offsets of the 8 k-slots (point 2q + hi of a stage), stage 0
-    unsigned aoff[8], boff[8][NBV];
+    // (P24: the mid-byte offset of a k-slot follows from its upper-half offset oh: (oh >> 1) + mid_k, mid_k = (k-chunk base >> 1) + 1024 per lane)
+    unsigned aoff[8], boff[8][NBV], amid_k = 0;
+    auto p24_offs = [&](unsigned col, unsigned c, unsigned& oh, unsigned& mid_k) __attribute__((always_inline)) {
+      const unsigned kc = col >> 4, q = (col >> 2) & 3u;
+      oh = (kc * P24_KCS + c * 8u + (q & 1u) * 4u + (q >> 1) * 2u) * 4u;
+      mid_k = (kc * P24_KCS * 4u >> 1) + P24_MID * 4u;
+    };
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const unsigned c = (unsigned)(2 * q + hi);
@@ -210,6 +223,7 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
       else {
         const unsigned col = (unsigned)(job.a_c0 + 4 * i32);
         aoff[q] = (4 * i32 < job.a_w) ? (ablk ? ((col >> 4) * 512u + (col & 15u) + c * 16u) * 4u : (c * (unsigned)job.lda + col) * 4u) : OOB;
+        if (a24) p24_offs(col, c, aoff[q], amid_k);         // (host: packed operands are whole 128-column tiles of 256-wide tensors -- no column mask)
       }
       if (BM) {
 #pragma unroll
@@ -223,15 +237,31 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
     auto stage_off = [&](int s, bool blk, int ld) -> unsigned {
       return blk ? (unsigned)(((s >> 1) * 8192 + (s & 1) * 256) * 4) : (unsigned)(s * 16 * ld * 4);
     };
+    // ... packed 24-bit records: 32-point blocks of P24_BLOCK floats; the second 16 points of a block 128 floats (upper halves) / 64 floats (mid bytes) further
+    // (part 1: the mid-byte loads form their offset as (upper-half offset + stage offset) / 2 + mid_k, see load_stage: the scalar part is the other half
+    // of the block offset -- the (s & 1) term halves exactly: 128 floats -> 64 floats)
+    auto stage_off24 = [&](int s, int part) -> unsigned { return part == 0 ? (unsigned)(((s >> 1) * P24_BLOCK + (s & 1) * 128) * 4) : (unsigned)((s >> 1) * P24_BLOCK * 2); };
     const float relu_lo = t.relu_b != 0 ? 0.f : -3.0e38f;
     const float bias_w = (t.has_bias && jb == 0) ? 1.f : 0.f;
     float A0[8][TA], B0[8][TB], A1[8][TA], B1[8][TB];           // raw values of two stages: [k-slot q][tile]
     auto load_stage = [&](float (&A)[8][TA], float (&Bv)[8][TB], int s) __attribute__((always_inline)) {
       const unsigned sa = stage_off(s, ablk, job.lda), sb = stage_off(s, bblk, job.ldb);
+      if (!AM && a24) {
+        const unsigned sh = stage_off24(s, 0), sm = stage_off24(s, 1);      // sm: what (offset + sh) / 2 leaves of the mid part's stage offset
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          // plain global loads (no column mask to range-check), as floats: `__builtin_bit_cast(float, v[1])` on an element of an unsigned ext-vector
+          // read element 0 with hipcc 7.2 (values 2, 3 of every quad carried the upper halves of values 0, 1: profiles/r6_saves24.txt)
+          const f32x2 hh = *reinterpret_cast<const f32x2*>(pa24 + (sh + aoff[q]));
+          A[q][0] = hh[0]; A[q][1 % TA] = hh[1];
+          // (the mid-byte offset is formed from the STAGE's upper-half offset, per load: as a loop invariant it would be hoisted into eight more live registers)
+          A[q][2 % TA] = *reinterpret_cast<const float*>(pa24 + sm + (((aoff[q] + sh) >> 1) + amid_k));
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         if (AM) A[q][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, aoff[q], sa, WGN_AUX));
-        else {
+        else if (!a24) {
           const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, aoff[q], sa, WGN_AUX));
 #pragma unroll
           for (int ta = 0; ta < TA; ++ta) A[q][ta] = x[ta];
@@ -246,6 +276,15 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
         }
       }
     };
+    // packed 24-bit rows: the three raw dwords of a k-slot -> its four values (masked columns were read as zeros: they unpack to zeros)
+    auto unpack24 = [&](float (&X)[4]) __attribute__((always_inline)) {
+      const unsigned h0 = __builtin_bit_cast(unsigned, X[0]), h1 = __builtin_bit_cast(unsigned, X[1]), mm = __builtin_bit_cast(unsigned, X[2]);
+      // (x3.h p24_quad_value, written out: value tt = upper half (tt & 1) of h[tt >> 1] << 16 | mid byte tt << 8)
+      X[0] = __builtin_bit_cast(float, __builtin_amdgcn_perm(h0, mm, 0x0504000cu));
+      X[1] = __builtin_bit_cast(float, __builtin_amdgcn_perm(h0, mm, 0x0706010cu));
+      X[2] = __builtin_bit_cast(float, __builtin_amdgcn_perm(h1, mm, 0x0504020cu));
+      X[3] = __builtin_bit_cast(float, __builtin_amdgcn_perm(h1, mm, 0x0706030cu));
+    };
     auto split = [&](const float (&X)[8], u32x4 (&pl)[NPL]) __attribute__((always_inline)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -255,6 +294,12 @@ __device__ __forceinline__ void wgrad_accumulate_x_core(const WgTask& t, int64_t
     };
     // nv = valid points of the stage (16, or fewer in the ragged last stage: those rows exist in the padded tensors but are not data)
     auto compute_stage = [&](float (&A)[8][TA], float (&Bv)[8][TB], int nv) __attribute__((always_inline)) {
+      if constexpr (!AM) {
+        if (a24) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) unpack24(A[q]);
+        }
+      }
       if (nv < 16) {                            // (wave-uniform: the ragged last stage of a job; selects, not per-lane branches)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -378,7 +423,7 @@ constexpr int WGW_SLOT = (16 * 16 + 4) * 64;               // floats of one wave
 constexpr int WGN_LDS_BYTES = 2 * WGW_SLOT * 4;            // two such slots (wgrad_wide_body) > three narrow partials (3 * (8 * 16 + 4) * 64 * 4)
 
 // NPL = 0: fp32-input MFMA (wgrad_accumulate); 2 / 3: bf16 split arithmetic with that many planes per operand (wgrad_accumulate_x)
-template <int AM, int BM, int NPL>
+template <int AM, int BM, int NPL, bool A24 = false>
 __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTask& t, int64_t chunk, int wave, int lane, float* lds) {
   constexpr int TA = AM ? 1 : 4, TB = BM ? BM : 4, NW = TA * TB * 16 + TA;
   const int64_t lo = chunk * WG_CH + wave * (WG_CH / 4);
@@ -388,7 +433,7 @@ __device__ __forceinline__ void wgrad_narrow_body(const WgLaunch& L, const WgTas
     // 128-row tile) held 128 registers of tiles next to the store loop's addresses and spilled 26 of them (108 B of scratch in the
     // shipped round-4 binary; tests/test_wgrad3p_isa.py now holds this kernel to zero).  Same values, same summation order ((w0 + w1) + w2) + w3.
     float bsum[TA];
-    wgrad_accumulate_x_core<AM, BM, NPL == 0 ? 2 : NPL>(t, lo, lo + WG_CH / 4, lane, bsum);
+    wgrad_accumulate_x_core<AM, BM, NPL == 0 ? 2 : NPL, A24>(t, lo, lo + WG_CH / 4, lane, bsum);
     if (wave > 0) {
       float* dst = lds + (wave - 1) * NW * 64 + lane;
 #pragma unroll
@@ -549,8 +594,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(WgLaunch L) {
   const int64_t chunk = blockIdx.x + L.chunk0;
   if (NPL != 0 && t.variant == 0) wgrad_wide_body<NPL == 0 ? 3 : NPL>(L, t, chunk, wave, lane, wgn_lds);      // (only the split form gets such tasks)
   else if (t.variant == 1) wgrad_narrow_body<1, 0, NPL>(L, t, chunk, wave, lane, wgn_lds);
-  else if (t.variant == 2) wgrad_narrow_body<0, 1, NPL>(L, t, chunk, wave, lane, wgn_lds);
-  else wgrad_narrow_body<0, 2, NPL>(L, t, chunk, wave, lane, wgn_lds);
+  else if (t.variant == 2) { if (NPL != 0 && t.j[0].a_p24) wgrad_narrow_body<0, 1, NPL, NPL != 0>(L, t, chunk, wave, lane, wgn_lds); else wgrad_narrow_body<0, 1, NPL>(L, t, chunk, wave, lane, wgn_lds); }
+  else { if (NPL != 0 && t.j[0].a_p24) wgrad_narrow_body<0, 2, NPL, NPL != 0>(L, t, chunk, wave, lane, wgn_lds); else wgrad_narrow_body<0, 2, NPL>(L, t, chunk, wave, lane, wgn_lds); }
 }
 
 constexpr int W3_PTS = 16;               // points per stage = one MFMA k-group of v_mfma_f32_32x32x16_bf16
@@ -597,27 +642,21 @@ constexpr int W3P_LDS_BYTES = W3P_SLOTS * W3P_PL * 4;      // 96 KB of the CU's 
 // What the hazard recognizer does not see and this code provides: (1) a tile is the srcC of an MFMA again four MFMAs (128 cycles) after it
 // was written -- more than the 8 passes of the instruction; (2) the epilogue's reads come behind w3_mfma_drain(); (3) the zero fill is
 // separated from the first MFMA by the whole job prologue.  (s_waitcnt for the LDS-loaded A / B operands is the compiler's, as before.)
-template <bool BLKA, bool BLKB, int NPL, bool PLAIN>
-__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
-  float* plb = lds;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
+// LAY = layout of THIS WAVE'S operand quarter in this job and chunk: 0 point-major, 1 blocked fp32, 2 packed 24-bit records (x3.h P24).  A wave loads and
+// splits only its own quarter (the consumers read planes from LDS), so the layout is a property of the wave's code path, chosen per job by a
+// wave-uniform switch in wgrad3p_body: the four waves of a workgroup may run different instantiations (same barriers in the same order).
+template <int LAY, int NPL, bool PLAIN>
+__device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int jb, int64_t chunk, float* plb, float (&bsum)[4], int w, int lane) {
   const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
-  const WgTask& t = L.t[blockIdx.y];
-  const int64_t chunk = blockIdx.x + L.chunk0;
-  f32x16 acc_unused;                       // (the tiles are in a[0:255], see w3_mfma)
-  w3_acc_zero();
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
-  for (int jb = 0; jb < t.njobs; ++jb) {
-    const WgJob job = t.j[jb];
+  f32x16 acc_unused;                       // (the tiles are in a[0:255], see w3_mfma)
+  {
     const int64_t m_lo = chunk * WG_CH;
     const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
-    if (m_hi <= m_lo) continue;
     const int rows = (int)(m_hi - m_lo);
     const int nst = (rows + W3_PTS - 1) / W3_PTS;
     const int dld = opB ? job.ldb : job.lda;
-    const bool blk = opB ? BLKB : BLKA;        // (host: both jobs of a task share the operands' layouts)
+    constexpr bool blk = LAY != 0, P24 = LAY == 2;
     // Raw rows of stage s: this lane holds columns 4*i32 .. 4*i32+3 of its quarter for the 8 points 8*kg .. 8*kg+7, as four
     // point pairs (rlo[i], rhi[i]) = rows 8*kg+2i, 8*kg+2i+1 -- eight 16-byte loads per stage, address = scalar base + scalar
     // stage offset + a per-lane offset computed once per job (voff).  Rows of the last, partial stage that lie beyond `rows`
@@ -626,23 +665,39 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
     //   point-major: the 32 lanes of one kg read 512 contiguous bytes of a row
     //   blocked (mlp_common.h): columns 4*i32.. of point r sit at r*16 + (i32>>2)*512 + 4*(i32&3): groups of 4 lanes read the 64
     //     bytes one point has in a k-chunk, and the pair's other point is the neighbouring 64 bytes (same 128 B line)
-    const float* ubase = blk ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * wb) * 512
+    //   packed 24-bit records (x3.h): the column quad 4*i32.. is quad q = i32 & 3 of k-chunk i32 >> 2: 8 B of upper halves at
+    //     r*32 + (q & 1)*16 + (q >> 1)*8 and 4 mid bytes at 1024 + r*16 + (q & 1)*8 + (q >> 1)*4 of the k-chunk's 1536 B; a 16-point stage is 512 / 256 B further
+    const float* ubase = P24 ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * (P24_BLOCK / 32) + (8 * wb) * P24_KCS
+                       : blk ? (opB ? job.B - job.b_c0 : job.A - job.a_c0) + m_lo * 256 + (8 * wb) * 512
                              : (opB ? job.B : job.A) + m_lo * dld + 128 * wb;
     unsigned voff[4];                           // bytes, row 8*kg + 2i; the pair's second row is `vnext` further
+    unsigned voffm[P24 ? 4 : 1];                // P24: the mid-byte part (second row: vnext / 2 further)
     // the MFMA reduction index is the point, and any point <-> k-slot map will do as long as A and B use the same one: with the two
     // 32-lane halves taking the two points of a 128-B line (rows 4i + kg and 4i + 2 + kg) every load instruction moves whole lines
     // instead of half of each of twice as many
-    const unsigned vnext = 2u * 4u * (unsigned)(blk ? 16 : dld);
+    const unsigned vnext = 2u * 4u * (unsigned)(P24 ? 8 : (blk ? 16 : dld));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 4 * i + kg;
-      voff[i] = 4u * (unsigned)(blk ? r * 16 + (i32 >> 2) * 512 + 4 * (i32 & 3) : r * dld + 4 * i32);
+      voff[i] = 4u * (unsigned)(P24 ? (i32 >> 2) * P24_KCS + r * 8 + (i32 & 1) * 4 + ((i32 >> 1) & 1) * 2
+                                    : (blk ? r * 16 + (i32 >> 2) * 512 + 4 * (i32 & 3) : r * dld + 4 * i32));
+      if (P24) voffm[i] = 4u * (unsigned)((i32 >> 2) * P24_KCS + P24_MID + r * 4 + (i32 & 1) * 2 + ((i32 >> 1) & 1));
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    f32x4 rlo[4], rhi[4];
+    f32x4 rlo[P24 ? 1 : 4], rhi[P24 ? 1 : 4];
+    u32x2 hlo[P24 ? 4 : 1], hhi[P24 ? 4 : 1];           // P24: upper halves of the pair's two rows (values 0,1 | 2,3 of the quad) ...
+    unsigned mlo[P24 ? 4 : 1], mhi[P24 ? 4 : 1];        // ... and their four mid bytes
     auto gload = [&](int s, int i, int half) __attribute__((always_inline)) {
       const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches ahead without a branch)
+      if constexpr (P24) {
+        // plain loads: the eight instructions of a stage touch every 128-B line of the quarter twice (8-B / 4-B pieces of 32-B / 16-B point records)
+        const int64_t sblk = (int64_t)(sc >> 1) * P24_BLOCK;
+        const char* sh = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 128) + voff[i];
+        const char* sm = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 64) + voffm[i];
+        if (half == 0) { hlo[i] = *reinterpret_cast<const u32x2*>(sh); mlo[i] = *reinterpret_cast<const unsigned*>(sm); }
+        else { hhi[i] = *reinterpret_cast<const u32x2*>(sh + vnext); mhi[i] = *reinterpret_cast<const unsigned*>(sm + vnext / 2); }
+      } else {
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
 #if W3_NT_LD
@@ -652,6 +707,16 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
       else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
 #endif
+      }
+    };
+    // raw value of tile tt (a constant after unrolling) of the pair's first / second row
+    auto raw_lo = [&](int i, int tt) __attribute__((always_inline)) -> float {
+      if constexpr (P24) return p24_quad_value(hlo[i], mlo[i], tt);
+      else return rlo[i][tt];
+    };
+    auto raw_hi = [&](int i, int tt) __attribute__((always_inline)) -> float {
+      if constexpr (P24) return p24_quad_value(hhi[i], mhi[i], tt);
+      else return rhi[i][tt];
     };
     unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
@@ -679,7 +744,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           float x0, x1;
-          prep(s, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          prep(s, i, raw_lo(i, tt), raw_hi(i, tt), x0, x1);
           bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
           if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
           else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
@@ -730,7 +795,7 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
         if (MORE) {
           // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
           const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
-          if (st == 0) prep(s + 1, i, rlo[i][tt], rhi[i][tt], x0, x1);
+          if (st == 0) prep(s + 1, i, raw_lo(i, tt), raw_hi(i, tt), x0, x1);
           if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
           if (NPL == 3) {
             if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
@@ -762,6 +827,33 @@ __device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
       else stage(s, BF{}, P0{});
     }
   }
+  (void)wa;
+}
+
+template <int NPL, bool PLAIN>
+__device__ __forceinline__ void wgrad3p_body(const WgLaunch& L, float* lds) {
+  float* plb = lds;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);       // scalar: the load base addresses built from it stay in SGPRs
+  const int wa = w >> 1, wb = w & 1, i32 = lane & 31, kg = lane >> 5;
+  const WgTask& t = L.t[blockIdx.y];
+  const int64_t chunk = blockIdx.x + L.chunk0;
+  w3_acc_zero();
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool opB = (w >> 1) != 0;                          // this wave prepares a B quarter (else an A quarter)
+  for (int jb = 0; jb < t.njobs; ++jb) {
+    const WgJob& job = t.j[jb];
+    const int64_t m_lo = chunk * WG_CH;
+    const int64_t m_hi = (m_lo + WG_CH < job.m_count) ? m_lo + WG_CH : job.m_count;
+    if (m_hi <= m_lo) continue;
+    // this wave's operand in this job and chunk: point-major, blocked fp32 or packed 24-bit records (workgroup-uniform per operand, wave-uniform here)
+    const bool blk = m_lo < (opB ? job.b_blk : job.a_blk);
+    const int lay = __builtin_amdgcn_readfirstlane(!blk ? 0 : ((opB ? job.b_p24 : job.a_p24) != 0 ? 2 : 1));
+    if (lay == 2) {
+      if constexpr (NPL == 2) w3p_job<2, NPL, PLAIN>(t, job, jb, chunk, plb, bsum, w, lane);       // (the fp32-equivalent form keeps fp32 storage: mlp_common.h sdf_saves24)
+    } else if (lay == 1) w3p_job<1, NPL, PLAIN>(t, job, jb, chunk, plb, bsum, w, lane);
+    else w3p_job<0, NPL, PLAIN>(t, job, jb, chunk, plb, bsum, w, lane);
+  }
   w3_mfma_drain();
   float* out = L.partials + chunk * L.chunk_stride;
   const int64_t toff = t.out_off + (int64_t)(wa * 128) * t.ldo + wb * 128;
@@ -785,23 +877,13 @@ __global__ __launch_bounds__(256) void wgrad3p_kernel(WgLaunch L) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WgTask& t = L.t[blockIdx.y];
   const int64_t m_lo = (int64_t)(blockIdx.x + L.chunk0) * WG_CH;
-  const bool ba = m_lo < t.j[0].a_blk, bb = m_lo < t.j[0].b_blk;       // workgroup-uniform
   bool plain = t.relu_b == 0;
   for (int jb = 0; jb < t.njobs; ++jb) {
     const int64_t left = t.j[jb].m_count - m_lo;
     plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
   }
-  if (plain) {
-    if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
-    else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
-    else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
-    else wgrad3p_body<false, false, NPL, true>(L, lds);
-  } else {
-    if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
-    else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
-    else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
-    else wgrad3p_body<false, false, NPL, false>(L, lds);
-  }
+  if (plain) wgrad3p_body<NPL, true>(L, lds);
+  else wgrad3p_body<NPL, false>(L, lds);
 }
 
 // ---- ONE launch for every split-arithmetic task of a point range (round 6): the 256x256 blocks (wgrad3p_body) and the narrow / 128x128
@@ -815,23 +897,13 @@ __global__ __launch_bounds__(256) void wgrad_all_kernel(WgLaunch L) {
   const WgTask& t = L.t[blockIdx.y];
   if (t.variant == 4) {
     const int64_t m_lo = (int64_t)(blockIdx.x + L.chunk0) * WG_CH;
-    const bool ba = m_lo < t.j[0].a_blk, bb = m_lo < t.j[0].b_blk;       // workgroup-uniform
     bool plain = t.relu_b == 0;
     for (int jb = 0; jb < t.njobs; ++jb) {
       const int64_t left = t.j[jb].m_count - m_lo;
       plain = plain && (left >= WG_CH || left <= 0 || left % W3_PTS == 0);
     }
-    if (plain) {
-      if (ba && bb) wgrad3p_body<true, true, NPL, true>(L, lds);
-      else if (ba) wgrad3p_body<true, false, NPL, true>(L, lds);
-      else if (bb) wgrad3p_body<false, true, NPL, true>(L, lds);
-      else wgrad3p_body<false, false, NPL, true>(L, lds);
-    } else {
-      if (ba && bb) wgrad3p_body<true, true, NPL, false>(L, lds);
-      else if (ba) wgrad3p_body<true, false, NPL, false>(L, lds);
-      else if (bb) wgrad3p_body<false, true, NPL, false>(L, lds);
-      else wgrad3p_body<false, false, NPL, false>(L, lds);
-    }
+    if (plain) wgrad3p_body<NPL, true>(L, lds);
+    else wgrad3p_body<NPL, false>(L, lds);
     return;
   }
   // (the narrow blocks always with three planes, as in wgrad_narrow_kernel<3>: bound by their operand reads)
@@ -839,8 +911,8 @@ __global__ __launch_bounds__(256) void wgrad_all_kernel(WgLaunch L) {
   const int64_t chunk = blockIdx.x + L.chunk0;
   if (t.variant == 0) wgrad_wide_body<3>(L, t, chunk, wave, lane, lds);
   else if (t.variant == 1) wgrad_narrow_body<1, 0, 3>(L, t, chunk, wave, lane, lds);
-  else if (t.variant == 2) wgrad_narrow_body<0, 1, 3>(L, t, chunk, wave, lane, lds);
-  else wgrad_narrow_body<0, 2, 3>(L, t, chunk, wave, lane, lds);
+  else if (t.variant == 2) { if (t.j[0].a_p24) wgrad_narrow_body<0, 1, 3, true>(L, t, chunk, wave, lane, lds); else wgrad_narrow_body<0, 1, 3>(L, t, chunk, wave, lane, lds); }
+  else { if (t.j[0].a_p24) wgrad_narrow_body<0, 2, 3, true>(L, t, chunk, wave, lane, lds); else wgrad_narrow_body<0, 2, 3>(L, t, chunk, wave, lane, lds); }
 }
 
 // ---- split-M reduction + weight-norm backward: one wave per weight row ------------------------------------
@@ -923,7 +995,7 @@ __global__ __launch_bounds__(256) void wn_backward_kernel(WnTab tab, const float
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct Src { const float* p; int ld; int w; int64_t blk = 0; };     // a [Mp][ld] matrix, the width used from it, blocked-prefix points
+struct Src { const float* p; int ld; int w; int64_t blk = 0; int p24 = 0; };     // a [Mp][ld] matrix, the width used from it, blocked-prefix points, those as packed 24-bit records
 
 struct TaskList {
   std::vector<WgTask> tasks;
@@ -939,10 +1011,10 @@ struct TaskList {
         for (size_t i = 0; i < A0.size(); ++i) {
           if (A0[i].w != 256) continue;
           WgTask t{};
-          t.j[0] = WgJob{A0[i].p, B0[k].p, A0[i].ld, B0[k].ld, 256, 256, mA0[i], A0[i].blk, B0[k].blk, 0, 0};
+          t.j[0] = WgJob{A0[i].p, B0[k].p, A0[i].ld, B0[k].ld, 256, 256, mA0[i], A0[i].blk, B0[k].blk, 0, 0, A0[i].p24, B0[k].p24};
           t.njobs = 1;
           if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
-            t.j[1] = WgJob{A1[i].p, B1[k].p, A1[i].ld, B1[k].ld, 256, 256, m1, A1[i].blk, B1[k].blk, 0, 0};
+            t.j[1] = WgJob{A1[i].p, B1[k].p, A1[i].ld, B1[k].ld, 256, 256, m1, A1[i].blk, B1[k].blk, 0, 0, A1[i].p24, B1[k].p24};
             t.njobs = 2;
           }
           t.relu_b = relu_b ? 1 : 0;
@@ -959,10 +1031,10 @@ struct TaskList {
           for (int rt = 0; rt * 128 < A0[i].w; ++rt) {
             WgTask t{};
             const int aw = std::min(128, A0[i].w - rt * 128), bw = std::min(128, B0[k].w - ct * 128);
-            t.j[0] = WgJob{A0[i].p + rt * 128, B0[k].p + ct * 128, A0[i].ld, B0[k].ld, aw, bw, mA0[i], A0[i].blk, B0[k].blk, rt * 128, ct * 128};
+            t.j[0] = WgJob{A0[i].p + rt * 128, B0[k].p + ct * 128, A0[i].ld, B0[k].ld, aw, bw, mA0[i], A0[i].blk, B0[k].blk, rt * 128, ct * 128, A0[i].p24, B0[k].p24};
             t.njobs = 1;
             if (!A1.empty() && A1[i].p != nullptr && !B1.empty()) {
-              t.j[1] = WgJob{A1[i].p + rt * 128, B1[k].p + ct * 128, A1[i].ld, B1[k].ld, aw, bw, m1, A1[i].blk, B1[k].blk, rt * 128, ct * 128};
+              t.j[1] = WgJob{A1[i].p + rt * 128, B1[k].p + ct * 128, A1[i].ld, B1[k].ld, aw, bw, m1, A1[i].blk, B1[k].blk, rt * 128, ct * 128, A1[i].p24, B1[k].p24};
               t.njobs = 2;
             }
             t.relu_b = relu_b ? 1 : 0;
@@ -1021,15 +1093,16 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
     const int L = d.n_lin, H = d.hidden, F = p->F, PEC8 = cdiv(d.in0, 8) * 8;
     const int64_t ls = Mp * H;
     const int64_t bs = (H == 256) ? sdf_blocked_points(p, Ms, Mp) : 0;      // leading points of hs / abars / gus / gas in the blocked layout
+    const int s24 = (H == 256 && sdf_saves24(p) && bs == Mp) ? 1 : 0;       // abars / gus / gas as packed 24-bit records (hs stays fp32)
     for (int l = 0; l < L - 1; ++l) {
       std::vector<Src> B0, B1;
       if (l == 0) { B0 = {{tb->pe, PEC8, PEC8}}; B1 = {{tb->gpbar, PEC8, PEC8}}; }
       else {
-        B0 = {{tb->hs + (l - 1) * ls, H, H, bs}}; B1 = {{tb->gus + l * ls, H, H, bs}};
+        B0 = {{tb->hs + (l - 1) * ls, H, H, bs}}; B1 = {{tb->gus + l * ls, H, H, bs, s24}};
         if (l == d.skip_layer) { B0.push_back({tb->pe, PEC8, PEC8}); B1.push_back({tb->gpbar, PEC8, PEC8}); }
       }
       tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l],
-                   {{tb->gas + l * ls, H, H, bs}}, {{tb->abars + l * ls, H, H, bs}}, {0}, {Ms}, B0, B1, Ms, false);
+                   {{tb->gas + l * ls, H, H, bs, s24}}, {{tb->abars + l * ls, H, H, bs, s24}}, {0}, {Ms}, B0, B1, Ms, false);
     }
     {
       const int l = L - 1;
@@ -1038,7 +1111,7 @@ extern "C" int i2sdf_weight_grads(const i2sdf_plan* p, const i2sdf_train_buffers
       std::vector<int64_t> mA0 = {Ms};
       if (F > 0 && Mm > 0 && tb->fbar) { A0.push_back({tb->fbar, F, F}); A1.push_back({nullptr, 0, 0}); row0.push_back(32); mA0.push_back(Mm); }
       tl.add_block(np.wgrad_off[l], np.wg_cols[l], np.wgrad_off[l] + (int64_t)np.wg_rows[l] * np.wg_cols[l], A0, A1, row0, mA0,
-                   {{tb->hs + (L - 2) * ls, H, H, bs}}, {{tb->gus + (L - 1) * ls, H, H, bs}}, Ms, false);
+                   {{tb->hs + (L - 2) * ls, H, H, bs}}, {{tb->gus + (L - 1) * ls, H, H, bs}}, Ms, false);       // (gus[L-1] stays fp32: x3.h X3Sweep2Src)
     }
   }
   if (Mm > 0 && tb->gar) {  // ---- radiance net

@@ -25,6 +25,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // global loads of the B-operand sources are issued X3_AHEAD k-chunks before their use (ring of X3_RING register slots):
 // measured: a distance of 1 is enough (2 and 3 change nothing, on the kernels and on a model of them: scripts/ubench/mfma_paced.hip); what stalled
@@ -264,6 +265,61 @@ __device__ __forceinline__ void x3_drain(Src& src) {
   }
 }
 
+// ---- packed 24-bit records of abar / G(hbar) / G(a) (I2SDF_OPT_SAVES24, mlp_common.h: "P24") ------------------------------------------
+// The backward is bound by the bytes of its saved tensors (13 tensor passes per layer), and eight of those passes move tensors whose only
+// fp32-exact consumer does not exist: abar, G(hbar) and G(a) are operands of the weight-gradient GEMMs, which in their default form keep 16
+// significant bits of every operand anyway (I2SDF_OPT_WGRAD_BF16X2), and abar / G(hbar) feed sweep 2 only through the second-order injection
+// G2 = (G(hbar)/sigma) abar 100 (1 - sigma).  With the option on these three tensors are stored with 16 significant bits (round to nearest:
+// relative error <= 2^-16 per element; the two bf16 planes the GEMMs split them into keep 2^-18) in 3 bytes per value.  h stays fp32 (sigma is
+// recomputed from it in three kernels).  Layout of a 32-point block of one layer: 16 k-chunks of 1536 B =
+//   [32 points][hi 0..1][4 dwords: the upper 16 bits of the lane's values u = 0..7, two per dword]   1024 B   (lane (p, hi) of a 32-point wave: one 16-B access)
+//   [32 points][hi 0..1][2 dwords: bits 15..8 of the same values, four per dword]                       512 B   (one 8-B access)
+// i.e. both accesses of a wave instruction are contiguous (1 KB / 512 B).  The weight-gradient kernels read the same bytes by column quad
+// (wgrad.hip: p24 loaders): quad q of a point = values u = 4 (q >> 1) .. + 3 of lane hi = q & 1.
+// row = the tensor's layer base + p24_row_off(m) (floats); the k-chunk stride is P24_KCS floats.
+constexpr int P24_KCS = 384, P24_MID = 256, P24_BLOCK = 16 * P24_KCS;      // floats: k-chunk stride, offset of the mid-byte part, 32-point block
+__host__ __device__ inline int64_t p24_row_off(int64_t m) { return (m >> 5) * P24_BLOCK + (m & 31) * 8; }
+struct P24Rec { u32x4 h; unsigned m0, m1; };
+__device__ __forceinline__ void p24_load8(const float* row, int kc, int hi, P24Rec& r) {
+  r.h = *reinterpret_cast<const u32x4*>(row + P24_KCS * kc + 4 * hi);
+  const u32x2 t = *reinterpret_cast<const u32x2*>(row + P24_KCS * kc + (P24_MID - 4 * (int)(threadIdx.x & 31) + 2 * hi));      // row carries 8 floats per point
+  r.m0 = t[0]; r.m1 = t[1];
+}
+// value u (0..7) of a record: (upper 16 bits) << 16 | (mid byte) << 8
+template <int U>
+__device__ __forceinline__ float p24_value(const P24Rec& r) {
+  constexpr unsigned sel = ((5u + 2u * (U & 1)) << 24) | ((4u + 2u * (U & 1)) << 16) | ((unsigned)(U & 3) << 8) | 0x0cu;
+  return __builtin_bit_cast(float, __builtin_amdgcn_perm(r.h[U >> 1], U < 4 ? r.m0 : r.m1, sel));
+}
+__device__ __forceinline__ float p24_value(const P24Rec& r, int u) {      // u is a constant after unrolling
+  switch (u) {
+    case 0: return p24_value<0>(r); case 1: return p24_value<1>(r); case 2: return p24_value<2>(r); case 3: return p24_value<3>(r);
+    case 4: return p24_value<4>(r); case 5: return p24_value<5>(r); case 6: return p24_value<6>(r); default: return p24_value<7>(r);
+  }
+}
+// value tt (0..3) of a column quad as the weight-gradient kernels read it: h = upper halves of values (0,1 | 2,3), m = their four mid bytes
+__device__ __forceinline__ float p24_quad_value(u32x2 h, unsigned m, int tt) {      // tt is a constant after unrolling
+  const unsigned sel = ((5u + 2u * (tt & 1)) << 24) | ((4u + 2u * (tt & 1)) << 16) | ((unsigned)tt << 8) | 0x0cu;
+  return __builtin_bit_cast(float, __builtin_amdgcn_perm(h[tt >> 1], m, sel));
+}
+__device__ __forceinline__ void p24_store8(float* row, int kc, int hi, const float (&v)[8]) {
+  unsigned b[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) b[u] = __builtin_bit_cast(unsigned, v[u]) + 0x80u;          // round to nearest at bit 8 (magnitude: sign-magnitude bits)
+  u32x4 h;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) h[j] = __builtin_amdgcn_perm(b[2 * j + 1], b[2 * j], 0x07060302u);       // upper halves of (b[2j], b[2j+1])
+  u32x2 m;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const unsigned t0 = __builtin_amdgcn_perm(b[4 * j + 1], b[4 * j], 0x0c0c0501u);                    // byte 1 of b[4j], b[4j+1]
+    const unsigned t1 = __builtin_amdgcn_perm(b[4 * j + 3], b[4 * j + 2], 0x0c0c0501u);
+    m[j] = t0 | (t1 << 16);
+  }
+  __builtin_nontemporal_store(__builtin_bit_cast(f32x4, h), reinterpret_cast<f32x4*>(row + P24_KCS * kc + 4 * hi));
+  __builtin_nontemporal_store(__builtin_bit_cast(f32x2, m), reinterpret_cast<f32x2*>(row + P24_KCS * kc + (P24_MID - 4 * (int)(threadIdx.x & 31) + 2 * hi)));
+}
+
 // B-operand sources -------------------------------------------------------------------------------------------------
 // softplus100 of the previous layer's pre-activations (D layout) for k-chunks < KACC, this lane's PE values beyond;
 // stores the activations (h row of the saved tensor) as they are produced
@@ -299,7 +355,8 @@ struct X3RegSrc {
 };
 // reverse chain: abar = (previous op's accumulators) * sigma(h) with h re-read from the saved tensor; stores abar
 // UNC: abrow is known to be a row of an (Mp, 256) tensor -> unconditional, counted stores (the training forward; eval renders pass no abars)
-template <int NT, bool UNC = false>
+// P24: abrow is a row of the packed 24-bit layout (p24_store8; only with UNC)
+template <int NT, bool UNC = false, bool P24 = false>
 struct X3RevSrc {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = UNC;
@@ -317,7 +374,8 @@ struct X3RevSrc {
     return accP[kc >> 1][8 * (kc & 1) + u] * sp_sigma_from_h(hq[kc % X3_RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {
-    if (UNC || (abrow != nullptr && valid)) {
+    if (P24) p24_store8(abrow, kc, hi, v);
+    else if (UNC || (abrow != nullptr && valid)) {
       stg4(abrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
       stg4(abrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
     }
@@ -352,13 +410,14 @@ __device__ __forceinline__ void x3_store8(float* row, int kc, int hi, const floa
   stg4(row + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});
   stg4(row + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});
 }
+
 // sweep 1: from G(abar_l) (accumulators):  G(hbar_{l+1}) = G(abar_l) sigma_l  [value, stored to gurow]
 // Round 5: the second-order injection G2(a_l) = G(abar_l) abar_l 100 (1 - sigma_l) is no longer written here (and re-read by sweep 2): sweep 2
 // RECOVERS G(abar_l) = G(hbar_{l+1}) / sigma_l from the tensor stored above -- the same sigma bits from the same h, so the quotient is
 // G(abar_l) to one rounding -- and forms G2 itself.  One store pass of this sweep and its read of abar become one more read pass of
 // sweep 2; the knock-outs of profiles/r5_step0_knockouts.txt price a store pass of the sweeps at ~4x a load pass.
 // AH: k-chunks of load-ahead (the final drain of a sweep has no MFMAs to hide a load behind: it asks for X3_DRAIN_AHEAD)
-template <int NT, int KACC, int NREG, int AH = X3_AHEAD>
+template <int NT, int KACC, int NREG, int AH = X3_AHEAD, bool P24 = false>
 struct X3Sweep1Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
@@ -376,14 +435,16 @@ struct X3Sweep1Src {
     return ga * sp_sigma_from_h(hq[kc % RING][u >> 2][u & 3]);
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
-    if (kc < KACC) x3_store8(gurow, kc, hi, v, kcs);
+    if (kc < KACC) { if (P24) p24_store8(gurow, kc, hi, v); else x3_store8(gurow, kc, hi, v, kcs); }
     return kc < KACC ? 2 : 0;
   }
 };
 // sweep 2: G(a_l) = (accumulators [+ sb * w_sdf]) * sigma_l + G2(a_l)   [value, stored to grow]
 //          G2(a_l) = (G(hbar_{l+1}) / sigma_l) abar_l 100 (1 - sigma_l)   from sweep 1's stored G(hbar_{l+1}) (gurow) and the forward's abar_l (arow);
 //          sigma_l = 0 (h_{l+1} underflowed to 0: abar_l = 0 and G(hbar_{l+1}) = 0 as well) -> G2 = 0
-template <int NT, bool TOP, int AH = X3_SW2_AHEAD>
+// P24: arow / grow are rows of the packed 24-bit layout (hrow stays fp32); G24: gurow too (the top layer's G(hbar_{L-1}) stays fp32: its other reader is a
+// narrow weight-gradient task whose two jobs would otherwise differ in their operand format)
+template <int NT, bool TOP, int AH = X3_SW2_AHEAD, bool P24 = false, bool G24 = P24>
 struct X3Sweep2Src {
   static constexpr bool STORES = true;
   static constexpr bool COUNTED = true;
@@ -391,9 +452,12 @@ struct X3Sweep2Src {
   const f32x16 (&accP)[NT]; const float* hrow; const float* gurow; const float* arow; float* grow; int hi;
   float sb; const float* wsdf;        // TOP: w_sdf in stream layout (chunk of 8 indices = 64 lanes x 16 B), + lane*4 applied
   int kcs = 16;
-  f32x4 hq[RING][2], gq[RING][2], aq[RING][2], wq[RING][2];
+  f32x4 hq[RING][2], gq[G24 ? 1 : RING][2], aq[P24 ? 1 : RING][2], wq[RING][2];
+  P24Rec gr[G24 ? RING : 1], ar[P24 ? RING : 1];
   __device__ __forceinline__ int ahead(int kc) {
-    x3_load8(hrow, kc, hi, hq[kc % RING], kcs); x3_load8(gurow, kc, hi, gq[kc % RING], kcs); x3_load8(arow, kc, hi, aq[kc % RING], kcs);
+    x3_load8(hrow, kc, hi, hq[kc % RING], kcs);
+    if (G24) p24_load8(gurow, kc, hi, gr[kc % RING]); else x3_load8(gurow, kc, hi, gq[kc % RING], kcs);
+    if (P24) p24_load8(arow, kc, hi, ar[kc % RING]); else x3_load8(arow, kc, hi, aq[kc % RING], kcs);
     if (TOP) {
       wq[kc % RING][0] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc) * CHUNK_FLOATS);
       wq[kc % RING][1] = *reinterpret_cast<const f32x4*>(wsdf + (2 * kc + 1) * CHUNK_FLOATS);
@@ -403,21 +467,23 @@ struct X3Sweep2Src {
   __device__ __forceinline__ float value(int kc, int u, float&) {
     float x = accP[kc >> 1][8 * (kc & 1) + u];
     if (TOP) x = fmaf(sb, wq[kc % RING][u >> 2][u & 3], x);
+    const float gu_ = G24 ? p24_value(gr[G24 ? kc % RING : 0], u) : gq[G24 ? 0 : kc % RING][u >> 2][u & 3];
+    const float ab_ = P24 ? p24_value(ar[P24 ? kc % RING : 0], u) : aq[P24 ? 0 : kc % RING][u >> 2][u & 3];
 #if X3_SW2_SHARE_E
     // e = exp(-100 h) once: sigma = 1 - e, and (1 - sigma) IS e (exact where the fp32 subtraction 1 - sigma only rounds it again)
     const float e = __builtin_amdgcn_exp2f(-100.f * 1.44269504088896341f * hq[kc % RING][u >> 2][u & 3]);
     const float sg = 1.0f - e;
-    const float ga = sg > 0.f ? gq[kc % RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
-    const float g2 = ga * aq[kc % RING][u >> 2][u & 3] * (100.f * e);
+    const float ga = sg > 0.f ? gu_ * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
+    const float g2 = ga * ab_ * (100.f * e);
 #else
     const float sg = sp_sigma_from_h(hq[kc % RING][u >> 2][u & 3]);
-    const float ga = sg > 0.f ? gq[kc % RING][u >> 2][u & 3] * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
-    const float g2 = ga * aq[kc % RING][u >> 2][u & 3] * (100.f * (1.0f - sg));
+    const float ga = sg > 0.f ? gu_ * __builtin_amdgcn_rcpf(sg) : 0.f;       // G(abar_l)
+    const float g2 = ga * ab_ * (100.f * (1.0f - sg));
 #endif
     return fmaf(x, sg, g2);
   }
   __device__ __forceinline__ int done(int kc, const float (&v)[8], const float (&)[8]) {      // unconditional: padding points write their own rows
-    x3_store8(grow, kc, hi, v, kcs);
+    if (P24) p24_store8(grow, kc, hi, v); else x3_store8(grow, kc, hi, v, kcs);
     return 2;
   }
 };

@@ -48,6 +48,12 @@ class RenderEngine:
         if wide:
             self.set_sampler_bf16x2(bool(self.sdf_forward_bf16x3 and ((sx2 != "0") if sx2 != "" else getattr(cfg, "sampler_bf16x2", False))))
         self.set_blocked_saves(bool(cfg.bf16x3 and os.environ.get("I2SDF_BLOCKED_SAVES", "1") != "0"))      # I2SDF_BLOCKED_SAVES=0 for A/B runs
+        # abars / gus / gas as packed 24-bit records (include/i2sdf.h: I2SDF_OPT_SAVES24; takes effect only with the two-plane weight gradients
+        # and the point ranges: the fp32-equivalent mode keeps fp32 storage); conf `saves24`, I2SDF_SAVES24=0 / 1 overrides it
+        self.saves24 = False
+        s24 = os.environ.get("I2SDF_SAVES24", "")
+        if wide:
+            self.set_saves24(bool(cfg.bf16x3 and ((s24 != "0") if s24 != "" else getattr(cfg, "saves24", True))))
         self.set_tail_overlap(os.environ.get("I2SDF_TAIL_OVERLAP", "1") != "0")                            # I2SDF_TAIL_OVERLAP=0 for A/B runs
         # point ranges on their own streams instead of split-K tail workgroups (include/i2sdf.h: I2SDF_OPT_PARTS); I2SDF_PARTS=0 for A/B runs
         self.parts = 0
@@ -205,20 +211,61 @@ class RenderEngine:
         L.check(self._lib.i2sdf_plan_set_option(self._plan, L.OPT_BLOCKED_SAVES, int(bool(on))), "i2sdf_plan_set_option")
         self.blocked_saves = bool(on)
 
+    def set_saves24(self, on: bool):
+        """abars / gus / gas with 16 significant bits in 3 bytes per value (I2SDF_OPT_SAVES24, csrc/x3.h P24).  Change it only between
+        training steps.  `saves24_points` tells whether it takes effect under the other options."""
+        rc = self._lib.i2sdf_plan_set_option(self._plan, L.OPT_SAVES24, int(bool(on)))
+        if on or rc == 0:                      # (turning it OFF on a library build that predates the option is not an error: A/B runs)
+            L.check(rc, "i2sdf_plan_set_option")
+        self.saves24 = bool(on) and rc == 0
+
     def blocked_points(self, which: int, M: int, Mp: int, has_feat: bool = True) -> int:
         return int(self._lib.i2sdf_blocked_points(self._plan, which, M, Mp, int(has_feat)))
 
+    def saves24_points(self, M: int, Mp: int, has_feat: bool = True) -> int:
+        """leading points of a batch whose abars / gus / gas are packed 24-bit records (Mp or 0)"""
+        return int(self._lib.i2sdf_blocked_points(self._plan, 2, M, Mp, int(has_feat))) if self.saves24 else 0
+
     @staticmethod
-    def saved_to_point_major(t: torch.Tensor, n_blocked: int) -> torch.Tensor:
+    def saved_to_point_major(t: torch.Tensor, n_blocked: int, p24_layers=None) -> torch.Tensor:
         """A copy of a saved (layers, Mp, 256) tensor with ordinary rows (inspection / tests): the first n_blocked points are stored
-        [Mp/32][16 k-chunks][32 points][16 floats] (include/i2sdf.h: i2sdf_blocked_points)."""
+        [Mp/32][16 k-chunks][32 points][16 floats] (include/i2sdf.h: i2sdf_blocked_points).  p24_layers: for each layer, whether its
+        (all-blocked) points are packed 24-bit records (csrc/x3.h P24: per 32-point block 16 k-chunks of [32 points][2][8 upper halves]
+        + [32 points][2][8 mid bytes]; value u of lane hi = column (u < 4 ? 4 hi + u : 8 + 4 hi + u - 4) of the k-chunk) -- decoded to fp32."""
         if n_blocked <= 0:
             return t.clone()
         Lr, Mp, H = t.shape
         assert H == 256 and n_blocked % 32 == 0
         out = t.clone()
         out[:, :n_blocked] = t[:, :n_blocked].reshape(Lr, n_blocked // 32, 16, 32, 16).permute(0, 1, 3, 2, 4).reshape(Lr, n_blocked, 256)
+        if p24_layers is not None and any(p24_layers):
+            assert n_blocked == Mp, "packed records: every point is blocked"
+            nb = Mp // 32
+            for l in range(Lr):
+                if not p24_layers[l]:
+                    continue
+                raw = t[l].reshape(-1)[: nb * 6144].view(torch.int32).reshape(nb, 16, 384)
+                hi16 = raw[:, :, :256].contiguous().view(torch.int16).reshape(nb, 16, 32, 2, 8).to(torch.int32) & 0xFFFF     # [blk][kc][p][hi][u]
+                mid = raw[:, :, 256:].contiguous().view(torch.uint8).reshape(nb, 16, 32, 2, 8).to(torch.int32)
+                val = ((hi16 << 16) | (mid << 8)).view(torch.float32)                                                # wraps to the sign bit as intended
+                # (hi, u) -> column of the k-chunk: u < 4: 4 hi + u ; u >= 4: 8 + 4 hi + (u - 4)
+                v = val.reshape(nb, 16, 32, 2, 2, 4).permute(0, 2, 1, 4, 3, 5)       # [blk][p][kc][half][hi][4]
+                out[l] = v.reshape(Mp, 256)
         return out
+
+    def saved_pm(self, name: str, t: torch.Tensor, M: int, has_feat: bool = True) -> torch.Tensor:
+        """rows 0..M-1 of a saved tensor (`hs`, `abars`, `gus`, `gas`, `rs`, `gar`) in point-major fp32 form, whatever its storage"""
+        Mp = t.shape[1]
+        if name in ("rs", "gar"):
+            return self.saved_to_point_major(t, self.blocked_points(1, M, Mp))[:, :M]
+        nb = self.blocked_points(0, M, Mp, has_feat)
+        p24 = None
+        if name in ("abars", "gus", "gas") and self.saves24_points(M, Mp, has_feat) == Mp:
+            p24 = [True] * t.shape[0]
+            if name == "gus":
+                p24[-1] = False          # G(hbar_{L-1}) stays fp32 (csrc/x3.h: X3Sweep2Src)
+                p24[0] = False           # (slot 0 is unused)
+        return self.saved_to_point_major(t, nb, p24)[:, :M]
 
     def set_tail_overlap(self, on: bool):
         """Split-K tail workgroups on the plan's side stream, concurrent with the full workgroups (I2SDF_OPT_TAIL_OVERLAP)."""

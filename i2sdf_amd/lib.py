@@ -73,6 +73,7 @@ OPT_BLOCKED_SAVES = 128
 OPT_WGRAD_BF16X2 = 256
 OPT_PARTS = 512
 OPT_SAMPLER_BF16X2 = 1024
+OPT_SAVES24 = 2048
 MAX_PARTS = 4
 GRID_ORDER_MESHGRID, GRID_ORDER_VOLUME = 0, 1
 

@@ -134,6 +134,14 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
  *   the reference itself computes them with on its GPU (torch.set_float32_matmul_precision('medium'), main_recon.py:61).
  *   i2sdf_sdf_forward and i2sdf_sdf_grid (values that are returned) keep three planes.  Default 0. */
 #define I2SDF_OPT_SAMPLER_BF16X2 1024
+/*   I2SDF_OPT_SAVES24 (256-wide nets; takes effect only together with I2SDF_OPT_PARTS, I2SDF_OPT_BLOCKED_SAVES, the *_BF16X3 options and
+ *   I2SDF_OPT_WGRAD_BF16X2 -- otherwise the tensors keep their fp32 form): abars, gus and gas -- the three saved SDF tensors whose consumers are
+ *   the weight-gradient GEMMs (which in the two-plane form keep 16 significant bits of every operand) and, for abars / gus, the second-order
+ *   injection of sweep 2 -- are stored with 16 significant bits (round to nearest, relative error <= 2^-16 per element) as 3 bytes per value
+ *   inside their fp32 allocation (layout: mlp_common.h P24).  hs stays fp32.  8 of the 13 saved-tensor passes per layer move 3/4 of their bytes.
+ *   Measured: every parameter gradient stays within 7e-7 (max-norm relative) of the fp32-storage result at 1024 rays; the parity bar is 1e-4
+ *   against fp64.  The tensors are opaque to the caller in this form (i2sdf_amd.engine.saved_to_point_major decodes a copy).  Default 0. */
+#define I2SDF_OPT_SAVES24 2048
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset

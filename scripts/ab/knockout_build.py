@@ -39,13 +39,32 @@ PATCHES = {
     "sweeps_no_wgrad_stores": [
         # (measured on the round-4 sweeps, where sweep 1 also wrote G2; since round 5 it writes G(hbar) only and sweep 2 READS it, so this
         # knock-out now also feeds sweep 2 garbage -- timing only, as ever)
-        ("x3.h", "    if (kc < KACC) x3_store8(gurow, kc, hi, v, kcs);\n", "    (void)v;\n"),
-        ("x3.h", "    x3_store8(grow, kc, hi, v, kcs);\n    return 2;\n", "    (void)kc; (void)v;\n    return 2;\n"),
+        ("x3.h", "    if (kc < KACC) { if (P24) p24_store8(gurow, kc, hi, v); else x3_store8(gurow, kc, hi, v, kcs); }\n", "    (void)v;\n"),
+        ("x3.h", "    if (P24) p24_store8(grow, kc, hi, v); else x3_store8(grow, kc, hi, v, kcs);\n    return 2;\n", "    (void)kc; (void)v;\n    return 2;\n"),
     ],
     # ... and the 256x256 weight-gradient kernel without its operand loads (pure split + MFMA + partial-sum flush)
     "wgrad3p_no_loads": [
         ("wgrad.hip", "      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);\n      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);\n",
          "      (void)src;\n      if (half == 0) rlo[i] = f32x4{1.f + s, 2.f, 3.f, 4.f};\n      else rhi[i] = f32x4{0.5f, 0.25f + s, 0.125f, 2.5f};\n"),
+    ],
+    # round 6 (VERDICT r5 task 2b): NUMERICAL gates by emulation -- the stored tensor keeps its fp32 slot, but the value written has its low
+    # X3_EMU_DROP mantissa bits rounded away (-- -DX3_EMU_DROP=8: a 24-bit format; 13: an fp16 significand with an ideal scale; 16: bf16).
+    # Not a timing build: it answers "would the gradient tests hold if this tensor were stored narrower" before any narrow layout is built
+    # (profiles/r6_saves24.txt; run the result with I2SDF_SAVES24=0: the patches sit on the fp32-storage path).
+    # G(a), written by sweep 2 and read only by the weight-gradient GEMMs:
+    "emu_ga": [
+        ("x3.h", "    if (P24) p24_store8(grow, kc, hi, v); else x3_store8(grow, kc, hi, v, kcs);\n    return 2;\n",
+         "    float q[8];\n    for (int u = 0; u < 8; ++u) q[u] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v[u]) + (1u << (X3_EMU_DROP - 1))) & ~((1u << X3_EMU_DROP) - 1u));\n"
+         "    x3_store8(grow, kc, hi, q, kcs);\n    return 2;\n"),
+    ],
+    # ... and abar (the d sdf/dx chain's store) and G(hbar) (sweep 1's), which sweep 2 re-reads for the second-order injection:
+    "emu_abar_gu": [
+        ("x3.h", "      stg4(abrow + kcs * kc + 4 * hi, f32x4{v[0], v[1], v[2], v[3]});\n      stg4(abrow + kcs * kc + 8 + 4 * hi, f32x4{v[4], v[5], v[6], v[7]});\n",
+         "      float q[8];\n      for (int u = 0; u < 8; ++u) q[u] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v[u]) + (1u << (X3_EMU_DROP - 1))) & ~((1u << X3_EMU_DROP) - 1u));\n"
+         "      stg4(abrow + kcs * kc + 4 * hi, f32x4{q[0], q[1], q[2], q[3]});\n      stg4(abrow + kcs * kc + 8 + 4 * hi, f32x4{q[4], q[5], q[6], q[7]});\n"),
+        ("x3.h", "    if (kc < KACC) { if (P24) p24_store8(gurow, kc, hi, v); else x3_store8(gurow, kc, hi, v, kcs); }\n",
+         "    float q[8];\n    for (int u = 0; u < 8; ++u) q[u] = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, v[u]) + (1u << (X3_EMU_DROP - 1))) & ~((1u << X3_EMU_DROP) - 1u));\n"
+         "    if (kc < KACC) x3_store8(gurow, kc, hi, q, kcs);\n"),
     ],
 }
 

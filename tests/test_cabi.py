@@ -262,3 +262,40 @@ def test_module_refuses_cpu_tensors():
     net = I2SDFNetwork(plumbing_conf())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net.implicit_network(torch.zeros(4, 3))
+
+
+def test_saved_to_point_major_decodes_packed_24_bit_records():
+    """I2SDF_OPT_SAVES24: the layout csrc/x3.h (p24_store8) documents, written as explicit loops by an independent encoder, decoded by
+    Engine.saved_to_point_major: every value comes back rounded to 16 significant bits (relative error <= 2^-16), layers not packed stay exact."""
+    import numpy as np
+    import torch
+    from i2sdf_amd.engine import RenderEngine as Engine
+    g = torch.Generator().manual_seed(5)
+    Lr, Mp = 2, 64
+    x = (torch.randn(Lr, Mp, 256, generator=g) * torch.exp(4 * torch.randn(Lr, Mp, 256, generator=g))).float()
+    x[0, 3, 7] = 0.0; x[0, 4, 9] = -0.0
+    buf = np.zeros((Lr, Mp * 256), dtype=np.uint32)
+    bits = x.numpy().view(np.uint32)
+    for m in range(Mp):
+        blk, p = m // 32, m % 32
+        for kc in range(16):
+            for hi in range(2):
+                cols = [16 * kc + 4 * hi + u for u in range(4)] + [16 * kc + 8 + 4 * hi + u for u in range(4)]
+                b = (bits[0, m, cols].astype(np.uint64) + 0x80).astype(np.uint32)          # layer 0 packed
+                for j in range(4):
+                    buf[0, blk * 6144 + kc * 384 + p * 8 + hi * 4 + j] = (b[2 * j] >> 16) | ((b[2 * j + 1] >> 16) << 16)
+                for j in range(2):
+                    w = 0
+                    for k in range(4):
+                        w |= ((int(b[4 * j + k]) >> 8) & 0xFF) << (8 * k)
+                    buf[0, blk * 6144 + kc * 384 + 256 + p * 4 + hi * 2 + j] = w
+                # layer 1: fp32, blocked
+                for u, c in enumerate(cols):
+                    buf[1, blk * 8192 + kc * 512 + p * 16 + (4 * hi + u if u < 4 else 8 + 4 * hi + u - 4)] = bits[1, m, c]
+    t = torch.from_numpy(buf.view(np.float32).reshape(Lr, Mp, 256).copy())
+    got = Engine.saved_to_point_major(t, Mp, [True, False])
+    assert torch.equal(got[1], x[1])
+    want = torch.from_numpy(((bits[0].astype(np.uint64) + 0x80).astype(np.uint32) & np.uint32(0xFFFFFF00)).view(np.float32))
+    assert torch.equal(got[0], want)
+    rel = ((got[0].double() - x[0].double()).abs() / x[0].double().abs().clamp_min(1e-300))[x[0] != 0]
+    assert float(rel.max()) <= 2.0 ** -16 * 1.0001

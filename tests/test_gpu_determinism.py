@@ -42,14 +42,14 @@ def test_kernels_are_bitwise_reproducible(bf16x3, parts, B):
         gflat = torch.zeros_like(flat)
         eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
         # saved tensors in point-major form (padding points of a blocked tile hold whatever their lanes computed: compare real points only)
-        pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]
+        pm = lambda name, t_, m_: eng.saved_pm(name, t_, m_)       # (decodes the packed 24-bit records of abars / gus / gas when I2SDF_OPT_SAVES24 is in effect)
         if parts == 0:
             assert B != 360 or eng.blocked_points(0, M, fwd["Mp"]) in (0, 256 * 128), "the batch must exercise bulk + split-K tail"
         else:
             assert eng.blocked_points(0, M, fwd["Mp"]) == fwd["Mp"], "point ranges: no tail, every saved row blocked"
-        cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": pm(fwd["hs"], 0, M), "abars": pm(fwd["abars"], 0, M),
-               "rgb": rgb_h, "rs": pm(rs, 1, B * n), "gar": pm(gar, 1, B * n), "fbar": fbar[:B * n], "gus": pm(bw["gus"], 0, M)[1:],
-               "gas": pm(bw["gas"], 0, M), "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
+        cur = {"sdf": fwd["sdf"], "feat": fwd["feat"][:M], "grad": fwd["grad"], "hs": pm("hs", fwd["hs"], M), "abars": pm("abars", fwd["abars"], M),
+               "rgb": rgb_h, "rs": pm("rs", rs, B * n), "gar": pm("gar", gar, B * n), "fbar": fbar[:B * n], "gus": pm("gus", bw["gus"], M)[1:],
+               "gas": pm("gas", bw["gas"], M), "sdf_only": eng.sdf_forward(x), "param_grads": gflat}
         if ref is None:
             ref = {k: v.clone() for k, v in cur.items()}
             continue
@@ -80,9 +80,9 @@ def test_tail_overlap_changes_nothing(bf16x3):
         fwd = eng.sdf_forward_grad(points=x)
         bw = eng.sdf_backward(fwd, sbar=sb, fbar=fb, m_fbar=B * n, nbar=nb)
         # consumers on the caller's stream right behind the entry points: they must see the tail's results
-        pm = lambda t_: eng.saved_to_point_major(t_, fwd["blk"])[:, :M]       # real points only (padding points of a blocked tile are never written)
-        return {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "hs": pm(fwd["hs"]),
-                "abars": pm(fwd["abars"]), "gus": pm(bw["gus"])[1:], "gas": pm(bw["gas"])}
+        pm = lambda name, t_: eng.saved_pm(name, t_, M)       # real points only (padding points of a blocked tile are never written)
+        return {"sdf": fwd["sdf"].clone(), "feat": fwd["feat"][:M].clone(), "grad": fwd["grad"].clone(), "hs": pm("hs", fwd["hs"]),
+                "abars": pm("abars", fwd["abars"]), "gus": pm("gus", bw["gus"])[1:], "gas": pm("gas", bw["gas"])}
 
     eng.set_tail_overlap(False)
     ref = run()
@@ -123,9 +123,9 @@ def test_point_ranges_change_nothing():
             gar, ga_last, fbar = eng.rgb_backward(rgb_h, cw, rs, B * n)
             bw = eng.sdf_backward(fwd, sbar=sb, fbar=fbar, m_fbar=B * n, nbar=nb)
             eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
-        pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]
-        out.update({"hs": pm(fwd["hs"], 0, M), "abars": pm(fwd["abars"], 0, M), "rs": pm(rs, 1, B * n), "gar": pm(gar, 1, B * n),
-                    "fbar": fbar[:B * n].clone(), "gus": pm(bw["gus"], 0, M)[1:], "gas": pm(bw["gas"], 0, M), "param_grads": gflat})
+        pm = lambda name, t_, m_: eng.saved_pm(name, t_, m_)
+        out.update({"hs": pm("hs", fwd["hs"], M), "abars": pm("abars", fwd["abars"], M), "rs": pm("rs", rs, B * n), "gar": pm("gar", gar, B * n),
+                    "fbar": fbar[:B * n].clone(), "gus": pm("gus", bw["gus"], M)[1:], "gas": pm("gas", bw["gas"], M), "param_grads": gflat})
         return out
 
     eng.set_parts(2)
@@ -159,7 +159,13 @@ def test_chain_protocol_errors():
         a = eng.sdf_forward_grad(points=x)
     eng.set_parts(0)
     b = eng.sdf_forward_grad(points=x)
-    assert torch.equal(a["sdf"], b["sdf"]) and torch.equal(a["grad"], b["grad"])
+    assert torch.equal(a["sdf"], b["sdf"])
+    if eng.saves24:
+        # with packed 24-bit records (I2SDF_OPT_SAVES24) the ranged run takes the d sdf/dx kernel's packing instantiation, the un-ranged one (fp32 storage:
+        # the option needs the ranges) the plain one: the same arithmetic, compiled separately -- equal to rounding, not bit for bit
+        assert float((a["grad"] - b["grad"]).abs().max()) <= 2e-6 * float(b["grad"].abs().max())
+    else:
+        assert torch.equal(a["grad"], b["grad"])
     torch.cuda.synchronize()
 
 
@@ -197,8 +203,8 @@ def test_chain_with_an_entry_point_off_the_ranged_path():
             gar, ga_last, fbar = eng.rgb_backward(rgb_h, cw, rs, B * n)
             bw = eng.sdf_backward(fwd, sbar=sb, fbar=fbar, m_fbar=B * n, nbar=nb)
             eng.weight_grads(flat, gflat, fwd, bw, M_main=B * n, fbar=fbar, rgb_fw={"pev": pev, "rs": rs}, rgb_bw={"gar": gar, "ga_last": ga_last})
-        pm = lambda t_, which, m_: eng.saved_to_point_major(t_, eng.blocked_points(which, m_, t_.shape[1]))[:, :m_]      # (padding rows are never written)
-        out.update({"fbar": fbar[:B * n].clone(), "gus": pm(bw["gus"], 0, M)[1:], "gas": pm(bw["gas"], 0, M), "param_grads": gflat})
+        pm = lambda name, t_, m_: eng.saved_pm(name, t_, m_)      # (padding rows are never written)
+        out.update({"fbar": fbar[:B * n].clone(), "gus": pm("gus", bw["gus"], M)[1:], "gas": pm("gas", bw["gas"], M), "param_grads": gflat})
         return out
 
     ref = run(False)

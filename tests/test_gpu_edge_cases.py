@@ -150,12 +150,27 @@ def _canary_engine(conf, sd):
     return eng
 
 
-def _poison_padding(t, M, blocked):
-    """NaN into rows M..Mp of a saved (layers, Mp, 256) tensor (rows in the blocked layout for the first `blocked` points)."""
+def _poison_padding(t, M, blocked, p24_layers=None):
+    """NaN into rows M..Mp of a saved (layers, Mp, 256) tensor (rows in the blocked layout for the first `blocked` points; layers flagged in
+    p24_layers hold packed 24-bit records, csrc/x3.h P24: the padding points' upper halves become 0x7fc0 = NaN, their mid bytes 0xff)."""
     Lr, Mp, H = t.shape
     if M >= Mp:
         return
     nan = float("nan")
+    if p24_layers is not None and any(p24_layers):
+        assert blocked >= Mp
+        nb = Mp // 32
+        for l in range(Lr):
+            if not p24_layers[l]:
+                _poison_padding(t[l:l + 1], M, blocked)
+                continue
+            raw = t[l].reshape(-1)[: nb * 6144].view(torch.int32).reshape(nb, 16, 384)
+            hi = raw[:, :, :256].reshape(nb, 16, 32, 8)       # [blk][kc][point][2 lanes x 4 dwords]
+            mid = raw[:, :, 256:].reshape(nb, 16, 32, 4)
+            b0 = M // 32
+            hi[b0, :, M % 32:] = 0x7fc07fc0; mid[b0, :, M % 32:] = -1
+            hi[b0 + 1:] = 0x7fc07fc0; mid[b0 + 1:] = -1
+        return
     if blocked >= Mp:
         v = t.view(Lr, Mp // 32, 16, 32, 16)
         b0 = M // 32
@@ -189,9 +204,11 @@ def test_padding_rows_may_be_written_but_nothing_beyond_them_and_nobody_reads_th
         Mp = fwd["Mp"]
         assert Mp == (M + 127) // 128 * 128
         blk_s, blk_r = eng.blocked_points(0, M, Mp), eng.blocked_points(1, M, Mp)
+        s24 = eng.saves24_points(M, Mp) == Mp          # abars / gus / gas as packed 24-bit records (gus: all layers but the unused slot 0 and the last)
+        nl = fwd["abars"].shape[0]
         if poison:
-            for t_ in (fwd["hs"], fwd["abars"]):
-                _poison_padding(t_, M, blk_s)
+            _poison_padding(fwd["hs"], M, blk_s)
+            _poison_padding(fwd["abars"], M, blk_s, [True] * nl if s24 else None)
             _poison_padding(rs, M, blk_r)
             fwd["feat"][M:] = float("nan"); fwd["pe"][M:] = float("nan"); pev[M:] = float("nan")
         gar, ga_last, fbar = eng.rgb_backward(rgb, cw, rs, M)
@@ -203,7 +220,8 @@ def test_padding_rows_may_be_written_but_nothing_beyond_them_and_nobody_reads_th
             fbar[M:] = float("nan"); ga_last[M:] = float("nan")
         bw = eng.sdf_backward(fwd, sbar=sw, fbar=fbar, m_fbar=M, nbar=nbar)
         if poison:
-            _poison_padding(bw["gus"], M, blk_s); _poison_padding(bw["gas"], M, blk_s)
+            _poison_padding(bw["gus"], M, blk_s, ([False] + [True] * (nl - 1) + [False]) if s24 else None)
+            _poison_padding(bw["gas"], M, blk_s, [True] * nl if s24 else None)
             for k in ("gpbar", "ga_last4", "ones4"):
                 bw[k][M:] = float("nan")
         gflat = torch.zeros_like(flat)

@@ -47,7 +47,7 @@ def test_sdf_forward_grad_and_saves(which):
     assert_close(out["sdf"].cpu(), fw["sdf"], TOL, "sdf")
     assert_close(out["feat"][:M].cpu(), fw["feat"], TOL, "feature")
     assert_close(out["grad"].cpu(), fw["n"], TOL, "d sdf/dx")
-    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_to_point_major(out["abars"], out["blk"])
+    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_pm("abars", out["abars"], out["abars"].shape[1])
     for l in range(L - 1):
         ref_h = orc.softplus100(fw["a"][l])
         w = ref_h.shape[1]
@@ -158,7 +158,7 @@ def test_sdf_forward_grad_split_k_tail(light, parts):
     assert_close(out["feat"].cpu()[idx], fw["feat"], TOL, "feature")
     assert_close(out["grad"].cpu()[idx], fw["n"], TOL, "d sdf/dx")
     assert_close(out["pe"].cpu()[idx][:, :39], fw["p"], 1e-6, "PE")
-    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_to_point_major(out["abars"], out["blk"])
+    hs_pm, ab_pm = eng.saved_to_point_major(out["hs"], out["blk"]), eng.saved_pm("abars", out["abars"], out["abars"].shape[1])
     assert out["blk"] in ((0, 256 * 128) if parts == 0 else (out["Mp"],)), "blocked prefix = the points of the full workgroups"
     for l in range(L - 1):
         ref_h = orc.softplus100(fw["a"][l])
