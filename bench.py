@@ -409,6 +409,12 @@ def main():
             extras["wgrad_bf16x3"] = sub(x3r, B, n_shaded, "the headline step with the weight-gradient GEMMs AND the sampler's sdf-only passes in bf16x3 too "
                                          "(I2SDF_OPT_WGRAD_BF16X2 and I2SDF_OPT_SAMPLER_BF16X2 off: three bf16 terms per operand, six products): fp32-equivalent "
                                          "arithmetic in EVERY kernel of the step -- the round-3 headline convention")
+        if getattr(eng, "saves24", False) and eng.wgrad_bf16x2:
+            # abars / G(hbar) / G(a) in fp32 storage, everything else as in the headline: what I2SDF_OPT_SAVES24 buys (round 6)
+            eng.set_saves24(False)
+            extras["saves_fp32"] = sub(wl.run(B, 1000 + rank, args.sampler_iters, K, W, windows=SW), B, n_shaded,
+                                       "headline step with abars / G(hbar) / G(a) of the SDF net stored as fp32 (I2SDF_OPT_SAVES24 off), everything else unchanged")
+            eng.set_saves24(True)
         if sx2:
             # the sampler's passes in the fp32-equivalent form, everything else as in the headline: what I2SDF_OPT_SAMPLER_BF16X2 buys (round 6)
             eng.set_sampler_bf16x2(False)
@@ -540,7 +546,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32" if not any_x3 else ("f32 (bf16x3 split MFMA: fp32 operands as 3 bf16 terms, fp32 accumulate"
                                                 + ("; the 256x256 weight-gradient GEMM blocks" + (" and the sampler's depth-choosing sdf-only passes" if getattr(eng, "sampler_bf16x2", False) else "")
-                                                   + ": 2 bf16 terms per operand, 3 products, fp32 accumulate -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
+                                                   + ": 2 bf16 terms per operand, 3 products, fp32 accumulate"
+                                                   + ("; the saved SDF tensors abar / G(hbar) / G(a) -- operands of those GEMMs and of the second-order injection -- stored with 16 "
+                                                      "significant bits in 3 bytes per value (saves_fp32: the same step with fp32 storage)" if getattr(eng, "saves24", False) else "")
+                                                   + " -- see wgrad_bf16x3 for the all-fp32-equivalent step)"
                                                    if eng.wgrad_bf16x2 else ")")),
             "data": "synthetic" if not mock else "mock (launch-logic self-test on the CPU stand-in core: value / ms_per_step carry NO throughput claim)",
             "config": {"workload": "synthetic.yml nets (8x256 SDF + 4x256 radiance, 800955 params), training step incl. sampler, loss, backward, Adam",

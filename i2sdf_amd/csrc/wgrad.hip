@@ -22,6 +22,9 @@ namespace {
 #ifndef W3_NT_LD
 #define W3_NT_LD 1
 #endif
+#ifndef W3_P24_NT
+#define W3_P24_NT 0      // the packed 24-bit operands' loads: plain (see w3p_job; A/B in profiles/r6_saves24.txt)
+#endif
 constexpr int WG_CH = I2SDF_WG_CH;   // points per split-M chunk (plan.h; plan.cpp: PART_ALIGN -- point ranges are cut at chunk boundaries)
 constexpr int PFW = 6;               // point pairs in flight
 constexpr int MAX_TASKS = 30;
@@ -695,8 +698,13 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
         const int64_t sblk = (int64_t)(sc >> 1) * P24_BLOCK;
         const char* sh = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 128) + voff[i];
         const char* sm = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 64) + voffm[i];
+#if W3_P24_NT
+        if (half == 0) { hlo[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh)); mlo[i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm)); }
+        else { hhi[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh + vnext)); mhi[i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm + vnext / 2)); }
+#else
         if (half == 0) { hlo[i] = *reinterpret_cast<const u32x2*>(sh); mlo[i] = *reinterpret_cast<const unsigned*>(sm); }
         else { hhi[i] = *reinterpret_cast<const u32x2*>(sh + vnext); mhi[i] = *reinterpret_cast<const unsigned*>(sm + vnext / 2); }
+#endif
       } else {
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
