@@ -145,7 +145,11 @@ void i2sdf_plan_destroy(i2sdf_plan* plan);
 /* number of leading points (a multiple of 32) of a batch whose saved tensors are blocked under the current options: which = 0
  * hs / abars / gus / gas of an i2sdf_sdf_forward_grad batch of M points (has_feat: feat != NULL in that call), which = 1 rs / gar
  * of an i2sdf_rgb_forward batch.  Element (point m < that count, column c) of a blocked (Mp,256) tensor lives at float offset
- * (m/32)*8192 + (c/16)*512 + (m%32)*16 + c%16; points behind the count are ordinary rows m*256 + c. */
+ * (m/32)*8192 + (c/16)*512 + (m%32)*16 + c%16; points behind the count are ordinary rows m*256 + c.
+ * which = 2: the leading points whose abars / gus / gas are packed 24-bit records under the current options (I2SDF_OPT_SAVES24: Mp -- every point --
+ * or 0).  A packed layer holds, per 32-point block (6144 floats, dense) and 16-column k-chunk (384 floats): 32 x 2 x 4 dwords of upper halves
+ * (lane hi = 0, 1 of point p at dword p*8 + hi*4; value u of that lane = column 4 hi + u for u < 4, 8 + 4 hi + u - 4 for u >= 4; two values per dword)
+ * and, from dword 256 on, 32 x 2 x 2 dwords of mid bytes (four per dword); value = upper half << 16 | mid byte << 8.  The top layer of gus stays fp32. */
 int64_t i2sdf_blocked_points(const i2sdf_plan* plan, int32_t which, int64_t M, int64_t Mp, int32_t has_feat);
 int i2sdf_plan_set_option(i2sdf_plan* plan, int32_t option, int32_t value);
 /* A chain (I2SDF_OPT_PARTS): the per-point entry points called between begin and end leave their point ranges un-joined.

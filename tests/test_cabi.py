@@ -221,12 +221,27 @@ def test_new_plan_options_and_blocked_prefix(lib):
     for n in (0, 1):                                            # 0 / 1 = off: back to full rounds + split-K tail
         assert h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, n) == 0
         assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == bulk
+    # round 6, I2SDF_OPT_SAVES24: packed 24-bit records of abars / gus / gas take effect only with point ranges + blocked saves + the bf16x3 families
+    # + the two-plane weight gradients all on (which = 2: Mp or 0)
+    assert h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0                       # option off
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SAVES24, 1) == 0
+    assert h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0                       # no point ranges, no two-plane weight gradients
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_PARTS, 2) == 0
+    assert h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0                       # still the fp32-equivalent weight gradients: fp32 storage
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_WGRAD_BF16X2, 1) == 0
+    assert h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == Mp and h.i2sdf_blocked_points(plan, 2, M2, Mp2, 1) == Mp2
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 0) == 0 and h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SDF_BWD_BF16X3, 0) == 0 and h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SDF_BWD_BF16X3, 1) == 0
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SAVES24, 0) == 0 and h.i2sdf_blocked_points(plan, 2, M, Mp, 1) == 0
     h.i2sdf_plan_destroy(plan)
     rc, plan, _, _ = _plan(lib, plumbing_conf())                # 64-wide nets have no bf16x3 train path: nothing is blocked
     assert rc == 0
     h.i2sdf_plan_set_option(plan, lib.OPT_BLOCKED_SAVES, 1)
     assert h.i2sdf_blocked_points(plan, 0, M, Mp, 1) == 0
     assert h.i2sdf_plan_set_option(plan, lib.OPT_SAMPLER_BF16X2, 1) == -1      # the two-plane sampler stream exists for 256-wide nets only
+    assert h.i2sdf_plan_set_option(plan, lib.OPT_SAVES24, 1) == -1             # ... and so do the packing kernels
     h.i2sdf_plan_destroy(plan)
 
 

@@ -150,6 +150,7 @@ def test_chain_protocol_errors():
     assert h.i2sdf_chain_begin(plan, 50000, st) == 0
     assert h.i2sdf_chain_begin(plan, 50000, st) == -1                         # no nesting
     assert h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 3) == -1                # not inside a chain
+    assert h.i2sdf_plan_set_option(plan, L.OPT_SAVES24, 0) == -1              # nor the storage format of the tensors in flight
     assert h.i2sdf_chain_fence(plan, st) == 0
     assert h.i2sdf_chain_end(plan, st) == 0
     assert h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 3) == 0 and h.i2sdf_plan_set_option(plan, L.OPT_PARTS, 2) == 0
