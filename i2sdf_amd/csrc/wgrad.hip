@@ -22,6 +22,11 @@ namespace {
 #ifndef W3_NT_LD
 #define W3_NT_LD 1
 #endif
+// raw-row register sets of the 256x256 body: 1 = a pair's registers are refilled with the rows of stage s+2 while stage s runs (one stage in flight);
+// 2 = two sets, refilled with stage s+3 (two stages in flight; +24-32 VGPRs) -- the kernel keeps ~56 VGPRs free
+#ifndef W3_RAW_SETS
+#define W3_RAW_SETS 1
+#endif
 #ifndef W3_P24_NT
 #define W3_P24_NT 0      // the packed 24-bit operands' loads: plain (see w3p_job; A/B in profiles/r6_saves24.txt)
 #endif
@@ -688,10 +693,12 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
     }
     const float relu_lo = (opB && t.relu_b != 0) ? 0.f : -3.0e38f;
     const float bias_w = (!opB && t.has_bias != 0 && jb == 0) ? 1.f : 0.f;
-    f32x4 rlo[P24 ? 1 : 4], rhi[P24 ? 1 : 4];
-    u32x2 hlo[P24 ? 4 : 1], hhi[P24 ? 4 : 1];           // P24: upper halves of the pair's two rows (values 0,1 | 2,3 of the quad) ...
-    unsigned mlo[P24 ? 4 : 1], mhi[P24 ? 4 : 1];        // ... and their four mid bytes
-    auto gload = [&](int s, int i, int half) __attribute__((always_inline)) {
+    constexpr int RS = W3_RAW_SETS;                     // register sets of raw rows (set of stage s: s % RS)
+    f32x4 rlo[RS][P24 ? 1 : 4], rhi[RS][P24 ? 1 : 4];
+    u32x2 hlo[RS][P24 ? 4 : 1], hhi[RS][P24 ? 4 : 1];           // P24: upper halves of the pair's two rows (values 0,1 | 2,3 of the quad) ...
+    unsigned mlo[RS][P24 ? 4 : 1], mhi[RS][P24 ? 4 : 1];        // ... and their four mid bytes
+    // (st = the register set, a constant at every call site: s % RS of the stage loaded)
+    auto gload = [&](int st, int s, int i, int half) __attribute__((always_inline)) {
       const int sc = s < nst ? s : nst - 1;     // (the stream below prefetches ahead without a branch)
       if constexpr (P24) {
         // plain loads: the eight instructions of a stage touch every 128-B line of the quarter twice (8-B / 4-B pieces of 32-B / 16-B point records)
@@ -699,32 +706,32 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
         const char* sh = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 128) + voff[i];
         const char* sm = reinterpret_cast<const char*>(ubase + sblk + (sc & 1) * 64) + voffm[i];
 #if W3_P24_NT
-        if (half == 0) { hlo[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh)); mlo[i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm)); }
-        else { hhi[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh + vnext)); mhi[i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm + vnext / 2)); }
+        if (half == 0) { hlo[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh)); mlo[st][i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm)); }
+        else { hhi[st][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(sh + vnext)); mhi[st][i] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(sm + vnext / 2)); }
 #else
-        if (half == 0) { hlo[i] = *reinterpret_cast<const u32x2*>(sh); mlo[i] = *reinterpret_cast<const unsigned*>(sm); }
-        else { hhi[i] = *reinterpret_cast<const u32x2*>(sh + vnext); mhi[i] = *reinterpret_cast<const unsigned*>(sm + vnext / 2); }
+        if (half == 0) { hlo[st][i] = *reinterpret_cast<const u32x2*>(sh); mlo[st][i] = *reinterpret_cast<const unsigned*>(sm); }
+        else { hhi[st][i] = *reinterpret_cast<const u32x2*>(sh + vnext); mhi[st][i] = *reinterpret_cast<const unsigned*>(sm + vnext / 2); }
 #endif
       } else {
       const int64_t soff = blk ? (int64_t)(sc >> 1) * 8192 + (sc & 1) * 256 : (int64_t)sc * W3_PTS * dld;
       const char* src = reinterpret_cast<const char*>(ubase + soff) + voff[i];
 #if W3_NT_LD
-      if (half == 0) rlo[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-      else rhi[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + vnext));
+      if (half == 0) rlo[st][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+      else rhi[st][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + vnext));
 #else
-      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);
-      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);
+      if (half == 0) rlo[st][i] = *reinterpret_cast<const f32x4*>(src);
+      else rhi[st][i] = *reinterpret_cast<const f32x4*>(src + vnext);
 #endif
       }
     };
     // raw value of tile tt (a constant after unrolling) of the pair's first / second row
-    auto raw_lo = [&](int i, int tt) __attribute__((always_inline)) -> float {
-      if constexpr (P24) return p24_quad_value(hlo[i], mlo[i], tt);
-      else return rlo[i][tt];
+    auto raw_lo = [&](int st, int i, int tt) __attribute__((always_inline)) -> float {
+      if constexpr (P24) return p24_quad_value(hlo[st][i], mlo[st][i], tt);
+      else return rlo[st][i][tt];
     };
-    auto raw_hi = [&](int i, int tt) __attribute__((always_inline)) -> float {
-      if constexpr (P24) return p24_quad_value(hhi[i], mhi[i], tt);
-      else return rhi[i][tt];
+    auto raw_hi = [&](int st, int i, int tt) __attribute__((always_inline)) -> float {
+      if constexpr (P24) return p24_quad_value(hhi[st][i], mhi[st][i], tt);
+      else return rhi[st][i][tt];
     };
     unsigned pl[4][NPL][4];               // planes of the quarter being split: [tile][plane][point pair]
     // values of tile tt of point pair i (rows 2i, 2i+1 of this lane's 8) of stage s: mask / relu
@@ -742,9 +749,9 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
     auto plane = [&](int so, int quarter, int tile, int p) __attribute__((always_inline)) -> u32x4 {
       return *reinterpret_cast<const u32x4*>(plb + so + quarter * (4 * 3 * 256) + (tile * 3 + p) * 256 + lane * 4);
     };
-    auto load_all = [&](int s) __attribute__((always_inline)) {
+    auto load_all = [&](int st, int s) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { gload(s, i, 0); gload(s, i, 1); }
+      for (int i = 0; i < 4; ++i) { gload(st, s, i, 0); gload(st, s, i, 1); }
     };
     auto split_all = [&](int s) __attribute__((always_inline)) {          // rows of stage s (in rlo / rhi) -> pl, up front (job prologue)
 #pragma unroll
@@ -752,7 +759,7 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           float x0, x1;
-          prep(s, i, raw_lo(i, tt), raw_hi(i, tt), x0, x1);
+          prep(s, i, raw_lo(0, i, tt), raw_hi(0, i, tt), x0, x1);       // (stage 0: set 0)
           bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]);
           if (NPL == 3) split3_pair(x0, x1, pl[tt][0][i], pl[tt][1][i], pl[tt][NPL - 1][i]);
           else split2_pair(x0, x1, pl[tt][0][i], pl[tt][1][i]);
@@ -767,10 +774,11 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
     };
     constexpr int NQ = (NPL == 3 ? 6 : 3), PH = 4 * NQ, NM = 4 * PH, GPI = NM / 16;     // MFMAs per phase / stage, units per item
     using BT = std::integral_constant<bool, true>; using BF = std::integral_constant<bool, false>;
-    load_all(0);
+    load_all(0, 0);
     __syncthreads();                       // the previous job is done with LDS
     split_all(0);                          // stage 0 is split up front
-    load_all(1);
+    load_all(1 % RS, 1);
+    if (RS == 2) load_all(0, 2);           // (two sets: stage 2 into the set stage 0 has left)
     write_all(0);
     // ---- two plane slots.  MORE: stage s+1 exists: its raw rows (in rlo / rhi) are split here, and each point pair's registers are
     // refilled with the rows of stage s+2 as soon as the pair has been consumed (most of a stage ahead of their use)
@@ -781,6 +789,7 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
     auto stage = [&](int s, auto Mc, auto Pc) __attribute__((always_inline)) {
       constexpr bool MORE = decltype(Mc)::value;
       constexpr int so0 = decltype(Pc)::value * W3P_PL, so1 = W3P_PL - so0;
+      constexpr int NX = (decltype(Pc)::value + 1) % RS;      // register set of stage s + 1 (s has the parity Pc); refilled with stage s + 1 + RS
       __syncthreads();   // planes(s) written, everyone done with stage s-1
       u32x4 ap[4][NPL], bp[2][NPL];
       // the opening plane loads in the order of their first use (products (0,0) (0,1) (1,0) (0,2) (2,0) (1,1)): the first MFMA
@@ -803,7 +812,7 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
         if (MORE) {
           // split item `it` = (point pair i, tile tt): pair i is split during phase i from the raw rows fetched in phase i-1
           const int it = g / GPI, st = g % GPI, i = it / 4, tt = it % 4;
-          if (st == 0) prep(s + 1, i, raw_lo(i, tt), raw_hi(i, tt), x0, x1);
+          if (st == 0) prep(s + 1, i, raw_lo(NX, i, tt), raw_hi(NX, i, tt), x0, x1);
           if (st == 1) { pl[tt][0][i] = pk_bf16(x0, x1); bsum[tt] = fmaf(x0 + x1, bias_w, bsum[tt]); }
           if (NPL == 3) {
             if (st == 2) { ra = x0 - bf16_lo(pl[tt][0][i]); rb = x1 - bf16_hi(pl[tt][0][i]); }
@@ -815,8 +824,8 @@ __device__ __forceinline__ void w3p_job(const WgTask& t, const WgJob& job, int j
           }
           // the planes of tile tt are complete once pair 3 has been split: they are written in the units of the next item
           if (it >= 13 && st < NPL) write_tile(so1, tt - 1, st);
-          if (tt == 3 && st == 1) gload(s + 2, i, 0);          // the pair's last value was taken in the previous unit
-          if (tt == 3 && st == 2) gload(s + 2, i, 1);
+          if (tt == 3 && st == 1) gload(NX, s + 1 + RS, i, 0);          // the pair's last value was taken in the previous unit
+          if (tt == 3 && st == 2) gload(NX, s + 1 + RS, i, 1);
         }
         // LDS reads of the next phase, one instruction per unit, half a phase ahead
         if (tb < 3 && gg >= PH / 2 && gg < PH / 2 + NPL) bp[(tb + 1) & 1][gg - PH / 2] = plane(so0, 2 + wb, tb + 1, gg - PH / 2);
