@@ -44,8 +44,8 @@ PATCHES = {
     ],
     # ... and the 256x256 weight-gradient kernel without its operand loads (pure split + MFMA + partial-sum flush)
     "wgrad3p_no_loads": [
-        ("wgrad.hip", "      if (half == 0) rlo[i] = *reinterpret_cast<const f32x4*>(src);\n      else rhi[i] = *reinterpret_cast<const f32x4*>(src + vnext);\n",
-         "      (void)src;\n      if (half == 0) rlo[i] = f32x4{1.f + s, 2.f, 3.f, 4.f};\n      else rhi[i] = f32x4{0.5f, 0.25f + s, 0.125f, 2.5f};\n"),
+        ("wgrad.hip", "      if (half == 0) rlo[st][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));\n      else rhi[st][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + vnext));\n",
+         "      (void)src;\n      if (half == 0) rlo[st][i] = f32x4{1.f + s, 2.f, 3.f, 4.f};\n      else rhi[st][i] = f32x4{0.5f, 0.25f + s, 0.125f, 2.5f};\n"),
     ],
     # round 6 (VERDICT r5 task 2b): NUMERICAL gates by emulation -- the stored tensor keeps its fp32 slot, but the value written has its low
     # X3_EMU_DROP mantissa bits rounded away (-- -DX3_EMU_DROP=8: a 24-bit format; 13: an fp16 significand with an ideal scale; 16: bf16).
