@@ -8,12 +8,13 @@ mkdir -p ../lib ../lib/obj
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -Wno-unused-result"
 X3FLAGS="-mllvm -pragma-unroll-threshold=1000000"     # only where the bf16x3 training kernels live
 pids=()
-for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip mlp_x3.hip mlp_x3h.hip render.hip mlp_bwd.hip wgrad.hip sampler.hip loss.hip optim.hip grid.hip draws.hip "$@"; do
+for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip mlp_x3.hip mlp_x3p.hip mlp_x3h.hip render.hip mlp_bwd.hip wgrad.hip sampler.hip loss.hip optim.hip grid.hip draws.hip "$@"; do
   o=../lib/obj/$(basename ${f%.*}).o
   stale=0
   for h in "$f" *.h ../../include/i2sdf.h build.sh; do [ "$h" -nt "$o" ] && stale=1; done
   if [ ! -f "$o" ] || [ $stale = 1 ]; then
     extra=""; [ "$f" = mlp_x3.hip ] && extra="$X3FLAGS"
+    [ "$f" = mlp_x3p.hip ] && extra="$X3FLAGS"          # (the packing instantiations of mlp_x3.hip's kernels: same flags)
     # wgrad.hip: the hand-placed stage of wgrad3p_body is a 96-unit unrolled loop whose scalar ops must stay where they are written
     [ "$f" = wgrad.hip ] && extra="$X3FLAGS -fno-slp-vectorize"
     # mlp_x3h.hip: one fenced unit per MFMA (x3h.h); packed f32 VALU ops beside MFMAs are slower than the scalar ones they replace

@@ -252,6 +252,18 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
 
 }  // namespace
 
+// The packing instantiations (I2SDF_OPT_SAVES24: abars / gus / gas as packed 24-bit records) are compiled in a SECOND translation unit, mlp_x3p.hip, which
+// includes this file with I2SDF_X3_P24_TU defined: the three kernels with and without packing in one unit took hipcc 8 minutes, single-threaded; as two
+// units the build stays at ~4.5 minutes (build.sh compiles the units in parallel).
+#ifdef I2SDF_X3_P24_TU
+void i2sdf_launch_igrad3_p24(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) { launch_lds(sdf_igrad3_kernel<256, 6, true, true>, grid, st, a); }
+void i2sdf_launch_sdf_bwd3_p24(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
+  launch_lds(sdf_bwd3_sweep1_kernel<256, 6, true>, grid, st, a);
+  launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6, true>, grid, st, a);
+}
+#else
+void i2sdf_launch_igrad3_p24(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st);      // mlp_x3p.hip
+void i2sdf_launch_sdf_bwd3_p24(const SdfBwdArgs& a, unsigned grid, hipStream_t st);
 // 64-wide nets only: the 256-wide sdf-only forward runs on 16-point waves (mlp_x3h.hip)
 void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int skip, const PointSpec& ps, const int* skip_flag, int64_t M,
                            float* sdf_out, unsigned grid, hipStream_t st) {
@@ -259,16 +271,13 @@ void i2sdf_launch_sdf_fwd3(int H, const float* stream, int n_stages, int L, int 
   launch_lds(sdf_fwd3_kernel<64, 6>, grid, st, stream, n_stages, L, skip, ps, skip_flag, M, sdf_out);
 }
 void i2sdf_launch_igrad3(const SdfTrainFwdArgs& a, unsigned grid, hipStream_t st) {
-  if (a.abars && a.p24) launch_lds(sdf_igrad3_kernel<256, 6, true, true>, grid, st, a);
+  if (a.abars && a.p24) i2sdf_launch_igrad3_p24(a, grid, st);
   else if (a.abars) launch_lds(sdf_igrad3_kernel<256, 6, true>, grid, st, a);
   else launch_lds(sdf_igrad3_kernel<256, 6, false>, grid, st, a);
 }
 void i2sdf_launch_sdf_bwd3(const SdfBwdArgs& a, unsigned grid, hipStream_t st) {
-  if (a.p24) {
-    launch_lds(sdf_bwd3_sweep1_kernel<256, 6, true>, grid, st, a);
-    launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6, true>, grid, st, a);
-    return;
-  }
+  if (a.p24) { i2sdf_launch_sdf_bwd3_p24(a, grid, st); return; }
   launch_lds(sdf_bwd3_sweep1_kernel<256, 6>, grid, st, a);
   launch_lds(sdf_bwd3_sweep2_kernel<256, 256, 6>, grid, st, a);
 }
+#endif

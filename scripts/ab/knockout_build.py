@@ -70,7 +70,7 @@ PATCHES = {
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-Wno-unused-result"]
 X3 = ["-mllvm", "-pragma-unroll-threshold=1000000"]
-EXTRA = {"mlp_x3.hip": X3, "mlp_x3h.hip": X3 + ["-fno-slp-vectorize"], "wgrad.hip": X3 + ["-fno-slp-vectorize"]}
+EXTRA = {"mlp_x3.hip": X3, "mlp_x3p.hip": X3, "mlp_x3h.hip": X3 + ["-fno-slp-vectorize"], "wgrad.hip": X3 + ["-fno-slp-vectorize"]}
 
 
 def main():

@@ -14,6 +14,7 @@ for f in "$@"; do
   base=$(basename ${f%.*})
   skip="$skip /$base.o"
   fx=""; [ "$f" = mlp_x3.hip ] && fx="$X3FLAGS"
+  [ "$f" = mlp_x3p.hip ] && fx="$X3FLAGS"
   [ "$f" = mlp_x3h.hip ] && fx="$X3FLAGS -fno-slp-vectorize"
   [ "$f" = wgrad.hip ] && fx="$X3FLAGS -fno-slp-vectorize"
   ( hipcc $FLAGS $fx $extra -x hip -c "$f" -o ../lib/ab/$name/$base.o ) &

@@ -51,8 +51,8 @@ def _kernels_of(obj, tmp):
 def test_hot_kernels_stay_inside_their_register_budget(tmp_path):
     if not os.path.isdir(OBJ) or not all(os.path.exists(f"{LLVM}/{t}") for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
         pytest.skip("no in-tree build (i2sdf_amd/lib/obj) or no LLVM binutils")
-    objs = [o for o in glob.glob(os.path.join(OBJ, "*.o")) if os.path.basename(o) in ("mlp_x3.o", "mlp_x3h.o", "wgrad.o")]
-    if len(objs) < 3:
+    objs = [o for o in glob.glob(os.path.join(OBJ, "*.o")) if os.path.basename(o) in ("mlp_x3.o", "mlp_x3p.o", "mlp_x3h.o", "wgrad.o")]      # (mlp_x3p: the packing instantiations of mlp_x3's kernels)
+    if len(objs) < 4:
         pytest.skip("in-tree objects missing: run __graft_entry__.build()")
     newest_src = max(os.path.getmtime(f) for f in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")))
     if any(os.path.getmtime(o) < newest_src for o in objs):
@@ -66,3 +66,7 @@ def test_hot_kernels_stay_inside_their_register_budget(tmp_path):
                     assert res["scratch"] <= max_scratch, f"{name}: {res['scratch']} B of scratch per lane (budget {max_scratch}): {res}"
                     assert res["vgpr"] <= max_vgpr, (name, res)
     assert seen == set(BUDGET), f"kernels not found in the build: {set(BUDGET) - seen}"
+    # the packing instantiations (I2SDF_OPT_SAVES24) live in mlp_x3p.o: they must be there, under the same budget (checked by name fragment above)
+    packed = _kernels_of(os.path.join(OBJ, "mlp_x3p.o"), str(tmp_path))
+    for frag in ("sdf_igrad3_kernel", "sdf_bwd3_sweep1_kernel", "sdf_bwd3_sweep2_kernel"):
+        assert any(frag in n for n in packed), f"{frag}: no packing instantiation in mlp_x3p.o"

@@ -163,6 +163,20 @@ def test_stage_barriers_of_the_16_point_kernels(tmp_path):
     _check_counted_barriers(_bodies(text), KERNELS_H, True, min_barriers=8)
 
 
+def test_stage_barriers_of_the_packing_instantiations(tmp_path):
+    """The same invariant on mlp_x3p.o: the d sdf/dx chain and the sweeps with packed 24-bit records of abars / gus / gas (I2SDF_OPT_SAVES24; x3.h P24) -- a
+    16-B + an 8-B access per tensor and k-chunk where the fp32 form has two 16-B ones, so the sources' instruction counts are unchanged.  In-tree object only."""
+    text = _disassemble_in_tree(str(tmp_path), os.path.join(ROOT, "i2sdf_amd", "lib", "obj", "mlp_x3p.o"), "mlp_x3.hip")
+    if text is None:
+        pytest.skip("no fresh in-tree mlp_x3p.o: run __graft_entry__.build()")
+    bodies = _bodies(text)
+    assert not any("sdf_fwd3_kernel" in n for n in bodies), "mlp_x3p.o holds the packing instantiations only"
+    _check_counted_barriers(bodies, KERNELS, True)
+    for key in KERNELS:
+        for m in re.finditer(r"\.name:\s+(\S*%s\S*)\n(?:.*\n){0,12}?\s+\.private_segment_fixed_size:\s+(\d+)" % key, text):
+            assert int(m.group(2)) == 0, (m.group(1), m.group(2))
+
+
 def test_no_scratch_in_the_counted_kernels(isa):
     isa = isa[0]
     for key in KERNELS:
