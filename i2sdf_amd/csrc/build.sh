@@ -12,6 +12,7 @@ for f in plan.cpp comm.cpp render_image.cpp pack.hip mlp_fwd.hip mlp_train.hip m
   o=../lib/obj/$(basename ${f%.*}).o
   stale=0
   for h in "$f" *.h ../../include/i2sdf.h build.sh; do [ "$h" -nt "$o" ] && stale=1; done
+  [ "$f" = mlp_x3p.hip ] && [ mlp_x3.hip -nt "$o" ] && stale=1          # (mlp_x3p.hip is mlp_x3.hip with I2SDF_X3_P24_TU)
   if [ ! -f "$o" ] || [ $stale = 1 ]; then
     extra=""; [ "$f" = mlp_x3.hip ] && extra="$X3FLAGS"
     [ "$f" = mlp_x3p.hip ] && extra="$X3FLAGS"          # (the packing instantiations of mlp_x3.hip's kernels: same flags)

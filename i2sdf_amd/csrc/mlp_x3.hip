@@ -203,8 +203,10 @@ __global__ __launch_bounds__(256) void sdf_bwd3_sweep2_kernel(SdfBwdArgs a) {
   const int64_t lstride = a.Mp * H;
   const int kcs = a.kcs;
   const int64_t mrow = save_row_off(m, kcs), mcrow = save_row_off(mc, kcs);     // this point's row in the saved tensors
-  // rows of gus / abars (read: the clamped point) and gas (written: this point, padding rows included) -- fp32 blocked or packed 24-bit records
-  const int64_t srow = P24 ? p24_row_off(mc) : mcrow, wrow = P24 ? p24_row_off(m) : mrow;
+  // rows of gus / abars (read) and gas (written: this point, padding rows included) -- fp32 blocked or packed 24-bit records.  fp32 rows are read at the CLAMPED
+  // point; packed rows at the lane's OWN point, padding lanes included: p24_load8 / p24_store8 address the mid-byte part through the lane's index in its 32-point
+  // block (threadIdx.x & 31 == m & 31), and the padding rows of abars / gus exist and hold what the producers' padding lanes wrote (unconditional stores, Mp rows)
+  const int64_t srow = P24 ? p24_row_off(m) : mcrow, wrow = P24 ? p24_row_off(m) : mrow;
   const float sb = a.sbar ? a.sbar[mc] : 0.f;
   if (valid && hi == 0) {
     *reinterpret_cast<f32x4*>(a.ga_last4 + m * 4) = f32x4{sb, 0.f, 0.f, 0.f};
